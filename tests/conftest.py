@@ -1,0 +1,43 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_mesh(name):
+    v = np.fromfile(os.path.join(GOLDEN, name + "_verts.f32"), dtype="<f4").reshape(-1, 3)
+    t = np.fromfile(os.path.join(GOLDEN, name + "_tets.i32"), dtype="<i4").reshape(-1, 4)
+    return v, t
+
+
+def load_f32(name):
+    return np.fromfile(os.path.join(GOLDEN, name), dtype="<f4")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        g = json.load(f)
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        cases = {c["name"]: c for c in json.load(f)}
+    return g["cases"], cases
+
+
+def sha16(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<f4").tobytes()).hexdigest()[:16]
+
+
+def case_dt(case):
+    return (case["timeScale"] * case["timeStep"]) / case["numSubsteps"]  # f64, as main.js:79

@@ -1,0 +1,71 @@
+"""Pins the CPU oracle (oracle/tetsim_oracle.c, section A) to the REFERENCE: bit-exact equality with
+golden vectors recorded by importing /root/reference/src/Softbody.js under Node (tests/golden/make_golden.*)."""
+import numpy as np
+import pytest
+
+from conftest import case_dt, load_f32, load_mesh, sha16
+from oracle import OracleNH
+
+CASES = ["dragon", "dragon_sub5", "dragon_grab", "dragon_soft", "lat4", "lat4c", "lat2degen", "notets"]
+
+
+@pytest.mark.parametrize("mesh", ["dragon", "lat4", "lat4c", "lat2degen"])
+def test_init_physics_bit_exact(mesh, golden):
+    v, t = load_mesh(mesh)
+    o = OracleNH(v, t, {"density": 1000.0})
+    assert np.array_equal(o.invMass.view(np.uint32), load_f32(mesh + "_invMass.f32").view(np.uint32))
+    assert np.array_equal(o.invRestPose.view(np.uint32), load_f32(mesh + "_invRestPose.f32").view(np.uint32))
+    assert np.array_equal(o.invRestVolume.view(np.uint32), load_f32(mesh + "_invRestVolume.f32").view(np.uint32))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_trajectory_bit_exact(name, golden):
+    gold, cases = golden
+    c, g = cases[name], gold[name]
+    if name == "dragon":
+        nsteps = 600  # the 1200-substep hash is covered by test_dragon_long
+    else:
+        nsteps = c["nsteps"]
+    v, t = load_mesh(c["mesh"])
+    o = OracleNH(v, t, c["params"])
+    dt = case_dt(c)
+    assert dt == g["dt"]
+    grab_ids = []
+    for step in range(1, nsteps + 1):
+        for ev in c["grab"]:
+            if ev["at"] != step:
+                continue
+            if ev["op"] == "start":
+                grab_ids.append(o.startGrab(*ev["p"]))
+            elif ev["op"] == "move":
+                o.moveGrabbed(*ev["p"])
+            else:
+                o.endGrab()
+        o.simulate(dt, c["params"])
+        key = str(step)
+        if key in g["steps"]:
+            gs = g["steps"][key]
+            assert sha16(o.pos) == gs["pos"], (name, step)
+            assert sha16(o.vel) == gs["vel"], (name, step)
+            assert sha16(o.prevPos) == gs["prev"], (name, step)
+            if gs["volError"] is not None:
+                assert o.volError == gs["volError"], (name, step)
+            else:
+                assert np.isnan(o.volError)
+        if step in c["dumps"]:
+            assert np.array_equal(o.pos.ravel().view(np.uint32), load_f32(f"{name}_pos_{step}.f32").view(np.uint32))
+            assert np.array_equal(o.vel.ravel().view(np.uint32), load_f32(f"{name}_vel_{step}.f32").view(np.uint32))
+    assert grab_ids == g["grabIds"]
+
+
+def test_dragon_long(golden):
+    """1200 substeps (2 s of simulated time incl. floor contact): SURVEY.md §8(c) known answer."""
+    gold, cases = golden
+    c, g = cases["dragon"], gold["dragon"]
+    v, t = load_mesh("dragon")
+    o = OracleNH(v, t, c["params"])
+    dt = case_dt(c)
+    for _ in range(1200):
+        o.simulate(dt, c["params"])
+    assert sha16(o.pos) == g["steps"]["1200"]["pos"] == "9f52c76cdd7223f0"
+    assert float(np.sum(o.pos.ravel().astype(np.float64))) == pytest.approx(g["steps"]["1200"]["sumPos"], rel=1e-12)
