@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: M tet-solves/s on the 1 M-tet Kuhn lattice, polar-decomposition Jacobi,
+20 substeps per frame, on N MI355X (BASELINE.json metric; SURVEY.md §8(d) config 3, config 5 shape for N>1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one animation frame of the reference's driver loop (main.js:79-84): 20 substeps of the hot path
+over the whole body, issued as ONE tetsim_step_n call (one HIP-graph launch).  All state is resident in HBM
+before the timed region; nothing is read back inside it.  N > 1: weak scaling -- the lattice is stacked to
+55 x 55 x 55N cells, slab-partitioned along z (one slab, ~1 M tets, per GPU), ghost-vertex positions cross
+xGMI once per substep through RCCL send/recv issued by libtetsim_hip itself.
+
+The JSON line carries two extra objects:
+  roofline      the dominant kernel (pj_tet_kernel, P3+P4 of the reference) against HBM peak.  `achieved` =
+                algorithmic bytes per launch / mean launch duration measured here with HIP events on the
+                handle's own stream.  Bytes per tet are SURVEY.md §8(d)'s tet row (148 B) -- see DESIGN.md.
+  cpu_baseline  the CPU restatement (oracle/, "port") of the same algorithm on this host's cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SUBSTEPS = 20
+CELLS = 55
+PP = dict(gravity=-9.81, timeScale=1.0, timeStep=1.0 / 60.0, numSubsteps=SUBSTEPS, friction=1000.0,
+          density=1000.0, devCompliance=1.0 / 100000.0, volCompliance=0.0,
+          worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+DT = (PP["timeScale"] * PP["timeStep"]) / PP["numSubsteps"]  # main.js:79
+
+# SURVEY.md §8(d), reference formulation (world-space lastRest carried forward), per tet per substep:
+# idx 16 R + lastRest 48 R + 48 W + quat 16 R + 16 W + restVol 4 R.
+TET_KERNEL_BYTES = 148.0
+VERTEX_BYTES = 144.0           # per particle per substep (integrate/accumulate/finalize rows)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(verts, tets):
+    """Time the CPU restatement of the SAME algorithm (oracle section G) on this host, bounded to ~15 s."""
+    from oracle import OraclePJ, max_threads, set_threads
+    cores = max_threads()
+    set_threads(cores)
+    o = OraclePJ(verts, tets, PP, slot_quirk=True)
+    t0 = time.perf_counter()
+    o.simulate(DT, PP)
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(SUBSTEPS, round(15.0 / max(t1, 1e-3)))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o.simulate(DT, PP)
+    dt = time.perf_counter() - t0
+    res = {"value": round(len(tets) * n / dt / 1e6, 3), "unit": "M tet-solves/s", "cores": cores, "kind": "port",
+           "sample": "%d substeps of the same %d-tet lattice, OpenMP over tets/particles (oracle/tetsim_oracle.c section G)" % (n, len(tets))}
+    if cores > 1:  # single-thread figure on a shorter sample: like-for-like with the reference's single JS thread
+        set_threads(1)
+        t0 = time.perf_counter()
+        o.simulate(DT, PP)
+        res["value_1core"] = round(len(tets) / (time.perf_counter() - t0) / 1e6, 3)
+        set_threads(cores)
+    try:
+        with open("/proc/cpuinfo") as f:
+            res["cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="fast", choices=["fast", "precise"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from tetsim_amd import SoftBodyHIP, make_lattice, measure_copy_bandwidth
+    from tetsim_amd import _capi as capi
+    import ctypes as C
+
+    # ---- workload ------------------------------------------------------------------------------------
+    nz = CELLS * world
+    verts, tets = make_lattice(CELLS, nz=nz)
+    nt_global = len(tets)
+    kw = {}
+    if world > 1:
+        plane = (CELLS + 1) * (CELLS + 1)
+        owner = np.minimum((np.arange(len(verts)) // plane) // CELLS, world - 1).astype(np.int32)
+        kw = dict(part_count=world, part_index=rank, vert_owner=owner)
+    body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
+                       device=local_rank, **kw)
+    if world > 1:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            capi.check(capi.lib().tetsim_comm_unique_id(buf))
+            uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        capi.check(capi.lib().tetsim_comm_init(body._h, raw, rank, world), body._h)
+
+    def barrier():
+        body.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # ---- timed region --------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    pos = body.pos
+    if not np.isfinite(pos).all():
+        raise SystemExit("non-finite positions after the timed region")
+
+    out = None
+    if rank == 0:
+        tet_solves = nt_global * SUBSTEPS * args.steps
+        value = tet_solves / elapsed / 1e6
+        nv_global = len(verts)
+        out = {
+            "metric": "tet_solves_per_sec", "value": round(value, 1), "unit": "M tet-solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
+                                   "%d substeps/frame, dt=1/1200 s" % (CELLS, CELLS, nz, nt_global, nv_global, SUBSTEPS),
+                       "solver": "polar_jacobi", "arithmetic": args.precision, "substeps_per_step": SUBSTEPS,
+                       "tets": nt_global, "particles": nv_global,
+                       "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
+        }
+    if world == 1:
+        # dominant kernel, HIP events on the handle's stream (eager launches, same kernels as the graph)
+        pr = body.profile(SUBSTEPS * 3, DT, PP)
+        tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
+        vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3
+        achieved = TET_KERNEL_BYTES * len(tets) / (tet_us * 1e-6) / 1e9
+        b_alg = TET_KERNEL_BYTES + VERTEX_BYTES * len(verts) / len(tets)
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if present
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get("pj_tet_kernel_%s" % args.precision)
+        except Exception:
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": "pj_tet_kernel_%s" % args.precision,
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
+                           "alg_bytes_per_launch": TET_KERNEL_BYTES * len(tets),
+                           "substep_alg_bytes_per_tet": round(b_alg, 1),
+                           "substep_achieved": round(b_alg * value * 1e6 / 1e9, 1),
+                           "substep_frac": round(b_alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
+                           "measured_copy_peak": {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0),
+                                                  "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}}
+        if not args.no_cpu_baseline:
+            body.close()
+            out["cpu_baseline"] = cpu_baseline(verts, tets)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        body.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

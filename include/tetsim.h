@@ -1,0 +1,247 @@
+/*
+ * tetsim.h -- C ABI of libtetsim_hip.so: the MI355X-native XPBD tetrahedral soft-body hot path.
+ *
+ * This is the drop-in boundary for the per-substep solve of zalo/TetSim.  Every entry point replaces
+ * one piece of the reference's `SoftBody` / `SoftBodyGPU` surface (citations are file:line under the
+ * reference tree); the N-API shim (tetsim_amd/node/tetsim_napi.cc) and the ctypes host
+ * (tetsim_amd/softbody.py) bind these 1:1.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a TETSIM_E* code; tetsim_last_error() gives the text
+ *     (the reference reports init problems as an error *string*, SoftbodyGPU.js:379-380);
+ *   - all inputs are copied at create; device memory is owned by the handle;
+ *   - step calls enqueue work on the handle's HIP stream and return WITHOUT synchronising;
+ *     reads synchronise;
+ *   - a handle is not thread-safe (the reference is single-threaded JS, World.js:73).
+ *   - numbers that are JS `number`s in the reference (dt, physicsParams) are doubles here so the
+ *     Neo-Hookean path can reproduce Softbody.js's f64-arithmetic/f32-store results bit for bit.
+ */
+#ifndef TETSIM_H
+#define TETSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TETSIM_ABI_VERSION 1
+
+typedef struct tetsim_body *tetsim_handle;
+
+/* error codes */
+enum {
+    TETSIM_OK = 0,
+    TETSIM_EINVAL = 1,    /* bad argument (null pointer, index out of range, repeated vertex in a tet ...) */
+    TETSIM_ENODEVICE = 2, /* no usable HIP device / HIP extension not functional: never falls back to CPU */
+    TETSIM_EHIP = 3,      /* a HIP runtime call failed; text in tetsim_last_error */
+    TETSIM_ENOMEM = 4,
+    TETSIM_ECOMM = 5,     /* RCCL load/init/transfer failure */
+    TETSIM_ESTATE = 6     /* call not valid for this handle (e.g. quats of a Neo-Hookean body) */
+};
+
+/* which of the reference's two solvers */
+enum {
+    TETSIM_SOLVER_POLAR_JACOBI = 0,  /* SoftbodyGPU.js: shape-matching / polar decomposition, Jacobi (7 GLSL passes :59-376) */
+    TETSIM_SOLVER_NEOHOOKEAN_GS = 1  /* Softbody.js:  Neo-Hookean XPBD, Gauss-Seidel (:91-240) */
+};
+
+/* arithmetic mode */
+enum {
+    /* POLAR_JACOBI: IEEE f32, no FMA contraction, correctly rounded div/sqrt, libm-grade sin -- op-for-op the
+     *               GLSL source order.  NEOHOOKEAN_GS: f64 arithmetic with f32 stores exactly where
+     *               Softbody.js rounds (bit-exact with the reference CPU solver). */
+    TETSIM_PRECISE = 0,
+    /* f32 throughout, FMA contraction, hardware rcp/rsq/sin.  Tolerance-level parity (tests state it). */
+    TETSIM_FAST = 1
+};
+
+/* Gauss-Seidel element order (NEOHOOKEAN_GS only) */
+enum {
+    /* exactly the sequential order of the caller's tetIds (Softbody.js:207-208), parallelised by
+     * dependency levels: two tets run concurrently only if no earlier/later pair shares a vertex. */
+    TETSIM_ORDER_ORIGINAL = 0,
+    /* greedy graph colouring, tets stably sorted by colour (BASELINE config 4).  The result equals the
+     * reference CPU solver run on tetIds permuted by tetsim_get_tet_order(). */
+    TETSIM_ORDER_COLOURED = 1
+};
+
+/* flags */
+enum {
+    /* build the particle->(tet,vertex) scatter table exactly as SoftbodyGPU.js:563-577 does, including
+     * its `<= 0.0` empty-slot test (:568), which drops tet 0 / vertex 0's contribution, and the 36-slot
+     * cap.  Without it every incident tet contributes. */
+    TETSIM_FLAG_REF_SLOT_TABLE = 1u << 0,
+    /* ignore params.worldBounds and clamp to the constants hard-coded in the collision pass
+     * (SoftbodyGPU.js:347).  POLAR_JACOBI only; on by default through tetsim_default_options(). */
+    TETSIM_FLAG_REF_FIXED_BOUNDS = 1u << 1
+};
+
+/* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */
+typedef struct TetSimParams {
+    double gravity;        /* Softbody.js:199 ; SoftbodyGPU.js:371 */
+    double friction;       /* Softbody.js:224-225 ; SoftbodyGPU.js:352 */
+    double devCompliance;  /* Softbody.js:130,161 (NEOHOOKEAN_GS) */
+    double volCompliance;  /* Softbody.js:161,165 (NEOHOOKEAN_GS) */
+    double worldBounds[6]; /* lo xyz, hi xyz ; Softbody.js:215-216 */
+} TetSimParams;
+
+typedef struct TetSimOptions {
+    int32_t solver;     /* TETSIM_SOLVER_* */
+    int32_t precision;  /* TETSIM_PRECISE / TETSIM_FAST */
+    int32_t order;      /* TETSIM_ORDER_* (NEOHOOKEAN_GS) */
+    uint32_t flags;     /* TETSIM_FLAG_* */
+    int32_t device;     /* HIP device ordinal */
+    double density;     /* physicsParams.density, consumed at construction (Softbody.js:32,74) */
+    /* Domain decomposition (POLAR_JACOBI).  part_count <= 1: whole mesh on this handle.  Otherwise this
+     * handle owns the vertices v with vert_owner[v] == part_index (vert_owner == NULL: equal contiguous
+     * index ranges) plus a ghost layer; see DESIGN.md "Multi-GPU". */
+    int32_t part_count;
+    int32_t part_index;
+    const int32_t *vert_owner;
+} TetSimOptions;
+
+typedef struct TetSimInfo {
+    uint32_t num_particles;      /* vertices of the caller's (global) mesh  -- SoftBody.numParticles */
+    uint32_t num_elems;          /* tets of the caller's (global) mesh      -- SoftBody.numElems */
+    uint32_t owned_particles;    /* vertices this handle integrates (== num_particles when unpartitioned) */
+    uint32_t local_particles;    /* owned + ghost */
+    uint32_t local_elems;        /* tets this handle solves (owned + ghost tets) */
+    uint32_t owned_elems;        /* tets counted once across partitions (lowest-owner rule) */
+    uint32_t num_levels;         /* Gauss-Seidel dependency levels / colours (0 for POLAR_JACOBI) */
+    uint32_t max_valence;        /* max incident tets per vertex used by the scatter table */
+    uint32_t dropped_slots;      /* (tet,vertex) contributions dropped by TETSIM_FLAG_REF_SLOT_TABLE */
+    uint32_t num_neighbours;     /* partitions this handle exchanges a halo with */
+    uint64_t device_bytes;       /* HBM allocated by this handle */
+    int32_t solver, precision, order, device;
+    uint32_t flags;
+} TetSimInfo;
+
+/* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
+enum { TETSIM_K_TET = 0, TETSIM_K_VERTEX = 1, TETSIM_K_HALO = 2, TETSIM_K_COUNT = 3 };
+typedef struct TetSimProfile {
+    double total_ms;                 /* wall on the stream for all substeps */
+    double kernel_ms[TETSIM_K_COUNT]; /* summed duration per kernel class */
+    uint32_t launches[TETSIM_K_COUNT];
+    uint32_t substeps;
+} TetSimProfile;
+
+/* --- lifecycle ------------------------------------------------------------------------------- */
+
+/* Fill `o` with the defaults that mirror the reference's GPU demo path
+ * (POLAR_JACOBI, PRECISE, REF_SLOT_TABLE|REF_FIXED_BOUNDS, density 1000, device 0, unpartitioned). */
+void tetsim_default_options(TetSimOptions *o);
+/* physicsParams defaults of main.js:22-36. */
+void tetsim_default_params(TetSimParams *p);
+
+/* Replaces `new SoftBody(vertices, tetIds, ...)` (Softbody.js:4-58 + initPhysics :60-87) and
+ * `new SoftBodyGPU(...)` (SoftbodyGPU.js:5-56 + initPhysics :487-608): copies the mesh, builds rest
+ * data / tables on the host, uploads.  verts = [3*nv] xyz, tets = [4*nt] vertex ids. */
+int tetsim_create(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt,
+                  const TetSimOptions *opts, tetsim_handle *out);
+void tetsim_destroy(tetsim_handle h);
+
+/* Text of the last error on this handle (h == NULL: last error of a failed create on this thread). */
+const char *tetsim_last_error(tetsim_handle h);
+int tetsim_get_info(tetsim_handle h, TetSimInfo *info);
+
+/* --- the hot path ---------------------------------------------------------------------------- */
+
+/* Replaces `simulate(dt, physicsParams)` (Softbody.js:195-240 ; SoftbodyGPU.js:610-641): ONE substep,
+ * enqueued on the handle's stream, no synchronisation. */
+int tetsim_step(tetsim_handle h, double dt, const TetSimParams *params);
+/* n substeps with the same dt/params/grab as one host call and one HIP-graph launch: the body of the
+ * caller's substep loop (main.js:79-84). */
+int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params);
+/* Block until everything enqueued on the handle's stream(s) has finished. */
+int tetsim_sync(tetsim_handle h);
+
+/* --- state access (synchronising) ------------------------------------------------------------ */
+
+/* Replaces reading `.pos` (Softbody.js:12) / readToCPU (SoftbodyGPU.js:649-653): xyz of the OWNED
+ * particles after the last completed substep, [3*owned_particles], in tetsim_get_owned_ids order. */
+int tetsim_read_positions(tetsim_handle h, float *out);
+int tetsim_read_prev_positions(tetsim_handle h, float *out); /* .prevPos */
+int tetsim_read_velocities(tetsim_handle h, float *out);     /* .vel */
+/* POLAR_JACOBI: per-tet rotation quaternion xyzw (textureQuat, SoftbodyGPU.js:55,181), [4*local_elems]
+ * in tetsim_get_local_tets order. */
+int tetsim_read_quats(tetsim_handle h, float *out);
+/* NEOHOOKEAN_GS: `.volError` of the last substep (Softbody.js:163,206,209), summed in the caller's
+ * tet order in f64. */
+int tetsim_read_vol_error(tetsim_handle h, double *out);
+/* Overwrite positions and velocities of the owned particles (checkpoint restore). */
+int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
+
+/* global vertex id of each owned particle, [owned_particles] (identity when unpartitioned) */
+int tetsim_get_owned_ids(tetsim_handle h, int32_t *out);
+/* global tet id of each local tet, [local_elems] */
+int tetsim_get_local_tets(tetsim_handle h, int32_t *out);
+/* NEOHOOKEAN_GS: the order in which tets are solved, as indices into the caller's tetIds, [num_elems]. */
+int tetsim_get_tet_order(tetsim_handle h, int32_t *out);
+/* NEOHOOKEAN_GS: first solve-order position of every level, [num_levels + 1]. */
+int tetsim_get_level_offsets(tetsim_handle h, int32_t *out);
+/* rest data as the reference computes it (Softbody.js:60-87): invMass [nv] */
+int tetsim_read_inv_mass(tetsim_handle h, float *out);
+
+/* --- grab (Softbody.js:279-298 ; SoftbodyGPU.js:692-712) --------------------------------------- */
+
+/* Pin global particle `id` (-1 = none, endGrab) at xyz: consumed by the next substeps
+ * (Softbody.js:233-235 ; SoftbodyGPU.js:345, with the exact particle index -- see DESIGN.md). */
+int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]);
+/* startGrab: nearest particle to xyz among the latest positions (device argmin); sets and returns it. */
+int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t *id_out);
+
+/* --- measurement ----------------------------------------------------------------------------- */
+
+/* Run n substeps eagerly with HIP events around every kernel on the handle's own stream. */
+int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, TetSimProfile *out);
+/* n substeps through the production path (tetsim_step_n), bracketed by HIP events on the handle's
+ * stream; returns elapsed milliseconds.  Synchronises. */
+int tetsim_time_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, double *ms_out);
+/* Device-to-device stream copy of `bytes` on the handle's stream, `reps` times: measured copy
+ * bandwidth in GB/s (read+write bytes / time) -- the "measured HBM peak" of SURVEY.md §8(d). */
+int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps, double *gbps_out);
+
+/* --- multi-GPU halo (POLAR_JACOBI, part_count > 1) ---------------------------------------------- */
+
+/* RCCL transport: rank 0 calls tetsim_comm_unique_id, the host distributes the 128 bytes, every rank
+ * calls tetsim_comm_init.  Afterwards tetsim_step/_step_n exchange ghost positions with neighbouring
+ * partitions every substep (grouped ncclSend/ncclRecv on a dedicated stream). */
+int tetsim_comm_unique_id(void *id128);
+int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t nranks);
+/* In-process transport for partitions living on one device (tests; "multi-GPU without a cluster"):
+ * after every handle has been stepped ONE substep, copy owned interface positions into the
+ * neighbours' ghost ranges.  handles[i] must be partition i of the same mesh. */
+int tetsim_halo_exchange_local(tetsim_handle *handles, uint32_t count);
+/* Host-visible halo plan of this handle (for transports implemented by the caller and for tests):
+ * neighbour ranks, and per neighbour the global ids sent and received, concatenated. */
+int tetsim_get_halo_plan(tetsim_handle h, int32_t *neigh /*[num_neighbours]*/,
+                         int32_t *send_counts, int32_t *recv_counts,
+                         int32_t *send_ids, int32_t *recv_ids);
+/* Export this handle's packed send buffer for neighbour slot `n` (device->host) / import a received
+ * one (host->device): the slow, transport-agnostic path used by the CPU `gloo` tests. */
+int tetsim_halo_export(tetsim_handle h, uint32_t n, float *out_xyzw);
+int tetsim_halo_import(tetsim_handle h, uint32_t n, const float *in_xyzw);
+
+/* --- host-side preprocessing, callable without a GPU (unit-tested on CPU) ------------------------ */
+
+/* Dependency levels of sequential Gauss-Seidel over `tets` in the given order: level[e] in [0,L).
+ * Tets of one level are vertex-disjoint and every pair sharing a vertex keeps its relative order. */
+int tetsim_prep_levels(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *level, uint32_t *num_levels);
+/* Greedy colouring in tet order (smallest colour not used by any tet sharing a vertex). */
+int tetsim_prep_colours(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *colour, uint32_t *num_colours);
+/* Scatter table of SoftbodyGPU.js:563-577: slots[v*36 + s] = 4*tet + corner, -1 = empty.
+ * ref_quirk != 0 reproduces the `<= 0.0` test.  Returns the number of dropped contributions. */
+int tetsim_prep_slot_table(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t ref_quirk,
+                           int32_t *slots /*[nv*36]*/, uint32_t *dropped);
+/* Rest data of Softbody.js:60-87 in JS number semantics: invMass[nv], invRestPose[9*nt] (column-major),
+ * invRestVolume[nt]. */
+int tetsim_prep_rest(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt, double density,
+                     float *inv_mass, float *inv_rest_pose, float *inv_rest_volume);
+
+int tetsim_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETSIM_H */

@@ -1,0 +1,139 @@
+"""GPU parity, Neo-Hookean XPBD Gauss-Seidel (BASELINE configs 1 and 4), through the C ABI.
+
+PRECISE mode is compared BIT FOR BIT with (a) golden vectors recorded from the reference's Softbody.js and
+(b) the CPU oracle (itself pinned to those goldens) on meshes the goldens do not cover.
+FAST mode (f32 + FMA) is compared at the tolerances stated in the tests.
+"""
+import numpy as np
+import pytest
+
+from conftest import case_dt, load_f32, load_mesh, sha16
+from oracle import OracleNH
+from tetsim_amd import SoftBodyHIP, make_lattice
+
+pytestmark = pytest.mark.gpu
+
+GOLD_CASES = ["dragon", "dragon_sub5", "dragon_grab", "dragon_soft", "lat4", "lat4c", "lat2degen", "notets"]
+
+
+def _run_case(body, c, nsteps, on_step):
+    dt = case_dt(c)
+    for step in range(1, nsteps + 1):
+        for ev in c["grab"]:
+            if ev["at"] != step:
+                continue
+            if ev["op"] == "start":
+                body.startGrab(ev["p"])
+            elif ev["op"] == "move":
+                body.moveGrabbed(ev["p"])
+            else:
+                body.endGrab()
+        body.simulate(dt, c["params"])
+        on_step(step)
+
+
+@pytest.mark.parametrize("name", GOLD_CASES)
+def test_precise_bit_exact_vs_reference_goldens(name, golden):
+    gold, cases = golden
+    c, g = cases[name], gold[name]
+    nsteps = min(c["nsteps"], 200)
+    v, t = load_mesh(c["mesh"])
+    body = SoftBodyHIP(v, t, None, c["params"], solver="neohookean", precision="precise", order="original")
+    grab_ids = []
+
+    def on_step(step):
+        if body.grabId >= 0 and (not grab_ids or grab_ids[-1] != body.grabId):
+            grab_ids.append(body.grabId)
+        gs = g["steps"].get(str(step))
+        if gs:
+            assert sha16(body.pos) == gs["pos"], (name, step)
+            assert sha16(body.vel) == gs["vel"], (name, step)
+            assert sha16(body.prevPos) == gs["prev"], (name, step)
+            if gs["volError"] is not None:
+                assert body.volError == gs["volError"], (name, step)
+        if step in c["dumps"]:
+            assert np.array_equal(body.pos.ravel().view(np.uint32), load_f32(f"{name}_pos_{step}.f32").view(np.uint32))
+
+    _run_case(body, c, nsteps, on_step)
+    if c["grab"]:
+        assert grab_ids == g["grabIds"]
+    assert np.array_equal(body.invMass.view(np.uint32), load_f32(c["mesh"] + "_invMass.f32").view(np.uint32))
+
+
+def test_dragon_1200_substeps_hash(golden):
+    """SURVEY.md §8(c) known answer: two simulated seconds including floor contact, via graph launches."""
+    gold, cases = golden
+    c, g = cases["dragon"], gold["dragon"]
+    v, t = load_mesh("dragon")
+    body = SoftBodyHIP(v, t, None, c["params"], solver="neohookean", precision="precise")
+    dt = case_dt(c)
+    for frame in range(120):
+        body.simulateSubsteps(10, dt, c["params"])
+        if frame == 59:
+            assert sha16(body.pos) == g["steps"]["600"]["pos"]
+    assert sha16(body.pos) == g["steps"]["1200"]["pos"] == "9f52c76cdd7223f0"
+
+
+@pytest.mark.parametrize("order", ["original", "coloured"])
+def test_precise_bit_exact_vs_oracle_lattice(order):
+    """Config 4's claim: the coloured schedule equals the sequential solver fed the permuted tetIds."""
+    v, t = make_lattice(6, y0=0.02)
+    pp = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
+              worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+    body = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="precise", order=order)
+    perm = body.tetOrder
+    assert sorted(perm.tolist()) == list(range(len(t)))
+    if order == "original":
+        assert np.array_equal(perm, np.arange(len(t)))
+    lo = body.levelOffsets
+    assert lo[0] == 0 and lo[-1] == len(t) and np.all(np.diff(lo) > 0)
+    orc = OracleNH(v, t[perm], pp)
+    dt = (1.0 / 60.0) / 10
+    for step in range(60):
+        body.simulate(dt, pp)
+        orc.simulate(dt, pp)
+        if step in (0, 9, 59):
+            assert np.array_equal(body.pos.view(np.uint32), orc.pos.view(np.uint32)), step
+            assert np.array_equal(body.vel.view(np.uint32), orc.vel.view(np.uint32)), step
+            assert body.volError == orc.volError
+    if order == "coloured":
+        assert body.info.num_levels <= 64  # a colouring, not a wavefront
+
+
+def test_fast_tolerance_vs_reference_goldens(golden):
+    """f32 + FMA kernel vs the reference's f64-compute trajectory.  The system is stiff (|v| reaches 6 m/s after
+    one substep), so the tolerance is stated per horizon: max |dx| over all particles."""
+    gold, cases = golden
+    c = cases["dragon"]
+    v, t = load_mesh("dragon")
+    body = SoftBodyHIP(v, t, None, c["params"], solver="neohookean", precision="fast")
+    dt = case_dt(c)
+    tol = {1: 2e-6, 10: 2e-5, 100: 2e-3}
+    for step in range(1, 101):
+        body.simulate(dt, c["params"])
+        if step in tol:
+            ref = load_f32(f"dragon_pos_{step}.f32").reshape(-1, 3)
+            err = np.abs(body.pos - ref).max()
+            assert err <= tol[step], (step, err)
+
+
+def test_graph_equals_eager():
+    v, t = make_lattice(5, y0=0.1)
+    pp = dict(density=1000.0)
+    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", order="coloured")
+    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", order="coloured")
+    dt = 1.0 / 600
+    for _ in range(3):
+        a.simulateSubsteps(7, dt, pp)
+        for _ in range(7):
+            b.simulate(dt, pp)
+    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+
+
+def test_repeated_vertex_is_rejected():
+    from tetsim_amd import TetSimError
+    v, t = make_lattice(2)
+    t = t.copy()
+    t[3, 1] = t[3, 0]
+    with pytest.raises(TetSimError):
+        SoftBodyHIP(v, t, None, {}, solver="neohookean")

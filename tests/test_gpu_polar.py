@@ -1,0 +1,172 @@
+"""GPU parity, shape-matching polar-decomposition Jacobi (BASELINE configs 2, 3, 5), through the C ABI.
+
+The oracle is the GLSL-order CPU restatement (oracle/tetsim_oracle.c section G; parity UNPINNED by the
+reference: its WebGL passes cannot run here).  PRECISE mode performs the same IEEE f32 operations in the
+same order; the only permitted difference is the last-ulp behaviour of sin() (device libm vs glibc).
+Tolerances are absolute position errors in metres, stated per horizon.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_mesh
+from oracle import OraclePJ
+from tetsim_amd import SoftBodyHIP, halo_exchange_local, make_lattice
+
+pytestmark = pytest.mark.gpu
+
+PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
+          worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+DT20 = (1.0 * (1.0 / 60.0)) / 20  # config 2: 20 substeps per frame (main.js:26-27,79)
+
+
+def _pair(v, t, precision="precise", **kw):
+    return SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision, **kw), OraclePJ(v, t, PP, slot_quirk=True)
+
+
+@pytest.mark.parametrize("mesh", ["dragon", "lat4"])
+def test_precise_tracks_oracle(mesh):
+    v, t = load_mesh(mesh)
+    body, orc = _pair(v, t)
+    tol = {1: 1e-6, 20: 5e-6, 200: 2e-4}
+    for step in range(1, 201):
+        body.simulate(DT20, PP)
+        orc.simulate(DT20, PP)
+        if step in tol:
+            err = np.abs(body.pos - orc.pos).max()
+            verr = np.abs(body.vel - orc.vel).max()
+            assert err <= tol[step], (mesh, step, err)
+            assert verr <= tol[step] / DT20 * 2, (mesh, step, verr)
+            q = body.quats
+            assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-6
+            assert np.abs(q - orc.quats).max() < 1e-4
+
+
+def test_precise_first_substep_is_tight():
+    """After ONE substep there has been no feedback yet: only sin() ulps separate device and oracle."""
+    v, t = load_mesh("dragon")
+    body, orc = _pair(v, t)
+    body.simulate(DT20, PP)
+    orc.simulate(DT20, PP)
+    assert np.abs(body.pos - orc.pos).max() <= 2.5e-7
+    # the reference's slot quirk: particle tetIds[0] loses tet 0's contribution (SoftbodyGPU.js:568)
+    assert body.info.dropped_slots == 1
+
+
+def test_fast_tolerance():
+    v, t = load_mesh("dragon")
+    body, orc = _pair(v, t, precision="fast")
+    tol = {1: 2e-6, 20: 5e-5, 200: 2e-3}
+    for step in range(1, 201):
+        body.simulate(DT20, PP)
+        orc.simulate(DT20, PP)
+        if step in tol:
+            err = np.abs(body.pos - orc.pos).max()
+            assert err <= tol[step], (step, err)
+
+
+def test_floor_grab_and_bounds():
+    v, t = make_lattice(4, y0=0.02)
+    body, orc = _pair(v, t)
+    gid = 7
+    for step in range(150):
+        if step == 30:
+            body.setGrab(gid, [0.3, 0.8, 0.1]); orc.setGrab(gid, [0.3, 0.8, 0.1])
+        if 30 < step < 90:
+            p = [0.3 + 0.002 * step, 0.8, 0.1]
+            body.moveGrabbed(p); orc.setGrab(gid, p)
+        if step == 90:
+            body.endGrab(); orc.endGrab()
+        body.simulate(DT20, PP)
+        orc.simulate(DT20, PP)
+        if step == 60:
+            assert np.allclose(body.pos[gid], [0.3 + 0.002 * 60, 0.8, 0.1], atol=0)
+    assert body.pos[:, 1].min() >= 0.0
+    assert np.abs(body.pos - orc.pos).max() < 5e-4
+
+
+def test_rigid_rest_is_a_fixed_point_without_gravity():
+    """Invariant: with g = 0 and zero velocity every goal equals the current corner, so nothing moves."""
+    v, t = make_lattice(3, y0=0.5)
+    pp = dict(PP, gravity=0.0)
+    body = SoftBodyHIP(v, t, None, pp, solver="polar", ref_slot_table=False)
+    for _ in range(10):
+        body.simulate(DT20, pp)
+    assert np.abs(body.pos - v).max() < 2e-6
+
+
+def test_graph_equals_eager_and_dt_change():
+    v, t = load_mesh("dragon")
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar")
+    b = SoftBodyHIP(v, t, None, dict(PP), solver="polar")
+    for dt in (DT20, DT20 * 2, DT20):
+        a.simulateSubsteps(20, dt, PP)
+        for _ in range(20):
+            b.simulate(dt, PP)
+    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+    # and the fused prediction + re-prediction path tracks the oracle across a dt change
+    orc = OraclePJ(v, t, PP)
+    for dt in (DT20, DT20 * 2, DT20):
+        for _ in range(20):
+            orc.simulate(dt, PP)
+    assert np.abs(b.pos - orc.pos).max() < 1e-4
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_partitioned_equals_monolithic_bitwise(parts):
+    """SURVEY.md §4 'multi-GPU without a cluster': P partitions on one GPU, halo by local copies, must equal
+    the single-body run bit for bit (Jacobi; per-vertex sums keep the global slot order)."""
+    n = 8
+    v, t = make_lattice(n, y0=0.05)
+    plane = (n + 1) * (n + 1)
+    owner = np.minimum((np.arange(len(v)) // plane) * parts // (n + 1), parts - 1).astype(np.int32)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar")
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", part_count=parts, part_index=p, vert_owner=owner)
+              for p in range(parts)]
+    assert sum(b.info.owned_particles for b in bodies) == len(v)
+    assert sum(b.info.owned_elems for b in bodies) == len(t)
+    for _ in range(40):
+        mono.simulate(DT20, PP)
+        for b in bodies:
+            b.simulate(DT20, PP)
+        halo_exchange_local(bodies)
+    ref = mono.pos
+    for b in bodies:
+        assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
+
+
+def test_partition_irregular_mesh():
+    """Dragon-class mesh with an arbitrary (index-range) vertex partition: non-contiguous send lists."""
+    v, t = load_mesh("dragon")
+    parts = 4
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar")
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", part_count=parts, part_index=p) for p in range(parts)]
+    for _ in range(25):
+        mono.simulate(DT20, PP)
+        for b in bodies:
+            b.simulate(DT20, PP)
+        halo_exchange_local(bodies)
+    ref = mono.pos
+    for b in bodies:
+        assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
+
+
+def test_lattice_1m_properties():
+    """BASELINE config 3 at full size: size-independent properties instead of a CPU run."""
+    v, t = make_lattice(55)
+    assert len(t) == 998250 and len(v) == 175616
+    pp = dict(PP, gravity=0.0)
+    body = SoftBodyHIP(v, t, None, pp, solver="polar", precision="fast")
+    body.simulateSubsteps(20, DT20, pp)
+    assert np.abs(body.pos - v).max() < 5e-6          # rest + no gravity: fixed point
+    body2 = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    body2.simulateSubsteps(20, DT20, PP)
+    p = body2.pos
+    assert np.isfinite(p).all()
+    q = body2.quats
+    assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-5
+    # free fall of a (nearly) rigid block for one frame: centroid drops by ~ g t^2 / 2 with symplectic Euler
+    n = 20
+    expect = -9.81 * DT20 * DT20 * n * (n + 1) / 2
+    assert abs((p[:, 1] - v[:, 1]).mean() - expect) < 2e-4
+    # x/z mirror symmetry of the lattice is preserved by the centroid
+    assert abs(p[:, 0].mean() - v[:, 0].mean()) < 1e-5

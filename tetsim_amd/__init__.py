@@ -1,0 +1,8 @@
+"""tetsim_amd -- MI355X-native XPBD tetrahedral soft-body hot path behind TetSim's SoftBody surface.
+
+Product code: tetsim_amd/csrc (HIP kernels + C ABI, include/tetsim.h), this thin ctypes host
+(`SoftBodyHIP`) and its Node.js twin under tetsim_amd/node.  The CPU oracle lives in /oracle and is never
+imported from here.
+"""
+from .lattice import make_lattice  # noqa: F401
+from .softbody import SoftBodyHIP, TetSimError, halo_exchange_local, make_params, measure_copy_bandwidth  # noqa: F401

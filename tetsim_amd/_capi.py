@@ -1,0 +1,124 @@
+"""ctypes binding of include/tetsim.h (libtetsim_hip.so).  1:1 with the C ABI; no logic here.
+
+The library is REQUIRED: importing this module without a built libtetsim_hip.so raises, and creating a
+body without a HIP device raises TetSimError(ENODEVICE).  There is no CPU fallback anywhere in the product.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtetsim_hip.so")
+
+OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
+SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
+PRECISE, FAST = 0, 1
+ORDER_ORIGINAL, ORDER_COLOURED = 0, 1
+FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS = 1, 2
+K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
+
+
+class TetSimParams(C.Structure):
+    _fields_ = [("gravity", C.c_double), ("friction", C.c_double), ("devCompliance", C.c_double),
+                ("volCompliance", C.c_double), ("worldBounds", C.c_double * 6)]
+
+
+class TetSimOptions(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("precision", C.c_int32), ("order", C.c_int32), ("flags", C.c_uint32),
+                ("device", C.c_int32), ("density", C.c_double), ("part_count", C.c_int32),
+                ("part_index", C.c_int32), ("vert_owner", C.POINTER(C.c_int32))]
+
+
+class TetSimInfo(C.Structure):
+    _fields_ = [("num_particles", C.c_uint32), ("num_elems", C.c_uint32), ("owned_particles", C.c_uint32),
+                ("local_particles", C.c_uint32), ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32),
+                ("num_levels", C.c_uint32), ("max_valence", C.c_uint32), ("dropped_slots", C.c_uint32),
+                ("num_neighbours", C.c_uint32), ("device_bytes", C.c_uint64), ("solver", C.c_int32),
+                ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class TetSimProfile(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("kernel_ms", C.c_double * K_COUNT), ("launches", C.c_uint32 * K_COUNT),
+                ("substeps", C.c_uint32)]
+
+
+class TetSimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tetsim error %d: %s" % (code, msg))
+        self.code = code
+
+
+# every symbol include/tetsim.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "tetsim_abi_version", "tetsim_default_options", "tetsim_default_params", "tetsim_create", "tetsim_destroy",
+    "tetsim_last_error", "tetsim_get_info", "tetsim_step", "tetsim_step_n", "tetsim_sync",
+    "tetsim_read_positions", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
+    "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
+    "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_grab",
+    "tetsim_start_grab", "tetsim_profile", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
+    "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
+    "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
+    "tetsim_prep_slot_table", "tetsim_prep_rest",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libtetsim_hip.so (building it is __graft_entry__.build()'s / tetsim_amd.build's job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libtetsim_hip.so is not built: run `python -m tetsim_amd.build` "
+                          "(the HIP extension is mandatory; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    H, fp, ip, dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    u32, i32, dbl = C.c_uint32, C.c_int32, C.c_double
+    PP = C.POINTER(TetSimParams)
+    L.tetsim_abi_version.restype = C.c_int
+    L.tetsim_default_options.argtypes = [C.POINTER(TetSimOptions)]
+    L.tetsim_default_options.restype = None
+    L.tetsim_default_params.argtypes = [PP]
+    L.tetsim_default_params.restype = None
+    L.tetsim_create.argtypes = [fp, u32, ip, u32, C.POINTER(TetSimOptions), C.POINTER(H)]
+    L.tetsim_destroy.argtypes = [H]
+    L.tetsim_destroy.restype = None
+    L.tetsim_last_error.argtypes = [H]
+    L.tetsim_last_error.restype = C.c_char_p
+    L.tetsim_get_info.argtypes = [H, C.POINTER(TetSimInfo)]
+    L.tetsim_step.argtypes = [H, dbl, PP]
+    L.tetsim_step_n.argtypes = [H, u32, dbl, PP]
+    L.tetsim_sync.argtypes = [H]
+    for n in ("positions", "prev_positions", "velocities", "quats", "inv_mass"):
+        getattr(L, "tetsim_read_" + n).argtypes = [H, fp]
+    L.tetsim_read_vol_error.argtypes = [H, dp]
+    L.tetsim_write_state.argtypes = [H, fp, fp]
+    for n in ("owned_ids", "local_tets", "tet_order", "level_offsets"):
+        getattr(L, "tetsim_get_" + n).argtypes = [H, ip]
+    L.tetsim_set_grab.argtypes = [H, i32, fp]
+    L.tetsim_start_grab.argtypes = [H, fp, ip]
+    L.tetsim_profile.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]
+    L.tetsim_time_step_n.argtypes = [H, u32, dbl, PP, dp]
+    L.tetsim_measure_copy_bandwidth.argtypes = [i32, C.c_uint64, u32, dp]
+    L.tetsim_comm_unique_id.argtypes = [C.c_void_p]
+    L.tetsim_comm_init.argtypes = [H, C.c_void_p, i32, i32]
+    L.tetsim_halo_exchange_local.argtypes = [C.POINTER(H), u32]
+    L.tetsim_get_halo_plan.argtypes = [H, ip, ip, ip, ip, ip]
+    L.tetsim_halo_export.argtypes = [H, u32, fp]
+    L.tetsim_halo_import.argtypes = [H, u32, fp]
+    L.tetsim_prep_levels.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
+    L.tetsim_prep_colours.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
+    L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
+    L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]
+    for s in SYMBOLS:
+        f = getattr(L, s)
+        if s not in ("tetsim_default_options", "tetsim_default_params", "tetsim_destroy", "tetsim_last_error"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, handle=None):
+    if rc != OK:
+        msg = lib().tetsim_last_error(handle)
+        raise TetSimError(rc, msg.decode("utf-8", "replace") if msg else "")

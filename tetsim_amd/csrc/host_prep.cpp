@@ -1,0 +1,286 @@
+// host_prep.cpp -- host-side preprocessing for libtetsim_hip.so (no HIP dependency; unit-tested on CPU).
+//
+// Everything that the reference does once in its constructors (Softbody.js:60-87 initPhysics,
+// SoftbodyGPU.js:487-608 initPhysics) plus what a parallel schedule needs on top: Gauss-Seidel
+// dependency levels, greedy colouring, the particle->(tet,corner) incidence table and the
+// domain-decomposition plan.
+//
+// Must be compiled with -ffp-contract=off: prep_rest reproduces JS number semantics (f64 arithmetic,
+// an f32 rounding at every Float32Array store) and JS never fuses multiply-add.
+#include "host_prep.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace tetsim {
+
+namespace {
+inline float fround(double x) { return static_cast<float>(x); }
+
+// f32-stored edge matrix (column-major: column k = p_{k+1} - p_0), Softbody.js:69-71
+inline void edge_matrix(const float* verts, const int32_t* t, float m[9]) {
+    for (int k = 0; k < 3; k++)
+        for (int c = 0; c < 3; c++)
+            m[3 * k + c] = fround(static_cast<double>(verts[3 * t[k + 1] + c]) - static_cast<double>(verts[3 * t[0] + c]));
+}
+// Softbody.js:381-387, term order as written
+inline double det3(const float* A) {
+    double a11 = A[0], a12 = A[3], a13 = A[6];
+    double a21 = A[1], a22 = A[4], a23 = A[7];
+    double a31 = A[2], a32 = A[5], a33 = A[8];
+    return a11 * a22 * a33 + a12 * a23 * a31 + a13 * a21 * a32 - a13 * a22 * a31 - a12 * a21 * a33 - a11 * a23 * a32;
+}
+}  // namespace
+
+void prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, double density,
+               float* inv_mass, float* irp, float* irv) {
+    std::fill(inv_mass, inv_mass + nv, 0.0f);
+    const uint64_t total = 9ull * nt;
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        float* A = &irp[9 * e];
+        edge_matrix(verts, t, A);
+        const double det = det3(A);
+        const double V = det / 6.0;
+        if (det == 0.0) {
+            // Softbody.js:391-394 clears A[e .. e+8] of the WHOLE array (the index lacks the *9);
+            // out-of-range typed-array writes are dropped.
+            for (uint64_t i = 0; i < 9; i++)
+                if (e + i < total) irp[e + i] = 0.0f;
+        } else {
+            const double invDet = 1.0 / det;
+            const double a11 = A[0], a12 = A[3], a13 = A[6];
+            const double a21 = A[1], a22 = A[4], a23 = A[7];
+            const double a31 = A[2], a32 = A[5], a33 = A[8];
+            A[0] = fround((a22 * a33 - a23 * a32) * invDet);
+            A[3] = fround(-(a12 * a33 - a13 * a32) * invDet);
+            A[6] = fround((a12 * a23 - a13 * a22) * invDet);
+            A[1] = fround(-(a21 * a33 - a23 * a31) * invDet);
+            A[4] = fround((a11 * a33 - a13 * a31) * invDet);
+            A[7] = fround(-(a11 * a23 - a13 * a21) * invDet);
+            A[2] = fround((a21 * a32 - a22 * a31) * invDet);
+            A[5] = fround(-(a11 * a32 - a12 * a31) * invDet);
+            A[8] = fround((a11 * a22 - a12 * a21) * invDet);
+        }
+        const double pm = V / 4.0 * density;
+        for (int k = 0; k < 4; k++) inv_mass[t[k]] = fround(static_cast<double>(inv_mass[t[k]]) + pm);
+        irv[e] = fround(1.0 / V);
+    }
+    for (uint32_t i = 0; i < nv; i++)
+        if (inv_mass[i] != 0.0f) inv_mass[i] = fround(1.0 / static_cast<double>(inv_mass[i]));
+}
+
+float pj_inv_rest_volume(const float* verts, const int32_t* tet) {
+    float m[9];
+    edge_matrix(verts, tet, m);
+    return fround(1.0 / (det3(m) / 6.0));
+}
+
+uint32_t prep_levels(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* level) {
+    std::vector<int32_t> last(nv, -1);  // level of the latest tet touching each vertex
+    int32_t top = -1;
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        int32_t l = std::max(std::max(last[t[0]], last[t[1]]), std::max(last[t[2]], last[t[3]])) + 1;
+        level[e] = l;
+        last[t[0]] = last[t[1]] = last[t[2]] = last[t[3]] = l;
+        top = std::max(top, l);
+    }
+    return static_cast<uint32_t>(top + 1);
+}
+
+uint32_t prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* colour) {
+    // per-vertex bitset of used colours, grown in 64-colour words
+    std::vector<std::vector<uint64_t>> used(nv);
+    uint32_t ncol = 0;
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        size_t words = 0;
+        for (int k = 0; k < 4; k++) words = std::max(words, used[t[k]].size());
+        int32_t c = -1;
+        for (size_t w = 0; w <= words && c < 0; w++) {
+            uint64_t m = 0;
+            for (int k = 0; k < 4; k++)
+                if (w < used[t[k]].size()) m |= used[t[k]][w];
+            if (~m) c = static_cast<int32_t>(64 * w + __builtin_ctzll(~m));
+        }
+        colour[e] = c;
+        for (int k = 0; k < 4; k++) {
+            auto& u = used[t[k]];
+            if (u.size() <= static_cast<size_t>(c / 64)) u.resize(c / 64 + 1, 0);
+            u[c / 64] |= 1ull << (c % 64);
+        }
+        ncol = std::max<uint32_t>(ncol, c + 1);
+    }
+    return ncol;
+}
+
+Incidence build_incidence(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, bool ref_cap) {
+    Incidence inc;
+    std::vector<uint32_t> count(nv, 0);
+    for (uint64_t i = 0; i < 4ull * nt; i++) count[tets[i]]++;
+    // SoftbodyGPU.js:568: a slot holding the encoded value 0 (tet 0, corner 0) passes the `<= 0.0`
+    // "empty" test, so the particle's NEXT incidence overwrites it: that contribution is lost iff the
+    // particle has another incident tet.
+    const int32_t quirk_vertex = (ref_quirk && nt > 0 && count[tets[0]] >= 2) ? tets[0] : -1;
+    inc.offset.assign(nv + 1, 0);
+    for (uint32_t v = 0; v < nv; v++) {
+        uint32_t c = count[v];
+        if (static_cast<int32_t>(v) == quirk_vertex) c--;
+        if (ref_cap && c > kRefSlots) c = kRefSlots;  // valence beyond 36 is silently dropped
+        inc.offset[v + 1] = inc.offset[v] + c;
+        inc.max_valence = std::max(inc.max_valence, c);
+    }
+    inc.slot.assign(inc.offset[nv], -1);
+    std::vector<uint32_t> fill(nv, 0);
+    uint64_t kept = 0;
+    for (uint32_t e = 0; e < nt; e++)
+        for (int k = 0; k < 4; k++) {
+            const int32_t v = tets[4 * e + k];
+            if (v == quirk_vertex && e == 0 && k == 0) continue;
+            const uint32_t cap = inc.offset[v + 1] - inc.offset[v];
+            if (fill[v] >= cap) continue;
+            inc.slot[inc.offset[v] + fill[v]++] = static_cast<int32_t>(4 * e + k);
+            kept++;
+        }
+    inc.dropped = static_cast<uint32_t>(4ull * nt - kept);
+    return inc;
+}
+
+uint32_t prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, int32_t* slots) {
+    std::fill(slots, slots + static_cast<size_t>(nv) * kRefSlots, -1);
+    // direct emulation of the reference's fill loop (kept independent of build_incidence on purpose:
+    // the unit tests cross-check the two).
+    uint32_t dropped = 0;
+    for (uint32_t e = 0; e < nt; e++)
+        for (int k = 0; k < 4; k++) {
+            int32_t* row = &slots[static_cast<size_t>(tets[4 * e + k]) * kRefSlots];
+            bool placed = false;
+            for (int s = 0; s < kRefSlots; s++) {
+                const bool empty = ref_quirk ? (row[s] <= 0) : (row[s] < 0);
+                if (empty) {
+                    if (row[s] == 0) dropped++;  // overwriting a live 0 entry
+                    row[s] = static_cast<int32_t>(4 * e + k);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) dropped++;
+        }
+    return dropped;
+}
+
+std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats) {
+    if ((nv && !verts) || (nt && !tets)) return "null mesh pointer";
+    if (nv == 0) return "mesh has no vertices";
+    if (nv > 0x3fffffffu || nt > 0x1fffffffu) return "mesh too large for 32-bit slot encoding";
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        for (int k = 0; k < 4; k++)
+            if (t[k] < 0 || static_cast<uint32_t>(t[k]) >= nv)
+                return "tet " + std::to_string(e) + " references vertex " + std::to_string(t[k]) + " outside [0," + std::to_string(nv) + ")";
+        if (forbid_repeats && (t[0] == t[1] || t[0] == t[2] || t[0] == t[3] || t[1] == t[2] || t[1] == t[3] || t[2] == t[3]))
+            return "tet " + std::to_string(e) + " repeats a vertex (unsupported by the parallel Gauss-Seidel schedule)";
+    }
+    return "";
+}
+
+std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
+                            const int32_t* vert_owner, Partition* out) {
+    Partition& P = *out;
+    P = Partition();
+    P.nv_global = nv;
+    P.nt_global = nt;
+    P.part_count = part_count;
+    P.part_index = part_index;
+    if (part_count < 1 || part_index < 0 || part_index >= part_count) return "bad part_index/part_count";
+
+    std::vector<int32_t> owner(nv);
+    if (vert_owner) {
+        for (uint32_t v = 0; v < nv; v++) {
+            if (vert_owner[v] < 0 || vert_owner[v] >= part_count) return "vert_owner out of range";
+            owner[v] = vert_owner[v];
+        }
+    } else {
+        for (uint32_t v = 0; v < nv; v++)
+            owner[v] = static_cast<int32_t>(std::min<uint64_t>(part_count - 1, static_cast<uint64_t>(v) * part_count / nv));
+    }
+    const int me = part_index;
+
+    // local tets = every tet with at least one owned vertex (ascending global id)
+    std::vector<char> is_ghost(nv, 0), is_boundary(nv, 0);
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        bool mine = false, foreign = false;
+        int lowest = part_count;
+        for (int k = 0; k < 4; k++) {
+            if (owner[t[k]] == me) mine = true; else foreign = true;
+            lowest = std::min(lowest, owner[t[k]]);
+        }
+        if (!mine) continue;
+        P.local_to_global_tet.push_back(static_cast<int32_t>(e));
+        if (lowest == me) P.owned_tets++;
+        if (foreign)
+            for (int k = 0; k < 4; k++) {
+                if (owner[t[k]] == me) is_boundary[t[k]] = 1;  // some other partition reads it as a ghost
+                else is_ghost[t[k]] = 1;
+            }
+    }
+    // NOTE: an owned vertex is a ghost of rank r iff it shares a tet with an r-owned vertex; that tet has
+    // an owned vertex of mine and a foreign one, so it is covered by the loop above.
+
+    // local vertex numbering: [owned boundary | owned interior | ghosts sorted by (owner, id)]
+    std::vector<int32_t> g2l(nv, -1);
+    for (uint32_t v = 0; v < nv; v++)
+        if (owner[v] == me && is_boundary[v]) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+    P.n_boundary = static_cast<uint32_t>(P.local_to_global_vert.size());
+    for (uint32_t v = 0; v < nv; v++)
+        if (owner[v] == me && !is_boundary[v]) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+    P.n_owned = static_cast<uint32_t>(P.local_to_global_vert.size());
+    std::vector<int32_t> ghosts;
+    for (uint32_t v = 0; v < nv; v++)
+        if (is_ghost[v]) ghosts.push_back(static_cast<int32_t>(v));
+    std::stable_sort(ghosts.begin(), ghosts.end(), [&](int32_t a, int32_t b) { return owner[a] < owner[b]; });
+    for (int32_t v : ghosts) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+
+    P.local_tets.resize(4 * P.local_to_global_tet.size());
+    for (size_t i = 0; i < P.local_to_global_tet.size(); i++)
+        for (int k = 0; k < 4; k++) P.local_tets[4 * i + k] = g2l[tets[4 * P.local_to_global_tet[i] + k]];
+
+    // halo lists.  recv from r = my ghosts owned by r (contiguous by construction).  send to r = my owned
+    // vertices that share a tet with an r-owned vertex (ascending global id): exactly r's ghosts owned by me.
+    std::vector<std::vector<int32_t>> send(part_count);
+    {
+        std::vector<uint64_t> pairs;  // (rank << 32 | vertex)
+        for (uint32_t e = 0; e < nt; e++) {
+            const int32_t* t = &tets[4 * e];
+            for (int a = 0; a < 4; a++) {
+                if (owner[t[a]] != me) continue;
+                for (int b = 0; b < 4; b++)
+                    if (owner[t[b]] != me) pairs.push_back((static_cast<uint64_t>(owner[t[b]]) << 32) | static_cast<uint32_t>(t[a]));
+            }
+        }
+        std::sort(pairs.begin(), pairs.end());
+        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+        for (uint64_t p : pairs) send[p >> 32].push_back(static_cast<int32_t>(p & 0xffffffffu));
+    }
+    size_t gpos = 0;
+    for (int r = 0; r < part_count; r++) {
+        if (r == me) continue;
+        Partition::Neighbour nb;
+        nb.rank = r;
+        nb.recv_start = P.n_owned + static_cast<uint32_t>(gpos);
+        while (gpos < ghosts.size() && owner[ghosts[gpos]] == r) { nb.recv_global.push_back(ghosts[gpos]); gpos++; }
+        nb.recv_count = static_cast<uint32_t>(nb.recv_global.size());
+        nb.send_global = send[r];
+        for (int32_t v : nb.send_global) nb.send_local.push_back(g2l[v]);
+        nb.send_contiguous = !nb.send_local.empty();
+        for (size_t i = 1; i < nb.send_local.size(); i++)
+            if (nb.send_local[i] != nb.send_local[i - 1] + 1) { nb.send_contiguous = false; break; }
+        if (nb.recv_count || !nb.send_local.empty()) P.neigh.push_back(std::move(nb));
+    }
+    return "";
+}
+
+}  // namespace tetsim

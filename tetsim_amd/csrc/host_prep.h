@@ -1,0 +1,59 @@
+// host_prep.h -- host-side preprocessing shared by the C ABI (no HIP dependency).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tetsim {
+
+constexpr int kRefSlots = 36;  // 9 RGBA tables, SoftbodyGPU.js:29-37
+
+// Softbody.js:60-87 in JS number semantics (f64 arithmetic, f32 stores).
+void prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, double density,
+               float* inv_mass, float* inv_rest_pose, float* inv_rest_volume);
+
+// Rest volume as SoftbodyGPU.js:579-589 computes it: fround(1 / (det(f32 edge matrix) / 6)).
+float pj_inv_rest_volume(const float* verts, const int32_t* tet);
+
+uint32_t prep_levels(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* level);
+uint32_t prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* colour);
+// returns dropped contributions
+uint32_t prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, int32_t* slots);
+
+// Per-vertex incident (tet,corner) lists in tet order, CSR.  ref_quirk: drop (tet 0, corner 0) as the
+// reference's `<= 0.0` slot test does (only meaningful when local tet 0 IS global tet 0); ref_cap: keep at
+// most 36 incidences per vertex.  With both, the lists equal the reference's 36-slot rows.
+struct Incidence {
+    std::vector<uint32_t> offset;  // [nv+1]
+    std::vector<int32_t> slot;     // 4*tet + corner
+    uint32_t max_valence = 0;
+    uint32_t dropped = 0;
+};
+Incidence build_incidence(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, bool ref_cap);
+
+// Domain decomposition plan for one partition (DESIGN.md "Multi-GPU").
+struct Partition {
+    uint32_t nv_global = 0, nt_global = 0;
+    int part_count = 1, part_index = 0;
+    std::vector<int32_t> local_to_global_vert;  // [owned boundary | owned interior | ghosts by (owner,id)]
+    uint32_t n_owned = 0, n_boundary = 0;
+    std::vector<int32_t> local_to_global_tet;   // ascending global id
+    std::vector<int32_t> local_tets;            // [4*nt_local] local vertex ids
+    uint32_t owned_tets = 0;                    // tets whose lowest-owner rule assigns them here
+    struct Neighbour {
+        int rank;
+        std::vector<int32_t> send_local;  // owned local ids, ascending global id
+        std::vector<int32_t> send_global;
+        uint32_t recv_start = 0, recv_count = 0;  // contiguous ghost range in local numbering
+        std::vector<int32_t> recv_global;
+        bool send_contiguous = false;
+    };
+    std::vector<Neighbour> neigh;
+};
+// vert_owner may be null (equal contiguous index ranges). Returns "" or an error message.
+std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
+                            const int32_t* vert_owner, Partition* out);
+
+std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
+
+}  // namespace tetsim

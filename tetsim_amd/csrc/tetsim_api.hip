@@ -1,0 +1,952 @@
+// tetsim_api.hip -- C ABI of libtetsim_hip.so (include/tetsim.h): handle lifecycle, host preprocessing,
+// stream/graph orchestration of the gfx950 kernels, halo transports (in-process copies, RCCL over xGMI).
+//
+// There is NO CPU fallback: every compute entry point needs a working HIP device and fails with
+// TETSIM_ENODEVICE / TETSIM_EHIP otherwise.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tetsim.h"
+#include "dev_common.h"
+#include "host_prep.h"
+
+using namespace tetsim;
+
+namespace {
+
+thread_local std::string g_create_error;
+constexpr int kRing = 64;  // pinned parameter slots in flight
+
+// ---- RCCL, resolved at run time so single-GPU hosts (and the N-API addon) do not need librccl ----------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+Rccl g_rccl;
+
+struct NeighDev {
+    int rank = -1;
+    uint32_t send_count = 0, recv_start = 0, recv_count = 0;
+    bool contiguous = false;
+    uint32_t send_first = 0;       // when contiguous: first local id
+    int32_t* send_idx = nullptr;   // device, when not contiguous
+    float4* send_buf = nullptr;    // device staging, when not contiguous
+    std::vector<int32_t> send_global, recv_global, send_local;
+};
+
+}  // namespace
+
+struct tetsim_body {
+    std::string err;
+    TetSimOptions opt{};
+    TetSimInfo info{};
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_boundary = nullptr, ev_halo = nullptr;
+    DevParams* d_params = nullptr;
+    DevParams* h_ring = nullptr;  // pinned [kRing]
+    hipEvent_t ring_ev[kRing] = {};
+    bool ring_used[kRing] = {};
+    int ring_pos = 0;
+    int32_t grab_global = -1;
+    float grab_pos[3] = {0, 0, 0};
+    std::map<uint32_t, hipGraphExec_t> graphs;
+    std::vector<void*> allocs;
+    std::vector<float> h_verts;
+    std::vector<int32_t> h_tets;
+    bool fast = false;
+
+    // POLAR_JACOBI
+    PJDev pj;
+    Partition part;
+    bool partitioned = false;
+    std::vector<int32_t> g2l_owned;  // global vertex -> local id (owned) or -1
+    std::vector<NeighDev> neigh;
+    bool pred_any_dt = true;  // velocities are all zero: the prediction is valid for every dt
+    float dt_pred = 0.0f;
+    ncclComm_t comm = nullptr;
+    int comm_rank = -1, comm_size = 0;
+
+    // NEOHOOKEAN_GS
+    NHDev nh;
+    std::vector<uint32_t> level_off;
+    std::vector<int32_t> order;
+    std::vector<float> h_inv_mass;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return TETSIM_EHIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+int fail(tetsim_body* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+template <class Tp>
+int dev_alloc(tetsim_body* h, Tp** p, size_t count) {
+    *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
+    void* raw = nullptr;
+    hipError_t e = hipMalloc(&raw, bytes);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e); return TETSIM_ENOMEM; }
+    h->allocs.push_back(raw);
+    h->info.device_bytes += bytes;
+    *p = static_cast<Tp*>(raw);
+    return 0;
+}
+template <class Tp>
+int upload(tetsim_body* h, Tp* dst, const std::vector<Tp>& src) {
+    if (src.empty()) return 0;
+    HIPCHK(h, hipMemcpy(dst, src.data(), src.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevParams* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->dt = static_cast<float>(dt);
+    o->gravity = static_cast<float>(p.gravity);
+    o->friction = static_cast<float>(p.friction);
+    const bool fixed = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI && (h->opt.flags & TETSIM_FLAG_REF_FIXED_BOUNDS);
+    const float ref_lo[3] = {-2.5f, -1.0f, -2.5f}, ref_hi[3] = {2.5f, 10.0f, 2.5f};  // SoftbodyGPU.js:347
+    for (int c = 0; c < 3; c++) {
+        o->lo[c] = fixed ? ref_lo[c] : static_cast<float>(p.worldBounds[c]);
+        o->hi[c] = fixed ? ref_hi[c] : static_cast<float>(p.worldBounds[3 + c]);
+        o->d_lo[c] = p.worldBounds[c];
+        o->d_hi[c] = p.worldBounds[3 + c];
+        o->grab[c] = h->grab_pos[c];
+    }
+    o->grab_local = -1;
+    if (h->grab_global >= 0) {
+        if (!h->partitioned) o->grab_local = h->grab_global;
+        else if (static_cast<size_t>(h->grab_global) < h->g2l_owned.size()) o->grab_local = h->g2l_owned[h->grab_global];
+    }
+    o->d_dt = dt;
+    o->d_gravity = p.gravity;
+    o->d_friction = p.friction;
+    o->d_dev_compliance = p.devCompliance;
+    o->d_vol_compliance = p.volCompliance;
+}
+
+// Stage the parameters of this call into a pinned ring slot and copy them to the device in stream order.
+int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
+    if (!params) return fail(h, TETSIM_EINVAL, "params is null");
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
+    const int slot = h->ring_pos;
+    h->ring_pos = (h->ring_pos + 1) % kRing;
+    if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
+    fill_params(h, dt, *params, &h->h_ring[slot]);
+    HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
+    h->ring_used[slot] = true;
+    return 0;
+}
+
+// ---- kernel sequencing ---------------------------------------------------------------------------------
+void pj_tet(tetsim_body* h) { h->fast ? pj_launch_tet_fast(h->stream, h->pj) : pj_launch_tet_precise(h->stream, h->pj); }
+void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count) {
+    h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count) : pj_launch_vertex_precise(h->stream, h->pj, first, count);
+}
+void pj_repredict(tetsim_body* h) { h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj); }
+
+int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
+    return fail(h, TETSIM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
+}
+
+// Ghost positions travel once per substep: owned interface predictions -> the neighbours' ghost ranges.
+// Issued after the boundary vertices are final; the interior vertex kernel overlaps the transfer.
+int halo_rccl(tetsim_body* h) {
+    for (auto& nb : h->neigh)
+        if (!nb.contiguous && nb.send_count) util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+    HIPCHK(h, hipEventRecord(h->ev_boundary, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
+    for (auto& nb : h->neigh) {
+        if (nb.send_count) {
+            const float4* src = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
+            r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+            if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
+        }
+        if (nb.recv_count) {
+            r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+            if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
+        }
+    }
+    r = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
+    HIPCHK(h, hipEventRecord(h->ev_halo, h->comm_stream));
+    return 0;
+}
+
+// one substep's launches (parameters already on the device)
+int enqueue_substep(tetsim_body* h) {
+    if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
+        pj_tet(h);
+        if (h->comm && !h->neigh.empty()) {
+            pj_vertex(h, 0, h->pj.nv_boundary);
+            int rc = halo_rccl(h);
+            if (rc) return rc;
+            pj_vertex(h, h->pj.nv_boundary, h->pj.nv_owned - h->pj.nv_boundary);
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_halo, 0));  // next tet kernel gathers the ghosts
+        } else {
+            pj_vertex(h, 0, h->pj.nv_owned);
+        }
+    } else {
+        h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
+        for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
+            const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
+            h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        }
+        h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// POLAR_JACOBI keeps x* = x + v*dt precomputed by the previous vertex kernel; redo it if dt changed.
+int ensure_prediction(tetsim_body* h, double dt) {
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return 0;
+    const float fdt = static_cast<float>(dt);
+    if (!h->pred_any_dt && fdt != h->dt_pred) {
+        if (h->partitioned && !h->neigh.empty())
+            return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body (ghost predictions would be stale)");
+        pj_repredict(h);
+    }
+    h->pred_any_dt = false;
+    h->dt_pred = fdt;
+    return 0;
+}
+
+int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out) {
+    if (!out) return fail(h, TETSIM_EINVAL, "output pointer is null");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    std::vector<float4> tmp(n);
+    if (n) HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { out[3 * i] = tmp[i].x; out[3 * i + 1] = tmp[i].y; out[3 * i + 2] = tmp[i].z; }
+    return 0;
+}
+
+// ---- construction ----------------------------------------------------------------------------------------
+int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt) {
+    const TetSimOptions& o = h->opt;
+    const bool ref_table = (o.flags & TETSIM_FLAG_REF_SLOT_TABLE) != 0;
+    std::vector<int32_t> ltets;   // local connectivity
+    std::vector<int32_t> l2g_v, l2g_t;
+    uint32_t nvl = nv, nvo = nv, nvb = 0, ntl = nt;
+    h->partitioned = o.part_count > 1;
+    if (h->partitioned) {
+        std::string e = build_partition(tets, nt, nv, o.part_count, o.part_index, o.vert_owner, &h->part);
+        if (!e.empty()) return fail(h, TETSIM_EINVAL, e);
+        const Partition& P = h->part;
+        ltets = P.local_tets;
+        l2g_v = P.local_to_global_vert;
+        l2g_t = P.local_to_global_tet;
+        nvl = static_cast<uint32_t>(l2g_v.size());
+        nvo = P.n_owned;
+        nvb = P.n_boundary;
+        ntl = static_cast<uint32_t>(l2g_t.size());
+        h->g2l_owned.assign(nv, -1);
+        for (uint32_t i = 0; i < nvo; i++) h->g2l_owned[l2g_v[i]] = static_cast<int32_t>(i);
+        h->info.owned_elems = P.owned_tets;
+    } else {
+        ltets.assign(tets, tets + 4ull * nt);
+        h->info.owned_elems = nt;
+    }
+    const bool quirk_here = ref_table && ntl > 0 && (!h->partitioned || l2g_t[0] == 0);
+    Incidence inc = build_incidence(ltets.data(), ntl, nvl, quirk_here, ref_table);
+    // Only owned vertices are averaged here; the table rows of ghosts are never read.
+    uint32_t maxv = 0;
+    for (uint32_t v = 0; v < nvo; v++) maxv = std::max(maxv, inc.offset[v + 1] - inc.offset[v]);
+
+    PJDev& d = h->pj;
+    d.nv_local = nvl; d.nv_owned = nvo; d.nv_boundary = nvb; d.nt = ntl;
+    d.nt_pad = (ntl + 63u) & ~63u;
+    d.nv_pad = (nvo + 63u) & ~63u;
+    d.max_valence = maxv;
+    h->info.owned_particles = nvo;
+    h->info.local_particles = nvl;
+    h->info.local_elems = ntl;
+    h->info.max_valence = maxv;
+    h->info.dropped_slots = inc.dropped;
+
+    int rc;
+    if ((rc = dev_alloc(h, &d.pos_pred, nvl))) return rc;
+    if ((rc = dev_alloc(h, &d.pos_final, nvl))) return rc;
+    if ((rc = dev_alloc(h, &d.vel, nvl))) return rc;
+    if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
+    if ((rc = dev_alloc(h, &d.elem, 4ull * d.nt_pad))) return rc;
+    if ((rc = dev_alloc(h, &d.quat, ntl))) return rc;
+    if ((rc = dev_alloc(h, &d.slot_tab, static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad))) return rc;
+    if ((rc = dev_alloc(h, &d.slot_cnt, d.nv_pad))) return rc;
+    d.params = h->d_params;
+
+    std::vector<float4> pos(nvl);
+    for (uint32_t i = 0; i < nvl; i++) {
+        const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
+        pos[i] = make_float4(verts[3 * g], verts[3 * g + 1], verts[3 * g + 2], 0.0f);
+    }
+    if ((rc = upload(h, d.pos_pred, pos))) return rc;
+    if ((rc = upload(h, d.pos_final, pos))) return rc;
+    HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nvl, 1) * sizeof(float4)));
+
+    std::vector<int4> idx(ntl);
+    std::vector<float4> elem(4ull * d.nt_pad, make_float4(0, 0, 0, 0)), quat(ntl, make_float4(0, 0, 0, 1));
+    for (uint32_t e = 0; e < ntl; e++) {
+        const int32_t* lt = &ltets[4 * e];
+        idx[e] = make_int4(lt[0], lt[1], lt[2], lt[3]);
+        const uint32_t ge = h->partitioned ? static_cast<uint32_t>(l2g_t[e]) : e;
+        // the weight the reference's P4 writes into elems.w: 1.0 / texture(invRestVolume).x, in f32
+        // (SoftbodyGPU.js:220,259-262 with invRestVolume = fround(1/V), :582-589)
+        const float w = 1.0f / pj_inv_rest_volume(verts, &tets[4 * ge]);
+        for (int k = 0; k < 4; k++) {
+            const float4 p = pos[lt[k]];
+            elem[static_cast<size_t>(k) * d.nt_pad + e] = make_float4(p.x, p.y, p.z, w);
+        }
+    }
+    if ((rc = upload(h, d.tet_idx, idx))) return rc;
+    if ((rc = upload(h, d.elem, elem))) return rc;
+    if ((rc = upload(h, d.quat, quat))) return rc;
+
+    std::vector<int32_t> tab(static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad, 0);
+    std::vector<uint32_t> cnt(d.nv_pad, 0);
+    for (uint32_t v = 0; v < nvo; v++) {
+        const uint32_t c = inc.offset[v + 1] - inc.offset[v];
+        cnt[v] = c;
+        for (uint32_t s = 0; s < c; s++) {
+            const int32_t enc = inc.slot[inc.offset[v] + s];
+            tab[static_cast<size_t>(s) * d.nv_pad + v] = static_cast<int32_t>((enc & 3) * d.nt_pad + (enc >> 2));
+        }
+    }
+    if ((rc = upload(h, d.slot_tab, tab))) return rc;
+    if ((rc = upload(h, d.slot_cnt, cnt))) return rc;
+
+    if (h->partitioned) {
+        for (const auto& nb : h->part.neigh) {
+            NeighDev nd;
+            nd.rank = nb.rank;
+            nd.send_count = static_cast<uint32_t>(nb.send_local.size());
+            nd.recv_start = nb.recv_start;
+            nd.recv_count = nb.recv_count;
+            nd.contiguous = nb.send_contiguous;
+            nd.send_first = nd.send_count ? static_cast<uint32_t>(nb.send_local[0]) : 0;
+            nd.send_global = nb.send_global;
+            nd.recv_global = nb.recv_global;
+            nd.send_local = nb.send_local;
+            if (nd.send_count) {  // staging is always available (tetsim_halo_export, non-contiguous sends)
+                if ((rc = dev_alloc(h, &nd.send_idx, nd.send_count))) return rc;
+                if ((rc = dev_alloc(h, &nd.send_buf, nd.send_count))) return rc;
+                if ((rc = upload(h, nd.send_idx, nb.send_local))) return rc;
+            }
+            h->neigh.push_back(std::move(nd));
+        }
+        h->info.num_neighbours = static_cast<uint32_t>(h->neigh.size());
+    }
+    return 0;
+}
+
+int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt) {
+    const TetSimOptions& o = h->opt;
+    if (o.part_count > 1) return fail(h, TETSIM_EINVAL, "NEOHOOKEAN_GS does not partition (one halo per colour would be needed); use POLAR_JACOBI");
+    // 1. element order
+    std::vector<int32_t> pre(nt);
+    for (uint32_t e = 0; e < nt; e++) pre[e] = static_cast<int32_t>(e);
+    if (o.order == TETSIM_ORDER_COLOURED) {
+        std::vector<int32_t> colour(nt);
+        prep_colours(tets, nt, nv, colour.data());
+        std::stable_sort(pre.begin(), pre.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+    }
+    std::vector<int32_t> ptets(4ull * nt);
+    for (uint32_t i = 0; i < nt; i++) std::memcpy(&ptets[4 * i], &tets[4 * pre[i]], 4 * sizeof(int32_t));
+    // 2. rest data in the order the reference would see (mass accumulation is order dependent, Softbody.js:74-78)
+    std::vector<float> irp(9ull * nt), irv(nt);
+    h->h_inv_mass.assign(nv, 0.0f);
+    prep_rest(verts, nv, ptets.data(), nt, o.density, h->h_inv_mass.data(), irp.data(), irv.data());
+    // 3. dependency levels of that order; solve order = stable sort by level
+    std::vector<int32_t> level(nt);
+    const uint32_t nl = prep_levels(ptets.data(), nt, nv, level.data());
+    std::vector<int32_t> pos_in(nt);
+    for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(i);
+    std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+    h->level_off.assign(nl + 1, 0);
+    for (uint32_t i = 0; i < nt; i++) h->level_off[level[i] + 1]++;
+    for (uint32_t l = 0; l < nl; l++) h->level_off[l + 1] += h->level_off[l];
+    h->order.resize(nt);  // solve position -> caller's tet id, for the PERMUTED sequence the reference must be fed
+    std::vector<int32_t> seq(nt);
+    for (uint32_t i = 0; i < nt; i++) seq[i] = pre[i];
+    h->order = seq;  // tetsim_get_tet_order: the sequential order whose result we reproduce
+    h->info.num_levels = nl;
+    h->info.owned_particles = h->info.local_particles = nv;
+    h->info.local_elems = h->info.owned_elems = nt;
+
+    NHDev& d = h->nh;
+    d.nv = nv; d.nt = nt;
+    int rc;
+    if ((rc = dev_alloc(h, &d.pos, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.prev, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.vel, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.tet_idx, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_a, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_b, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_c, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.vol_err, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.order, nt))) return rc;
+    d.params = h->d_params;
+
+    std::vector<float4> pos(nv);
+    for (uint32_t i = 0; i < nv; i++) pos[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], h->h_inv_mass[i]);
+    if ((rc = upload(h, d.pos, pos))) return rc;
+    if ((rc = upload(h, d.prev, pos))) return rc;
+    HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nv, 1) * sizeof(float4)));
+    HIPCHK(h, hipMemset(d.vol_err, 0, std::max<size_t>(nt, 1) * sizeof(double)));
+    std::vector<int4> idx(nt);
+    std::vector<float4> a(nt), b(nt), c(nt);
+    std::vector<int32_t> ord(nt);
+    for (uint32_t s = 0; s < nt; s++) {
+        const uint32_t i = static_cast<uint32_t>(pos_in[s]);  // position in the permuted sequential order
+        const int32_t* t = &ptets[4 * i];
+        idx[s] = make_int4(t[0], t[1], t[2], t[3]);
+        const float* m = &irp[9 * i];
+        a[s] = make_float4(m[0], m[1], m[2], m[3]);
+        b[s] = make_float4(m[4], m[5], m[6], m[7]);
+        c[s] = make_float4(m[8], irv[i], 0.0f, 0.0f);
+        ord[s] = static_cast<int32_t>(i);  // vol_err is indexed by sequential position
+    }
+    if ((rc = upload(h, d.tet_idx, idx))) return rc;
+    if ((rc = upload(h, d.irp_a, a))) return rc;
+    if ((rc = upload(h, d.irp_b, b))) return rc;
+    if ((rc = upload(h, d.irp_c, c))) return rc;
+    if ((rc = upload(h, d.order, ord))) return rc;
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================================
+extern "C" {
+
+int tetsim_abi_version(void) { return TETSIM_ABI_VERSION; }
+
+void tetsim_default_options(TetSimOptions* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->solver = TETSIM_SOLVER_POLAR_JACOBI;
+    o->precision = TETSIM_PRECISE;
+    o->order = TETSIM_ORDER_ORIGINAL;
+    o->flags = TETSIM_FLAG_REF_SLOT_TABLE | TETSIM_FLAG_REF_FIXED_BOUNDS;
+    o->device = 0;
+    o->density = 1000.0;
+    o->part_count = 1;
+    o->part_index = 0;
+    o->vert_owner = nullptr;
+}
+
+void tetsim_default_params(TetSimParams* p) {  // main.js:22-36
+    if (!p) return;
+    p->gravity = -9.81;
+    p->friction = 1000.0;
+    p->devCompliance = 1.0 / 100000.0;
+    p->volCompliance = 0.0;
+    const double wb[6] = {-2.5, -1.0, -2.5, 2.5, 10.0, 2.5};
+    std::memcpy(p->worldBounds, wb, sizeof(wb));
+}
+
+const char* tetsim_last_error(tetsim_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, const TetSimOptions* opts, tetsim_handle* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "out handle pointer is null");
+    *out = nullptr;
+    TetSimOptions o;
+    if (opts) o = *opts; else tetsim_default_options(&o);
+    if (o.solver != TETSIM_SOLVER_POLAR_JACOBI && o.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(nullptr, TETSIM_EINVAL, "unknown solver");
+    if (o.precision != TETSIM_PRECISE && o.precision != TETSIM_FAST) return fail(nullptr, TETSIM_EINVAL, "unknown precision");
+    if (o.part_count < 1) o.part_count = 1;
+    std::string merr = validate_mesh(verts, nv, tets, nt, o.solver == TETSIM_SOLVER_NEOHOOKEAN_GS);
+    if (!merr.empty()) return fail(nullptr, TETSIM_EINVAL, merr);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, TETSIM_ENODEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                                   "); libtetsim_hip has no CPU fallback");
+    if (o.device < 0 || o.device >= ndev) return fail(nullptr, TETSIM_ENODEVICE, "device ordinal out of range");
+
+    tetsim_body* h = new tetsim_body();
+    h->opt = o;
+    h->opt.vert_owner = nullptr;  // not retained
+    h->fast = o.precision == TETSIM_FAST;
+    h->info.num_particles = nv;
+    h->info.num_elems = nt;
+    h->info.solver = o.solver; h->info.precision = o.precision; h->info.order = o.order; h->info.device = o.device; h->info.flags = o.flags;
+    h->h_verts.assign(verts, verts + 3ull * nv);
+    h->h_tets.assign(tets, tets + 4ull * nt);
+
+    auto bail = [&](int rc) { g_create_error = h->err; tetsim_destroy(h); return rc; };
+    auto hipok = [&](hipError_t er, const char* what) { if (er != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(er); return false; } return true; };
+    if (!hipok(hipSetDevice(o.device), "hipSetDevice")) return bail(TETSIM_EHIP);
+    if (!hipok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(TETSIM_EHIP);
+    if (!hipok(hipEventCreate(&h->ev_a), "hipEventCreate") || !hipok(hipEventCreate(&h->ev_b), "hipEventCreate")) return bail(TETSIM_EHIP);
+    if (!hipok(hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
+    if (!hipok(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
+    for (int i = 0; i < kRing; i++)
+        if (!hipok(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
+    if (!hipok(hipHostMalloc(reinterpret_cast<void**>(&h->h_ring), sizeof(DevParams) * kRing, hipHostMallocDefault), "hipHostMalloc")) return bail(TETSIM_EHIP);
+    { int rc = dev_alloc(h, &h->d_params, 1); if (rc) return bail(rc); }
+
+    TetSimOptions with_owner = o;  // vert_owner is only read during construction
+    h->opt.vert_owner = with_owner.vert_owner;
+    int rc = o.solver == TETSIM_SOLVER_POLAR_JACOBI ? create_polar(h, verts, nv, tets, nt) : create_neohookean(h, verts, nv, tets, nt);
+    h->opt.vert_owner = nullptr;
+    if (rc) return bail(rc);
+    if (!hipok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return bail(TETSIM_EHIP);
+    *out = h;
+    return TETSIM_OK;
+}
+
+void tetsim_destroy(tetsim_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->opt.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+    for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_boundary, h->ev_halo}) if (ev) (void)hipEventDestroy(ev);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int tetsim_get_info(tetsim_handle h, TetSimInfo* info) {
+    if (!h || !info) return fail(h, TETSIM_EINVAL, "null argument");
+    *info = h->info;
+    return 0;
+}
+
+int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
+    if (!h) return TETSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    int rc = push_params(h, dt, params);
+    if (rc) return rc;
+    if ((rc = ensure_prediction(h, dt))) return rc;
+    return enqueue_substep(h);
+}
+
+int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params) {
+    if (!h) return TETSIM_EINVAL;
+    if (n == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    int rc = push_params(h, dt, params);
+    if (rc) return rc;
+    if ((rc = ensure_prediction(h, dt))) return rc;
+    if (h->comm && !h->neigh.empty()) {  // RCCL transfers are issued eagerly (two streams, no capture)
+        for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+        return rc;
+    }
+    auto it = h->graphs.find(n);
+    if (it == h->graphs.end()) {
+        hipGraphExec_t exec = nullptr;
+        if ((rc = build_graph(h, n, &exec))) return rc;
+        it = h->graphs.emplace(n, exec).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+    return 0;
+}
+
+int tetsim_sync(tetsim_handle h) {
+    if (!h) return TETSIM_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    return 0;
+}
+
+int tetsim_read_positions(tetsim_handle h, float* out) {
+    if (!h) return TETSIM_EINVAL;
+    return h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI ? read_float4_as_xyz(h, h->pj.pos_final, h->pj.nv_owned, out)
+                                                       : read_float4_as_xyz(h, h->nh.pos, h->nh.nv, out);
+}
+int tetsim_read_prev_positions(tetsim_handle h, float* out) {
+    if (!h) return TETSIM_EINVAL;
+    if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI)
+        return fail(h, TETSIM_ESTATE, "POLAR_JACOBI does not keep prevPos after a substep (it equals the previous read_positions)");
+    return read_float4_as_xyz(h, h->nh.prev, h->nh.nv, out);
+}
+int tetsim_read_velocities(tetsim_handle h, float* out) {
+    if (!h) return TETSIM_EINVAL;
+    return h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI ? read_float4_as_xyz(h, h->pj.vel, h->pj.nv_owned, out)
+                                                       : read_float4_as_xyz(h, h->nh.vel, h->nh.nv, out);
+}
+int tetsim_read_quats(tetsim_handle h, float* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "quaternions exist only for POLAR_JACOBI");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->pj.nt) HIPCHK(h, hipMemcpy(out, h->pj.quat, h->pj.nt * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int tetsim_read_vol_error(tetsim_handle h, double* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(h, TETSIM_ESTATE, "volError exists only for NEOHOOKEAN_GS");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<double> ve(h->nh.nt);
+    if (h->nh.nt) HIPCHK(h, hipMemcpy(ve.data(), h->nh.vol_err, h->nh.nt * sizeof(double), hipMemcpyDeviceToHost));
+    double s = 0.0;  // Softbody.js:163 accumulates in element order; :209 divides by numElems
+    for (double v : ve) s += v;
+    *out = s / static_cast<double>(h->nh.nt);
+    return 0;
+}
+int tetsim_write_state(tetsim_handle h, const float* pos, const float* vel) {
+    if (!h || !pos || !vel) return fail(h, TETSIM_EINVAL, "null argument");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    const uint32_t n = pjs ? h->pj.nv_owned : h->nh.nv;
+    std::vector<float4> p(n), v(n);
+    for (uint32_t i = 0; i < n; i++) {
+        p[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pjs ? 0.0f : h->h_inv_mass[i]);
+        v[i] = make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.0f);
+    }
+    if (pjs) {
+        if (h->partitioned && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "write_state is not supported on partitioned bodies");
+        if (n) { HIPCHK(h, hipMemcpy(h->pj.pos_final, p.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+                 HIPCHK(h, hipMemcpy(h->pj.pos_pred, p.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+                 HIPCHK(h, hipMemcpy(h->pj.vel, v.data(), n * sizeof(float4), hipMemcpyHostToDevice)); }
+        h->pred_any_dt = false;
+        h->dt_pred = std::nanf("");  // forces a re-prediction at the next step
+    } else if (n) {
+        HIPCHK(h, hipMemcpy(h->nh.pos, p.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->nh.vel, v.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int tetsim_get_owned_ids(tetsim_handle h, int32_t* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    const uint32_t n = h->info.owned_particles;
+    for (uint32_t i = 0; i < n; i++) out[i] = h->partitioned ? h->part.local_to_global_vert[i] : static_cast<int32_t>(i);
+    return 0;
+}
+int tetsim_get_local_tets(tetsim_handle h, int32_t* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    const uint32_t n = h->info.local_elems;
+    for (uint32_t i = 0; i < n; i++) out[i] = h->partitioned ? h->part.local_to_global_tet[i] : static_cast<int32_t>(i);
+    return 0;
+}
+int tetsim_get_tet_order(tetsim_handle h, int32_t* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(h, TETSIM_ESTATE, "tet order exists only for NEOHOOKEAN_GS");
+    std::copy(h->order.begin(), h->order.end(), out);
+    return 0;
+}
+int tetsim_get_level_offsets(tetsim_handle h, int32_t* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(h, TETSIM_ESTATE, "levels exist only for NEOHOOKEAN_GS");
+    for (size_t i = 0; i < h->level_off.size(); i++) out[i] = static_cast<int32_t>(h->level_off[i]);
+    return 0;
+}
+int tetsim_read_inv_mass(tetsim_handle h, float* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver == TETSIM_SOLVER_NEOHOOKEAN_GS) { std::copy(h->h_inv_mass.begin(), h->h_inv_mass.end(), out); return 0; }
+    const uint32_t nv = h->info.num_particles, nt = h->info.num_elems;
+    std::vector<float> irp(9ull * nt), irv(nt);
+    prep_rest(h->h_verts.data(), nv, h->h_tets.data(), nt, h->opt.density, out, irp.data(), irv.data());
+    return 0;
+}
+
+int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {
+    if (!h) return TETSIM_EINVAL;
+    if (id >= static_cast<int32_t>(h->info.num_particles)) return fail(h, TETSIM_EINVAL, "grab id out of range");
+    h->grab_global = id < 0 ? -1 : id;
+    if (xyz) std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
+    return 0;
+}
+int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
+    if (!h || !xyz) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->partitioned) return fail(h, TETSIM_ESTATE, "start_grab on a partitioned body: pick the particle on the host and use tetsim_set_grab");
+    // As GPUGrabber.start does (SoftbodyGPU.js:790-795): read the positions back, then the argmin of
+    // Softbody.js:279-291 (f64 squared distance, first minimum wins).
+    const uint32_t n = h->info.num_particles;
+    std::vector<float> pos(3ull * n);
+    int rc = tetsim_read_positions(h, pos.data());
+    if (rc) return rc;
+    double best = 1.7976931348623157e308;
+    int32_t id = -1;
+    for (uint32_t i = 0; i < n; i++) {
+        const double a0 = static_cast<double>(xyz[0]) - pos[3 * i], a1 = static_cast<double>(xyz[1]) - pos[3 * i + 1], a2 = static_cast<double>(xyz[2]) - pos[3 * i + 2];
+        const double d2 = a0 * a0 + a1 * a1 + a2 * a2;
+        if (d2 < best) { best = d2; id = static_cast<int32_t>(i); }
+    }
+    h->grab_global = id;
+    std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
+    if (id_out) *id_out = id;
+    return 0;
+}
+
+int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params, TetSimProfile* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->comm && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "profile a partitioned body through rocprofv3 instead");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    std::memset(out, 0, sizeof(*out));
+    int rc = push_params(h, dt, params);
+    if (rc) return rc;
+    if ((rc = ensure_prediction(h, dt))) return rc;
+    std::vector<hipEvent_t> ev(3ull * n + 1);
+    for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    HIPCHK(h, hipEventRecord(ev[0], h->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        if (pjs) {
+            pj_tet(h);
+            HIPCHK(h, hipEventRecord(ev[3 * i + 1], h->stream));
+            pj_vertex(h, 0, h->pj.nv_owned);
+            HIPCHK(h, hipEventRecord(ev[3 * i + 2], h->stream));
+            HIPCHK(h, hipEventRecord(ev[3 * i + 3], h->stream));
+        } else {
+            h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
+            HIPCHK(h, hipEventRecord(ev[3 * i + 1], h->stream));
+            for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
+                const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
+                h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+            }
+            HIPCHK(h, hipEventRecord(ev[3 * i + 2], h->stream));
+            h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+            HIPCHK(h, hipEventRecord(ev[3 * i + 3], h->stream));
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        float a = 0, b = 0, c = 0;
+        HIPCHK(h, hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+        HIPCHK(h, hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+        HIPCHK(h, hipEventElapsedTime(&c, ev[3 * i + 2], ev[3 * i + 3]));
+        if (pjs) { out->kernel_ms[TETSIM_K_TET] += a; out->kernel_ms[TETSIM_K_VERTEX] += b; out->launches[TETSIM_K_TET]++; out->launches[TETSIM_K_VERTEX]++; }
+        else { out->kernel_ms[TETSIM_K_VERTEX] += a + c; out->kernel_ms[TETSIM_K_TET] += b; out->launches[TETSIM_K_VERTEX] += 2; out->launches[TETSIM_K_TET] += static_cast<uint32_t>(h->level_off.size() - 1); }
+    }
+    HIPCHK(h, hipEventElapsedTime(&ms, ev[0], ev[3ull * n]));
+    out->total_ms = ms;
+    out->substeps = n;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+int tetsim_time_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params, double* ms_out) {
+    if (!h || !ms_out) return fail(h, TETSIM_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
+    int rc = tetsim_step_n(h, n, dt, params);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_b, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev_b));
+    float ms = 0.0f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    *ms_out = ms;
+    return 0;
+}
+
+int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps, double* gbps_out) {
+    if (!gbps_out || bytes < 16 || reps == 0) return fail(nullptr, TETSIM_EINVAL, "bad argument");
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, TETSIM_ENODEVICE, "no HIP device available");
+    if (!chk(hipSetDevice(device), "hipSetDevice")) return TETSIM_EHIP;
+    const uint64_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = TETSIM_OK;
+    if (!chk(hipMalloc(reinterpret_cast<void**>(&a), n * 16), "hipMalloc") || !chk(hipMalloc(reinterpret_cast<void**>(&b), n * 16), "hipMalloc")) rc = TETSIM_ENOMEM;
+    if (!rc && (!chk(hipStreamCreate(&s), "hipStreamCreate") || !chk(hipEventCreate(&e0), "hipEventCreate") || !chk(hipEventCreate(&e1), "hipEventCreate"))) rc = TETSIM_EHIP;
+    if (!rc) {
+        (void)hipMemsetAsync(a, 0x3c, n * 16, s);
+        for (int w = 0; w < 3; w++) util_launch_copy(s, a, b, n);
+        (void)hipEventRecord(e0, s);
+        for (uint32_t r = 0; r < reps; r++) util_launch_copy(s, (r & 1) ? b : a, (r & 1) ? a : b, n);
+        (void)hipEventRecord(e1, s);
+        if (!chk(hipEventSynchronize(e1), "hipEventSynchronize")) rc = TETSIM_EHIP;
+        float ms = 0.0f;
+        if (!rc && chk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime")) *gbps_out = 2.0 * static_cast<double>(n * 16) * reps / (static_cast<double>(ms) * 1.0e6);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------------------
+int tetsim_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, TETSIM_EINVAL, "null id buffer");
+    if (!g_rccl.load()) return fail(nullptr, TETSIM_ECOMM, g_rccl.err);
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, TETSIM_ECOMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t nranks) {
+    if (!h || !id128) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "halo exchange exists only for POLAR_JACOBI");
+    if (nranks != h->opt.part_count || rank != h->opt.part_index) return fail(h, TETSIM_EINVAL, "rank/nranks must equal part_index/part_count");
+    if (!g_rccl.load()) return fail(h, TETSIM_ECOMM, g_rccl.err);
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail(h, r, "ncclCommInitRank"); }
+    h->comm_rank = rank;
+    h->comm_size = nranks;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    return 0;
+}
+
+int tetsim_get_halo_plan(tetsim_handle h, int32_t* neigh, int32_t* send_counts, int32_t* recv_counts, int32_t* send_ids, int32_t* recv_ids) {
+    if (!h) return TETSIM_EINVAL;
+    size_t so = 0, ro = 0;
+    for (size_t i = 0; i < h->neigh.size(); i++) {
+        const NeighDev& nb = h->neigh[i];
+        if (neigh) neigh[i] = nb.rank;
+        if (send_counts) send_counts[i] = static_cast<int32_t>(nb.send_count);
+        if (recv_counts) recv_counts[i] = static_cast<int32_t>(nb.recv_count);
+        if (send_ids) std::copy(nb.send_global.begin(), nb.send_global.end(), send_ids + so);
+        if (recv_ids) std::copy(nb.recv_global.begin(), nb.recv_global.end(), recv_ids + ro);
+        so += nb.send_global.size();
+        ro += nb.recv_global.size();
+    }
+    return 0;
+}
+
+int tetsim_halo_export(tetsim_handle h, uint32_t n, float* out_xyzw) {
+    if (!h || !out_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    NeighDev& nb = h->neigh[n];
+    if (!nb.send_count) return 0;
+    util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out_xyzw, nb.send_buf, nb.send_count * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
+    if (!h || !in_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    NeighDev& nb = h->neigh[n];
+    if (!nb.recv_count) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->pj.pos_pred + nb.recv_start, in_xyzw, nb.recv_count * sizeof(float4), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tetsim_halo_exchange_local(tetsim_handle* hs, uint32_t count) {
+    if (!hs || count == 0) return TETSIM_EINVAL;
+    for (uint32_t i = 0; i < count; i++) {
+        if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i))
+            return fail(hs[i], TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition");
+    }
+    // every partition must have finished its vertex kernel before anyone's ghosts are overwritten
+    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    for (uint32_t i = 0; i < count; i++) {
+        tetsim_body* src = hs[i];
+        for (auto& nb : src->neigh) {
+            if (!nb.send_count) continue;
+            tetsim_body* dst = hs[nb.rank];
+            NeighDev* back = nullptr;
+            for (auto& r : dst->neigh) if (r.rank == static_cast<int>(i)) back = &r;
+            if (!back || back->recv_count != nb.send_count) return fail(src, TETSIM_ESTATE, "asymmetric halo plan");
+            const float4* from = nb.contiguous ? src->pj.pos_pred + nb.send_first : nb.send_buf;
+            if (!nb.contiguous) util_launch_gather4(src->stream, src->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+            HIPCHK(src, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, src->stream));
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    return 0;
+}
+
+// ---- host-only preprocessing ---------------------------------------------------------------------------------
+int tetsim_prep_levels(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* level, uint32_t* num_levels) {
+    if ((nt && (!tets || !level)) || !num_levels) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *num_levels = prep_levels(tets, nt, nv, level);
+    return 0;
+}
+int tetsim_prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* colour, uint32_t* num_colours) {
+    if ((nt && (!tets || !colour)) || !num_colours) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *num_colours = prep_colours(tets, nt, nv, colour);
+    return 0;
+}
+int tetsim_prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t ref_quirk, int32_t* slots, uint32_t* dropped) {
+    if ((nt && !tets) || !slots) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    const uint32_t d = prep_slot_table(tets, nt, nv, ref_quirk != 0, slots);
+    if (dropped) *dropped = d;
+    return 0;
+}
+int tetsim_prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, double density, float* inv_mass, float* inv_rest_pose, float* inv_rest_volume) {
+    if (!inv_mass || (nt && (!inv_rest_pose || !inv_rest_volume))) return TETSIM_EINVAL;
+    std::string e = validate_mesh(verts, nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    prep_rest(verts, nv, tets, nt, density, inv_mass, inv_rest_pose, inv_rest_volume);
+    return 0;
+}
+
+}  // extern "C"

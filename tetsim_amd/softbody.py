@@ -1,0 +1,236 @@
+"""Host-side mirror of the reference's solver objects over the C ABI (include/tetsim.h).
+
+`SoftBodyHIP` keeps the constructor + simulate()/endFrame()/grab surface of the reference's
+`SoftBody` (/root/reference/src/Softbody.js:3-298) and `SoftBodyGPU` (SoftbodyGPU.js:4-712) so the
+caller's loop (main.js:79-89) is unchanged:
+
+    body = SoftBodyHIP(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial, world)
+    for step in range(numSubsteps): body.simulate(dt, physicsParams)
+    body.endFrame()
+
+Only the physics is here (display meshes are three.js objects of the JavaScript host; the N-API twin of this
+class, tetsim_amd/node/SoftBodyHIP.js, owns those).  All compute happens in libtetsim_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import TetSimError  # noqa: F401
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def make_params(physicsParams):
+    """physicsParams object (main.js:22-36) -> TetSimParams."""
+    p = capi.TetSimParams()
+    capi.lib().tetsim_default_params(C.byref(p))
+    g = physicsParams.get if isinstance(physicsParams, dict) else (lambda k, d=None: getattr(physicsParams, k, d))
+    for k in ("gravity", "friction", "devCompliance", "volCompliance"):
+        v = g(k, None)
+        if v is not None:
+            setattr(p, k, float(v))
+    wb = g("worldBounds", None)
+    if wb is not None:
+        for i in range(6):
+            p.worldBounds[i] = float(wb[i])
+    return p
+
+
+class SoftBodyHIP:
+    """Drop-in for `new SoftBody(...)` / `new SoftBodyGPU(...)`; `solver` picks which one is mirrored.
+
+    solver="polar"  -> SoftBodyGPU's shape-matching Jacobi (default, like the reference's GPU path)
+    solver="neohookean" -> SoftBody's Neo-Hookean XPBD Gauss-Seidel
+    """
+
+    def __init__(self, vertices, tetIds, tetEdgeIds=None, physicsParams=None, visVerts=None, visTriIds=None,
+                 visMaterial=None, world=None, *, solver="polar", precision="precise", order="original",
+                 ref_slot_table=True, ref_fixed_bounds=True, device=0, part_count=1, part_index=0,
+                 vert_owner=None):
+        L = capi.lib()
+        self.physicsParams = physicsParams if physicsParams is not None else {}
+        self._verts = _f32(vertices).reshape(-1)
+        self._tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
+        if self._verts.size % 3 or self._tets.size % 4:
+            raise ValueError("vertices must hold 3 floats per particle and tetIds 4 ids per tet")
+        self.numParticles = self._verts.size // 3   # Softbody.js:9
+        self.numElems = self._tets.size // 4        # Softbody.js:10
+        self.visVerts = visVerts
+        self.grabId = -1
+        self.grabPos = np.zeros(3, dtype=np.float32)
+        o = capi.TetSimOptions()
+        L.tetsim_default_options(C.byref(o))
+        o.solver = {"polar": capi.SOLVER_POLAR_JACOBI, "neohookean": capi.SOLVER_NEOHOOKEAN_GS}[solver]
+        o.precision = {"precise": capi.PRECISE, "fast": capi.FAST}[precision]
+        o.order = {"original": capi.ORDER_ORIGINAL, "coloured": capi.ORDER_COLOURED}[order]
+        o.flags = (capi.FLAG_REF_SLOT_TABLE if ref_slot_table else 0) | (capi.FLAG_REF_FIXED_BOUNDS if ref_fixed_bounds else 0)
+        o.device = device
+        d = self.physicsParams.get("density", 1000.0) if isinstance(self.physicsParams, dict) else getattr(self.physicsParams, "density", 1000.0)
+        o.density = float(d)
+        o.part_count, o.part_index = part_count, part_index
+        self._owner = None
+        if vert_owner is not None:
+            self._owner = np.ascontiguousarray(vert_owner, dtype=np.int32)
+            o.vert_owner = _ip(self._owner)
+        self.solver = solver
+        self._h = C.c_void_p()
+        capi.check(L.tetsim_create(_fp(self._verts), self.numParticles, _ip(self._tets), self.numElems,
+                                   C.byref(o), C.byref(self._h)))
+        self.info = capi.TetSimInfo()
+        capi.check(L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
+        self._L = L
+
+    # -- lifecycle ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tetsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path ---------------------------------------------------------------------------------
+    def simulate(self, dt, physicsParams=None):
+        """One substep (Softbody.js:195 / SoftbodyGPU.js:610).  Asynchronous."""
+        pp = self.physicsParams if physicsParams is None else physicsParams
+        if isinstance(pp, dict) and self.solver == "polar":
+            pp["dt"] = dt  # SoftbodyGPU.js:611 writes dt back into the caller's object
+        capi.check(self._L.tetsim_step(self._h, float(dt), C.byref(make_params(pp))), self._h)
+
+    def simulateSubsteps(self, n, dt, physicsParams=None):
+        """The caller's whole substep loop (main.js:79-84) as ONE FFI crossing / one HIP-graph launch."""
+        pp = self.physicsParams if physicsParams is None else physicsParams
+        capi.check(self._L.tetsim_step_n(self._h, int(n), float(dt), C.byref(make_params(pp))), self._h)
+
+    def endFrame(self):
+        """Softbody.js:244-247 refreshes the display meshes from .pos; here: make the frame's results visible."""
+        capi.check(self._L.tetsim_sync(self._h), self._h)
+
+    def sync(self):
+        capi.check(self._L.tetsim_sync(self._h), self._h)
+
+    # -- state ----------------------------------------------------------------------------------------
+    def _read3(self, fn, n):
+        out = np.empty(3 * n, dtype=np.float32)
+        capi.check(fn(self._h, _fp(out)), self._h)
+        return out.reshape(-1, 3)
+
+    @property
+    def pos(self):
+        return self._read3(self._L.tetsim_read_positions, self.info.owned_particles)
+
+    @property
+    def prevPos(self):
+        return self._read3(self._L.tetsim_read_prev_positions, self.info.owned_particles)
+
+    @property
+    def vel(self):
+        return self._read3(self._L.tetsim_read_velocities, self.info.owned_particles)
+
+    @property
+    def quats(self):
+        out = np.empty(4 * self.info.local_elems, dtype=np.float32)
+        capi.check(self._L.tetsim_read_quats(self._h, _fp(out)), self._h)
+        return out.reshape(-1, 4)
+
+    @property
+    def volError(self):
+        v = C.c_double()
+        capi.check(self._L.tetsim_read_vol_error(self._h, C.byref(v)), self._h)
+        return v.value
+
+    @property
+    def invMass(self):
+        out = np.empty(self.numParticles, dtype=np.float32)
+        capi.check(self._L.tetsim_read_inv_mass(self._h, _fp(out)), self._h)
+        return out
+
+    @property
+    def ownedIds(self):
+        out = np.empty(self.info.owned_particles, dtype=np.int32)
+        capi.check(self._L.tetsim_get_owned_ids(self._h, _ip(out)), self._h)
+        return out
+
+    @property
+    def localTets(self):
+        out = np.empty(self.info.local_elems, dtype=np.int32)
+        capi.check(self._L.tetsim_get_local_tets(self._h, _ip(out)), self._h)
+        return out
+
+    @property
+    def tetOrder(self):
+        out = np.empty(self.numElems, dtype=np.int32)
+        capi.check(self._L.tetsim_get_tet_order(self._h, _ip(out)), self._h)
+        return out
+
+    @property
+    def levelOffsets(self):
+        out = np.empty(self.info.num_levels + 1, dtype=np.int32)
+        capi.check(self._L.tetsim_get_level_offsets(self._h, _ip(out)), self._h)
+        return out
+
+    def writeState(self, pos, vel):
+        p, v = _f32(pos).reshape(-1), _f32(vel).reshape(-1)
+        capi.check(self._L.tetsim_write_state(self._h, _fp(p), _fp(v)), self._h)
+
+    # -- grab (Softbody.js:279-298) -------------------------------------------------------------------
+    def startGrab(self, pos):
+        p = _f32([pos["x"], pos["y"], pos["z"]] if isinstance(pos, dict) else pos)
+        gid = C.c_int32(-1)
+        capi.check(self._L.tetsim_start_grab(self._h, _fp(p), C.byref(gid)), self._h)
+        self.grabId = gid.value
+        self.grabPos[:] = p
+        return self.grabId
+
+    def setGrab(self, gid, pos):
+        p = _f32(pos)
+        capi.check(self._L.tetsim_set_grab(self._h, int(gid), _fp(p)), self._h)
+        self.grabId = int(gid)
+        self.grabPos[:] = p
+
+    def moveGrabbed(self, pos):
+        p = _f32([pos["x"], pos["y"], pos["z"]] if isinstance(pos, dict) else pos)
+        self.setGrab(self.grabId, p)
+
+    def endGrab(self):
+        capi.check(self._L.tetsim_set_grab(self._h, -1, None), self._h)
+        self.grabId = -1
+
+    # -- measurement ----------------------------------------------------------------------------------
+    def profile(self, n, dt, physicsParams=None):
+        pp = self.physicsParams if physicsParams is None else physicsParams
+        pr = capi.TetSimProfile()
+        capi.check(self._L.tetsim_profile(self._h, int(n), float(dt), C.byref(make_params(pp)), C.byref(pr)), self._h)
+        return dict(total_ms=pr.total_ms, tet_ms=pr.kernel_ms[capi.K_TET], vertex_ms=pr.kernel_ms[capi.K_VERTEX],
+                    tet_launches=pr.launches[capi.K_TET], vertex_launches=pr.launches[capi.K_VERTEX], substeps=pr.substeps)
+
+    def timeSubsteps(self, n, dt, physicsParams=None):
+        pp = self.physicsParams if physicsParams is None else physicsParams
+        ms = C.c_double()
+        capi.check(self._L.tetsim_time_step_n(self._h, int(n), float(dt), C.byref(make_params(pp)), C.byref(ms)), self._h)
+        return ms.value
+
+
+def measure_copy_bandwidth(nbytes, reps=20, device=0):
+    g = C.c_double()
+    capi.check(capi.lib().tetsim_measure_copy_bandwidth(device, int(nbytes), int(reps), C.byref(g)))
+    return g.value
+
+
+def halo_exchange_local(bodies):
+    arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
+    capi.check(capi.lib().tetsim_halo_exchange_local(arr, len(bodies)))
