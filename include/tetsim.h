@@ -74,7 +74,10 @@ enum {
     TETSIM_FLAG_REF_SLOT_TABLE = 1u << 0,
     /* ignore params.worldBounds and clamp to the constants hard-coded in the collision pass
      * (SoftbodyGPU.js:347).  POLAR_JACOBI only; on by default through tetsim_default_options(). */
-    TETSIM_FLAG_REF_FIXED_BOUNDS = 1u << 1
+    TETSIM_FLAG_REF_FIXED_BOUNDS = 1u << 1,
+    /* POLAR_JACOBI + FAST normally runs the blocked formulation (workgroup tiles, LDS-staged particles,
+     * per-tile partial sums).  This flag keeps the gather formulation (reference slot order). */
+    TETSIM_FLAG_GATHER_FORMULATION = 1u << 2
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */
@@ -238,6 +241,26 @@ int tetsim_prep_slot_table(const int32_t *tets, uint32_t nt, uint32_t nv, int32_
  * invRestVolume[nt]. */
 int tetsim_prep_rest(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt, double density,
                      float *inv_mass, float *inv_rest_pose, float *inv_rest_volume);
+
+/* Domain-decomposition plan of one partition, computed on the host exactly as tetsim_create does for
+ * part_count > 1 (local numbering: owned boundary | owned interior | ghosts grouped by owner).  Lets a host
+ * drive its own transport and lets the multi-process path be tested without GPUs. */
+typedef struct tetsim_plan_s *tetsim_plan;
+typedef struct TetSimPlanSizes {
+    uint32_t owned_particles, boundary_particles, local_particles, local_elems, owned_elems, num_neighbours;
+} TetSimPlanSizes;
+int tetsim_plan_create(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
+                       const int32_t *vert_owner, tetsim_plan *out);
+void tetsim_plan_destroy(tetsim_plan p);
+int tetsim_plan_sizes(tetsim_plan p, TetSimPlanSizes *out);
+/* local_to_global_vert [local_particles], local_to_global_tet [local_elems], local_tets [4*local_elems] */
+int tetsim_plan_arrays(tetsim_plan p, int32_t *local_to_global_vert, int32_t *local_to_global_tet, int32_t *local_tets);
+/* neighbour i: its rank, how many owned particles are sent to it, and the contiguous local ghost range
+ * [recv_start, recv_start+recv_count) its particles are received into. */
+int tetsim_plan_neighbour(tetsim_plan p, uint32_t i, int32_t *rank, uint32_t *send_count, uint32_t *recv_start,
+                          uint32_t *recv_count, int32_t *send_is_contiguous);
+/* send_local / send_global [send_count] (ascending global id), recv_global [recv_count] */
+int tetsim_plan_neighbour_ids(tetsim_plan p, uint32_t i, int32_t *send_local, int32_t *send_global, int32_t *recv_global);
 
 int tetsim_abi_version(void);
 

@@ -66,6 +66,7 @@ def _load():
     for n in ("pos", "prev", "vel", "quat"):
         getattr(lib, "orc_pj_read_" + n).argtypes = [vp, fp]
     lib.orc_pj_read_elem.argtypes = [vp, C.c_int, fp]
+    lib.orc_pj_write_particles.argtypes = [vp, C.c_int, ip, fp, fp]
     lib.orc_pj_slots.restype, lib.orc_pj_slots.argtypes = ip, [vp]
     lib.orc_pj_inv_rest_volume.restype, lib.orc_pj_inv_rest_volume.argtypes = fp, [vp]
     lib.orc_pj_inv_mass.restype, lib.orc_pj_inv_mass.argtypes = fp, [vp]
@@ -73,6 +74,7 @@ def _load():
     lib.orc_pj_iter_hist.argtypes = [vp, C.POINTER(C.c_longlong)]
     lib.orc_max_threads.restype = C.c_int
     lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_set_threads(1)  # deterministic and fastest for the small test meshes; bench.py opts into more
     _lib = lib
     return lib
 
@@ -248,3 +250,8 @@ class OraclePJ(_Base):
 
     def endGrab(self):
         self.setGrab(-1)
+
+    def writeParticles(self, idx, pos, vel):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        p, v = _f32(pos).reshape(-1), _f32(vel).reshape(-1)
+        self._lib.orc_pj_write_particles(self._h, len(idx), idx.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(p), _fptr(v))

@@ -602,6 +602,14 @@ void orc_pj_set_grab(OrcPJ *s, int id, const float *xyz) {
     s->grabId = id;
     if (xyz) { s->grabPos[0] = xyz[0]; s->grabPos[1] = xyz[1]; s->grabPos[2] = xyz[2]; }
 }
+/* Overwrite position and velocity of the listed particles (partitioned tests: ghost particles take the
+ * owner's state before the next substep). */
+void orc_pj_write_particles(OrcPJ *s, int n, const int32_t *idx, const float *pos3, const float *vel3) {
+    for (int i = 0; i < n; i++) {
+        s->pos[s->cur_pos][idx[i]] = V3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]);
+        s->vel[s->cur_vel][idx[i]] = V3(vel3[3 * i], vel3[3 * i + 1], vel3[3 * i + 2]);
+    }
+}
 void orc_pj_read_pos(OrcPJ *s, float *out) { memcpy(out, s->pos[s->cur_pos], sizeof(v3) * s->nv); }
 void orc_pj_read_prev(OrcPJ *s, float *out) { memcpy(out, s->prev[s->cur_prev], sizeof(v3) * s->nv); }
 void orc_pj_read_vel(OrcPJ *s, float *out) { memcpy(out, s->vel[s->cur_vel], sizeof(v3) * s->nv); }

@@ -1,0 +1,119 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/tetsim.h declares, refuses to
+compute without a GPU (no fallback), and its host preprocessing matches the reference-pinned data."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_f32, load_mesh
+from oracle import OraclePJ
+from tetsim_amd import _capi as capi
+from tetsim_amd import make_lattice
+
+ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "tetsim.h")).read()
+    declared = sorted(set(re.findall(r"\b(tetsim_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(capi.SYMBOLS)
+    L = capi.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.tetsim_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device create must FAIL loudly (ENODEVICE); with one it must succeed on the GPU."""
+    L = capi.lib()
+    v, t = make_lattice(2)
+    v = np.ascontiguousarray(v.reshape(-1)); t = np.ascontiguousarray(t.reshape(-1))
+    h = C.c_void_p()
+    rc = L.tetsim_create(fp(v), len(v) // 3, ip(t), len(t) // 4, None, C.byref(h))
+    if rc == capi.OK:
+        L.tetsim_destroy(h)
+        pytest.skip("a GPU is present; the failure path is exercised on CPU-only hosts")
+    assert rc == capi.ENODEVICE and not h.value
+    assert b"no CPU fallback" in L.tetsim_last_error(None)
+
+
+def test_invalid_meshes_are_rejected():
+    L = capi.lib()
+    v, t = make_lattice(2)
+    v = np.ascontiguousarray(v.reshape(-1)); t = np.ascontiguousarray(t.reshape(-1)).copy()
+    t[5] = 10 ** 6
+    h = C.c_void_p()
+    assert L.tetsim_create(fp(v), len(v) // 3, ip(t), len(t) // 4, None, C.byref(h)) == capi.EINVAL
+    assert b"outside" in L.tetsim_last_error(None)
+    lv = np.zeros(len(t) // 4, dtype=np.int32); n = C.c_uint32()
+    assert L.tetsim_prep_levels(ip(t), len(t) // 4, len(v) // 3, ip(lv), C.byref(n)) == capi.EINVAL
+
+
+@pytest.mark.parametrize("mesh", ["dragon", "lat4", "lat4c", "lat2degen"])
+def test_prep_rest_bit_exact_vs_reference(mesh):
+    """tetsim_prep_rest (product code) against arrays recorded from the reference's initPhysics."""
+    L = capi.lib()
+    v, t = load_mesh(mesh)
+    v = np.ascontiguousarray(v.reshape(-1)); t = np.ascontiguousarray(t.reshape(-1))
+    nv, nt = len(v) // 3, len(t) // 4
+    im, irp, irv = np.empty(nv, np.float32), np.empty(9 * nt, np.float32), np.empty(nt, np.float32)
+    assert L.tetsim_prep_rest(fp(v), nv, ip(t), nt, 1000.0, fp(im), fp(irp), fp(irv)) == 0
+    assert np.array_equal(im.view(np.uint32), load_f32(mesh + "_invMass.f32").view(np.uint32))
+    assert np.array_equal(irp.view(np.uint32), load_f32(mesh + "_invRestPose.f32").view(np.uint32))
+    assert np.array_equal(irv.view(np.uint32), load_f32(mesh + "_invRestVolume.f32").view(np.uint32))
+
+
+def _py_levels(t, nv):
+    last = np.full(nv, -1, dtype=np.int64)
+    out = np.empty(len(t), dtype=np.int32)
+    for e, tet in enumerate(t.tolist()):
+        l = max(last[x] for x in tet) + 1
+        out[e] = l
+        for x in tet:
+            last[x] = l
+    return out
+
+
+@pytest.mark.parametrize("mesh", ["dragon", "lat4"])
+def test_levels_and_colours(mesh):
+    L = capi.lib()
+    v, t = load_mesh(mesh)
+    tf = np.ascontiguousarray(t.reshape(-1))
+    nv, nt = len(v), len(t)
+    lv, n = np.empty(nt, np.int32), C.c_uint32()
+    assert L.tetsim_prep_levels(ip(tf), nt, nv, ip(lv), C.byref(n)) == 0
+    assert np.array_equal(lv, _py_levels(t, nv)) and n.value == lv.max() + 1
+    # tets of one level are vertex-disjoint; sharing pairs keep their order
+    for l in range(n.value):
+        ids = t[lv == l].ravel()
+        assert len(np.unique(ids)) == len(ids)
+    col, nc = np.empty(nt, np.int32), C.c_uint32()
+    assert L.tetsim_prep_colours(ip(tf), nt, nv, ip(col), C.byref(nc)) == 0
+    for c in range(nc.value):
+        ids = t[col == c].ravel()
+        assert len(np.unique(ids)) == len(ids)
+    assert nc.value <= np.bincount(t.ravel()).max() * 4  # greedy bound: deg + 1
+    # colour-sorting then levelling gives at most nc levels
+    order = np.argsort(col, kind="stable")
+    ts = np.ascontiguousarray(t[order].reshape(-1))
+    assert L.tetsim_prep_levels(ip(ts), nt, nv, ip(lv), C.byref(n)) == 0
+    assert n.value <= nc.value
+
+
+@pytest.mark.parametrize("quirk", [0, 1])
+@pytest.mark.parametrize("mesh", ["dragon", "lat4"])
+def test_slot_table_matches_oracle(mesh, quirk):
+    """Product table builder vs the oracle's direct emulation of SoftbodyGPU.js:563-577."""
+    L = capi.lib()
+    v, t = load_mesh(mesh)
+    tf = np.ascontiguousarray(t.reshape(-1))
+    slots, dropped = np.empty(len(v) * 36, np.int32), C.c_uint32()
+    assert L.tetsim_prep_slot_table(ip(tf), len(t), len(v), quirk, ip(slots), C.byref(dropped)) == 0
+    orc = OraclePJ(v, t, {"density": 1000.0}, slot_quirk=bool(quirk))
+    assert np.array_equal(slots.reshape(-1, 36), orc.slots)
+    assert dropped.value == quirk  # the only loss on these meshes is tet 0 / corner 0
+    if mesh == "dragon":
+        assert orc.biggestT == 7  # SURVEY.md §8(a) G1 probe: highest table used on the Dragon

@@ -13,7 +13,7 @@ OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
 PRECISE, FAST = 0, 1
 ORDER_ORIGINAL, ORDER_COLOURED = 0, 1
-FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS = 1, 2
+FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION = 1, 2, 4
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
 
@@ -41,6 +41,11 @@ class TetSimProfile(C.Structure):
                 ("substeps", C.c_uint32)]
 
 
+class TetSimPlanSizes(C.Structure):
+    _fields_ = [("owned_particles", C.c_uint32), ("boundary_particles", C.c_uint32), ("local_particles", C.c_uint32),
+                ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32), ("num_neighbours", C.c_uint32)]
+
+
 class TetSimError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("tetsim error %d: %s" % (code, msg))
@@ -57,7 +62,8 @@ SYMBOLS = [
     "tetsim_start_grab", "tetsim_profile", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
-    "tetsim_prep_slot_table", "tetsim_prep_rest",
+    "tetsim_prep_slot_table", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
+    "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
 ]
 
 _lib = None
@@ -110,9 +116,17 @@ def lib():
     L.tetsim_prep_colours.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
     L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]
+    L.tetsim_plan_create.argtypes = [ip, u32, u32, i32, i32, ip, C.POINTER(H)]
+    L.tetsim_plan_destroy.argtypes = [H]
+    L.tetsim_plan_destroy.restype = None
+    L.tetsim_plan_sizes.argtypes = [H, C.POINTER(TetSimPlanSizes)]
+    L.tetsim_plan_arrays.argtypes = [H, ip, ip, ip]
+    L.tetsim_plan_neighbour.argtypes = [H, u32, ip, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), ip]
+    L.tetsim_plan_neighbour_ids.argtypes = [H, u32, ip, ip, ip]
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ("tetsim_default_options", "tetsim_default_params", "tetsim_destroy", "tetsim_last_error"):
+        if s not in ("tetsim_default_options", "tetsim_default_params", "tetsim_destroy", "tetsim_last_error",
+                     "tetsim_plan_destroy"):
             f.restype = C.c_int
     _lib = L
     return L

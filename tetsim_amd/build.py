@@ -17,17 +17,22 @@ LIB = os.path.join(HERE, "libtetsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", f"--offload-arch={ARCH}"]
+# -fno-slp-vectorize: on gfx950 v_pk_{mul,add,fma}_f32 issue at half the rate of their scalar forms (no flop gain)
+# and the packing costs v_mov shuffles + VGPRs; the rotation-extraction loop is 109 -> ~100 VALU, 340 -> 200 cycles
+# per iteration, and the tet kernels drop from ~104 to ~52 VGPRs without it (rocprof + ISA notes in DESIGN.md).
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-fno-slp-vectorize",
+          f"--offload-arch={ARCH}"]
 UNITS = {
     "host_prep.cpp": ["-ffp-contract=off", "-x", "hip"],
     "tetsim_api.hip": ["-ffp-contract=off"],
     "pj_precise.hip": ["-ffp-contract=off"],
     "pj_fast.hip": ["-ffp-contract=fast"],
+    "pj_blocked.hip": ["-ffp-contract=fast"],
     "nh_precise.hip": ["-ffp-contract=off"],
     "nh_fast.hip": ["-ffp-contract=fast"],
     "util_kernels.hip": [],
 }
-HEADERS = ["dev_common.h", "host_prep.h", "pj_kernels.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
+HEADERS = ["dev_common.h", "host_prep.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
 
 
 def _newest(paths):

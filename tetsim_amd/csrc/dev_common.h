@@ -37,6 +37,33 @@ struct PJDev {
     const DevParams* params = nullptr;
 };
 
+// ---- POLAR_JACOBI, blocked formulation (FAST mode; DESIGN.md "Blocked formulation") -----------------------
+// Tets are tiled into workgroups of <= 256 tets touching <= 256 distinct particles.  The tile's particle
+// positions are staged in LDS, the 4 goals of every tet are reduced IN LDS to one partial sum per tile
+// particle (fixed order: deterministic), and the per-particle pass adds the few partial sums of the tiles
+// that touch it.
+struct PJBlk {
+    uint32_t nb = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0;
+    const uint32_t* blk_tet_off = nullptr;   // [nb+1]
+    const uint32_t* blk_vert_off = nullptr;  // [nb+1]
+    const int32_t* blk_verts = nullptr;      // particle id of every tile slot
+    const uchar4* tet_lidx = nullptr;        // [nt] LDS slot of the 4 corners
+    float4* rest_a = nullptr;                // [nt] carried rest corners, 12 floats packed in 3 x 16 B:
+    float4* rest_b = nullptr;                //      a = r0.xyz r1.x | b = r1.yz r2.xy | c = r2.z r3.xyz
+    float4* rest_c = nullptr;
+    const float* vol = nullptr;              // [nt] rest volume (the averaging weight)
+    float4* quat = nullptr;                  // [nt]
+    const uint32_t* lc_range = nullptr;      // per tile slot: first | end << 16 into the tile's entry list
+    const uint2* lc_ent = nullptr;           // [nt] 4 x u16 per tet position: (tetLocal*4 + corner), grouped by slot
+    float4* partial = nullptr;               // per tile slot: (sum V*goal, sum V)
+    const uint32_t* vp_off = nullptr;        // [nv_owned+1]
+    const uint32_t* vp_idx = nullptr;        // partial-sum indices of each owned particle
+    float4* pos_pred = nullptr;
+    float4* pos_final = nullptr;
+    float4* vel = nullptr;
+    const DevParams* params = nullptr;
+};
+
 // ---- NEOHOOKEAN_GS device state ---------------------------------------------------------------------
 struct NHDev {
     uint32_t nv = 0, nt = 0;
@@ -59,6 +86,10 @@ void pj_launch_vertex_precise(hipStream_t s, const PJDev& d, uint32_t first, uin
 void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32_t count);
 void pj_launch_repredict_precise(hipStream_t s, const PJDev& d);
 void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
+
+void pjb_launch_tet(hipStream_t s, const PJBlk& d);
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count);
+void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_predict_fast(hipStream_t s, const NHDev& d);

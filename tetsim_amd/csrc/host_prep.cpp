@@ -171,6 +171,111 @@ uint32_t prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref
     return dropped;
 }
 
+namespace {
+inline uint32_t spread3(uint32_t x) {  // 10 bits -> every third bit
+    x &= 0x3ffu;
+    x = (x | (x << 16)) & 0x030000ffu;
+    x = (x | (x << 8)) & 0x0300f00fu;
+    x = (x | (x << 4)) & 0x030c30c3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+}  // namespace
+
+void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
+                  const Incidence& inc, BlockPlan* out) {
+    BlockPlan& B = *out;
+    B = BlockPlan();
+    constexpr uint32_t kMaxTets = 256, kMaxVerts = 256;
+    // 1. Morton order of rest centroids (quantised to 10 bits per axis over the bounding box)
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t v = 0; v < nv; v++)
+        for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], verts[3 * v + c]); hi[c] = std::max(hi[c], verts[3 * v + c]); }
+    float ext = 1e-30f;
+    for (int c = 0; c < 3; c++) ext = std::max(ext, hi[c] - lo[c]);
+    std::vector<uint64_t> key(nt);
+    for (uint32_t e = 0; e < nt; e++) {
+        uint32_t code = 0;
+        for (int c = 0; c < 3; c++) {
+            float m = 0.0f;
+            for (int k = 0; k < 4; k++) m += verts[3 * tets[4 * e + k] + c];
+            const float u = (0.25f * m - lo[c]) / ext;
+            const uint32_t qv = static_cast<uint32_t>(std::min(1023.0f, std::max(0.0f, u * 1024.0f)));
+            code |= spread3(qv) << c;
+        }
+        key[e] = (static_cast<uint64_t>(code) << 32) | e;  // ties keep the caller's order
+    }
+    std::sort(key.begin(), key.end());
+    B.tet_perm.resize(nt);
+    for (uint32_t i = 0; i < nt; i++) B.tet_perm[i] = static_cast<int32_t>(key[i] & 0xffffffffu);
+
+    // which (tet,corner) contributions are live (the incidence table may drop some: reference quirk / cap)
+    std::vector<uint8_t> live(4ull * nt, 0);
+    for (int32_t enc : inc.slot) live[enc] = 1;
+
+    // 2. greedy tiling along the curve
+    std::vector<int32_t> slot_of(nv, -1);
+    std::vector<int32_t> touched;
+    B.tet_lidx.resize(4ull * nt);
+    B.lc_ent.resize(4ull * nt);
+    B.blk_tet_off.push_back(0);
+    B.blk_vert_off.push_back(0);
+    std::vector<std::vector<uint32_t>> vert_partials(nv_sum);
+    uint32_t i = 0;
+    while (i < nt) {
+        const uint32_t t0 = i;
+        touched.clear();
+        while (i < nt && i - t0 < kMaxTets) {
+            const int32_t* t = &tets[4 * B.tet_perm[i]];
+            uint32_t fresh = 0;
+            for (int k = 0; k < 4; k++) {
+                bool seen = slot_of[t[k]] >= 0;
+                for (int j = 0; j < k && !seen; j++) seen = t[j] == t[k];
+                if (!seen) fresh++;
+            }
+            if (touched.size() + fresh > kMaxVerts) break;
+            for (int k = 0; k < 4; k++) {
+                if (slot_of[t[k]] < 0) { slot_of[t[k]] = static_cast<int32_t>(touched.size()); touched.push_back(t[k]); }
+                B.tet_lidx[4ull * i + k] = static_cast<uint8_t>(slot_of[t[k]]);
+            }
+            i++;
+        }
+        const uint32_t ntb = i - t0, nu = static_cast<uint32_t>(touched.size());
+        const uint32_t v0 = B.blk_vert_off.back();
+        // per-slot entry lists: counting sort of the live (tetLocal, corner) pairs, tet order within a slot
+        std::vector<uint32_t> cnt(nu + 1, 0);
+        for (uint32_t j = 0; j < ntb; j++)
+            for (int k = 0; k < 4; k++)
+                if (live[4ull * B.tet_perm[t0 + j] + k]) cnt[B.tet_lidx[4ull * (t0 + j) + k] + 1]++;
+        for (uint32_t u = 0; u < nu; u++) cnt[u + 1] += cnt[u];
+        for (uint32_t u = 0; u < nu; u++) B.lc_range.push_back(cnt[u] | (cnt[u + 1] << 16));
+        std::vector<uint32_t> fillp(cnt.begin(), cnt.end() - 1);
+        for (uint32_t j = 0; j < ntb; j++)
+            for (int k = 0; k < 4; k++)
+                if (live[4ull * B.tet_perm[t0 + j] + k]) {
+                    const uint32_t u = B.tet_lidx[4ull * (t0 + j) + k];
+                    B.lc_ent[4ull * t0 + fillp[u]++] = static_cast<uint16_t>(4 * j + k);
+                }
+        for (uint32_t u = 0; u < nu; u++) {
+            const int32_t v = touched[u];
+            B.blk_verts.push_back(v);
+            if (static_cast<uint32_t>(v) < nv_sum && cnt[u + 1] > cnt[u]) vert_partials[v].push_back(v0 + u);
+            slot_of[v] = -1;
+        }
+        B.blk_tet_off.push_back(i);
+        B.blk_vert_off.push_back(v0 + nu);
+        B.max_tile_verts = std::max(B.max_tile_verts, nu);
+    }
+    B.num_blocks = static_cast<uint32_t>(B.blk_tet_off.size() - 1);
+    B.vp_off.assign(nv_sum + 1, 0);
+    for (uint32_t v = 0; v < nv_sum; v++) {
+        B.vp_off[v + 1] = B.vp_off[v] + static_cast<uint32_t>(vert_partials[v].size());
+        B.max_partials = std::max<uint32_t>(B.max_partials, static_cast<uint32_t>(vert_partials[v].size()));
+    }
+    B.vp_idx.reserve(B.vp_off[nv_sum]);
+    for (uint32_t v = 0; v < nv_sum; v++) B.vp_idx.insert(B.vp_idx.end(), vert_partials[v].begin(), vert_partials[v].end());
+}
+
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats) {
     if ((nv && !verts) || (nt && !tets)) return "null mesh pointer";
     if (nv == 0) return "mesh has no vertices";

@@ -54,6 +54,27 @@ struct Partition {
 std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
                             const int32_t* vert_owner, Partition* out);
 
+// Workgroup tiling for the blocked POLAR_JACOBI formulation (DESIGN.md "Blocked formulation").
+// Tets are sorted along a Morton curve of their rest centroids and cut into tiles of <= 256 tets that touch
+// <= 256 distinct vertices, so a tile's vertex set fits an LDS tile addressed by 8-bit local indices.
+struct BlockPlan {
+    uint32_t num_blocks = 0;
+    std::vector<int32_t> tet_perm;       // new tet position -> input tet index
+    std::vector<uint32_t> blk_tet_off;   // [num_blocks+1]
+    std::vector<uint32_t> blk_vert_off;  // [num_blocks+1] into blk_verts / partial sums
+    std::vector<int32_t> blk_verts;      // vertex ids of each tile's LDS slots
+    std::vector<uint8_t> tet_lidx;       // [4*nt] LDS slot of every corner (new tet order)
+    std::vector<uint32_t> lc_range;      // per tile vertex: first | (last+1) << 16 into the tile's lc_ent
+    std::vector<uint16_t> lc_ent;        // [4*nt] per tile: (tetLocal*4+corner) grouped by LDS slot, tet order inside
+    std::vector<uint32_t> vp_off;        // [nv_sum+1] per summed vertex: range into vp_idx
+    std::vector<uint32_t> vp_idx;        // indices into the partial-sum array, ascending tile
+    uint32_t max_tile_verts = 0, max_partials = 0;
+};
+// `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
+// it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).
+void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
+                  const Incidence& inc, BlockPlan* out);
+
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 
 }  // namespace tetsim

@@ -91,6 +91,9 @@ struct tetsim_body {
 
     // POLAR_JACOBI
     PJDev pj;
+    PJBlk blk;             // blocked formulation (FAST unless TETSIM_FLAG_GATHER_FORMULATION)
+    bool blocked = false;
+    std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
     Partition part;
     bool partitioned = false;
     std::vector<int32_t> g2l_owned;  // global vertex -> local id (owned) or -1
@@ -183,11 +186,18 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
 }
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
-void pj_tet(tetsim_body* h) { h->fast ? pj_launch_tet_fast(h->stream, h->pj) : pj_launch_tet_precise(h->stream, h->pj); }
-void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count) {
-    h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count) : pj_launch_vertex_precise(h->stream, h->pj, first, count);
+void pj_tet(tetsim_body* h) {
+    if (h->blocked) pjb_launch_tet(h->stream, h->blk);
+    else h->fast ? pj_launch_tet_fast(h->stream, h->pj) : pj_launch_tet_precise(h->stream, h->pj);
 }
-void pj_repredict(tetsim_body* h) { h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj); }
+void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count) {
+    if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count);
+    else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count) : pj_launch_vertex_precise(h->stream, h->pj, first, count);
+}
+void pj_repredict(tetsim_body* h) {
+    if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
+    else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
+}
 
 int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
     return fail(h, TETSIM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
@@ -330,52 +340,121 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     if ((rc = dev_alloc(h, &d.pos_pred, nvl))) return rc;
     if ((rc = dev_alloc(h, &d.pos_final, nvl))) return rc;
     if ((rc = dev_alloc(h, &d.vel, nvl))) return rc;
-    if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
-    if ((rc = dev_alloc(h, &d.elem, 4ull * d.nt_pad))) return rc;
-    if ((rc = dev_alloc(h, &d.quat, ntl))) return rc;
-    if ((rc = dev_alloc(h, &d.slot_tab, static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad))) return rc;
-    if ((rc = dev_alloc(h, &d.slot_cnt, d.nv_pad))) return rc;
     d.params = h->d_params;
 
     std::vector<float4> pos(nvl);
+    std::vector<float> lverts(3ull * nvl);
     for (uint32_t i = 0; i < nvl; i++) {
         const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
         pos[i] = make_float4(verts[3 * g], verts[3 * g + 1], verts[3 * g + 2], 0.0f);
+        lverts[3 * i] = verts[3 * g]; lverts[3 * i + 1] = verts[3 * g + 1]; lverts[3 * i + 2] = verts[3 * g + 2];
     }
     if ((rc = upload(h, d.pos_pred, pos))) return rc;
     if ((rc = upload(h, d.pos_final, pos))) return rc;
     HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nvl, 1) * sizeof(float4)));
 
-    std::vector<int4> idx(ntl);
-    std::vector<float4> elem(4ull * d.nt_pad, make_float4(0, 0, 0, 0)), quat(ntl, make_float4(0, 0, 0, 1));
-    for (uint32_t e = 0; e < ntl; e++) {
-        const int32_t* lt = &ltets[4 * e];
-        idx[e] = make_int4(lt[0], lt[1], lt[2], lt[3]);
-        const uint32_t ge = h->partitioned ? static_cast<uint32_t>(l2g_t[e]) : e;
-        // the weight the reference's P4 writes into elems.w: 1.0 / texture(invRestVolume).x, in f32
-        // (SoftbodyGPU.js:220,259-262 with invRestVolume = fround(1/V), :582-589)
-        const float w = 1.0f / pj_inv_rest_volume(verts, &tets[4 * ge]);
-        for (int k = 0; k < 4; k++) {
-            const float4 p = pos[lt[k]];
-            elem[static_cast<size_t>(k) * d.nt_pad + e] = make_float4(p.x, p.y, p.z, w);
-        }
-    }
-    if ((rc = upload(h, d.tet_idx, idx))) return rc;
-    if ((rc = upload(h, d.elem, elem))) return rc;
-    if ((rc = upload(h, d.quat, quat))) return rc;
+    // the weight the reference's P4 writes into elems.w: 1.0 / texture(invRestVolume).x, in f32
+    // (SoftbodyGPU.js:220,259-262 with invRestVolume = fround(1/V), :582-589)
+    auto rest_weight = [&](uint32_t local_tet) {
+        const uint32_t ge = h->partitioned ? static_cast<uint32_t>(l2g_t[local_tet]) : local_tet;
+        return 1.0f / pj_inv_rest_volume(verts, &tets[4 * ge]);
+    };
 
-    std::vector<int32_t> tab(static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad, 0);
-    std::vector<uint32_t> cnt(d.nv_pad, 0);
-    for (uint32_t v = 0; v < nvo; v++) {
-        const uint32_t c = inc.offset[v + 1] - inc.offset[v];
-        cnt[v] = c;
-        for (uint32_t s = 0; s < c; s++) {
-            const int32_t enc = inc.slot[inc.offset[v] + s];
-            tab[static_cast<size_t>(s) * d.nv_pad + v] = static_cast<int32_t>((enc & 3) * d.nt_pad + (enc >> 2));
+    h->blocked = h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION);
+    if (h->blocked) {
+        BlockPlan B;
+        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
+        h->tet_perm = B.tet_perm;
+        PJBlk& k = h->blk;
+        k.nb = B.num_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
+        k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
+        uint32_t *bto, *bvo, *lcr, *vpo, *vpi;
+        int32_t* bv;
+        uchar4* lidx;
+        float* vol;
+        uint2* lce;
+        const size_t nslots = B.blk_verts.size();
+        if ((rc = dev_alloc(h, &bto, B.blk_tet_off.size()))) return rc;
+        if ((rc = dev_alloc(h, &bvo, B.blk_vert_off.size()))) return rc;
+        if ((rc = dev_alloc(h, &bv, nslots))) return rc;
+        if ((rc = dev_alloc(h, &lidx, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_a, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_b, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_c, ntl))) return rc;
+        if ((rc = dev_alloc(h, &vol, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.quat, ntl))) return rc;
+        if ((rc = dev_alloc(h, &lcr, nslots))) return rc;
+        if ((rc = dev_alloc(h, &lce, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.partial, nslots))) return rc;
+        if ((rc = dev_alloc(h, &vpo, B.vp_off.size()))) return rc;
+        if ((rc = dev_alloc(h, &vpi, B.vp_idx.size()))) return rc;
+        std::vector<float4> ra(ntl), rb(ntl), rcv(ntl), quat(ntl, make_float4(0, 0, 0, 1));
+        std::vector<float> volh(ntl);
+        std::vector<uchar4> lidxh(ntl);
+        std::vector<uint2> lceh(ntl);
+        for (uint32_t i = 0; i < ntl; i++) {
+            const uint32_t lt = static_cast<uint32_t>(B.tet_perm[i]);
+            const int32_t* c = &ltets[4 * lt];
+            const float4 p0 = pos[c[0]], p1 = pos[c[1]], p2 = pos[c[2]], p3 = pos[c[3]];
+            ra[i] = make_float4(p0.x, p0.y, p0.z, p1.x);
+            rb[i] = make_float4(p1.y, p1.z, p2.x, p2.y);
+            rcv[i] = make_float4(p2.z, p3.x, p3.y, p3.z);
+            volh[i] = rest_weight(lt);
+            lidxh[i] = make_uchar4(B.tet_lidx[4ull * i], B.tet_lidx[4ull * i + 1], B.tet_lidx[4ull * i + 2], B.tet_lidx[4ull * i + 3]);
+            const uint16_t* en = &B.lc_ent[4ull * i];
+            lceh[i] = make_uint2(en[0] | (static_cast<uint32_t>(en[1]) << 16), en[2] | (static_cast<uint32_t>(en[3]) << 16));
         }
+        if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
+        if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
+        if ((rc = upload(h, bv, B.blk_verts))) return rc;
+        if ((rc = upload(h, lidx, lidxh))) return rc;
+        if ((rc = upload(h, k.rest_a, ra))) return rc;
+        if ((rc = upload(h, k.rest_b, rb))) return rc;
+        if ((rc = upload(h, k.rest_c, rcv))) return rc;
+        if ((rc = upload(h, vol, volh))) return rc;
+        if ((rc = upload(h, k.quat, quat))) return rc;
+        if ((rc = upload(h, lcr, B.lc_range))) return rc;
+        if ((rc = upload(h, lce, lceh))) return rc;
+        if ((rc = upload(h, vpo, B.vp_off))) return rc;
+        if ((rc = upload(h, vpi, B.vp_idx))) return rc;
+        HIPCHK(h, hipMemset(k.partial, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
+        k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
+        k.lc_range = lcr; k.lc_ent = lce; k.vp_off = vpo; k.vp_idx = vpi;
+        d.quat = k.quat;  // tetsim_read_quats
+    } else {
+        if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
+        if ((rc = dev_alloc(h, &d.elem, 4ull * d.nt_pad))) return rc;
+        if ((rc = dev_alloc(h, &d.quat, ntl))) return rc;
+        if ((rc = dev_alloc(h, &d.slot_tab, static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad))) return rc;
+        if ((rc = dev_alloc(h, &d.slot_cnt, d.nv_pad))) return rc;
+        std::vector<int4> idx(ntl);
+        std::vector<float4> elem(4ull * d.nt_pad, make_float4(0, 0, 0, 0)), quat(ntl, make_float4(0, 0, 0, 1));
+        for (uint32_t e = 0; e < ntl; e++) {
+            const int32_t* lt = &ltets[4 * e];
+            idx[e] = make_int4(lt[0], lt[1], lt[2], lt[3]);
+            const float w = rest_weight(e);
+            for (int k = 0; k < 4; k++) {
+                const float4 p = pos[lt[k]];
+                elem[static_cast<size_t>(k) * d.nt_pad + e] = make_float4(p.x, p.y, p.z, w);
+            }
+        }
+        if ((rc = upload(h, d.tet_idx, idx))) return rc;
+        if ((rc = upload(h, d.elem, elem))) return rc;
+        if ((rc = upload(h, d.quat, quat))) return rc;
+
+        std::vector<int32_t> tab(static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad, 0);
+        std::vector<uint32_t> cnt(d.nv_pad, 0);
+        for (uint32_t v = 0; v < nvo; v++) {
+            const uint32_t c = inc.offset[v + 1] - inc.offset[v];
+            cnt[v] = c;
+            for (uint32_t sl = 0; sl < c; sl++) {
+                const int32_t enc = inc.slot[inc.offset[v] + sl];
+                tab[static_cast<size_t>(sl) * d.nv_pad + v] = static_cast<int32_t>((enc & 3) * d.nt_pad + (enc >> 2));
+            }
+        }
+        if ((rc = upload(h, d.slot_tab, tab))) return rc;
+        if ((rc = upload(h, d.slot_cnt, cnt))) return rc;
     }
-    if ((rc = upload(h, d.slot_tab, tab))) return rc;
-    if ((rc = upload(h, d.slot_cnt, cnt))) return rc;
 
     if (h->partitioned) {
         for (const auto& nb : h->part.neigh) {
@@ -685,7 +764,10 @@ int tetsim_get_owned_ids(tetsim_handle h, int32_t* out) {
 int tetsim_get_local_tets(tetsim_handle h, int32_t* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
     const uint32_t n = h->info.local_elems;
-    for (uint32_t i = 0; i < n; i++) out[i] = h->partitioned ? h->part.local_to_global_tet[i] : static_cast<int32_t>(i);
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t lt = h->blocked ? h->tet_perm[i] : static_cast<int32_t>(i);  // blocked: tets live in tile order
+        out[i] = h->partitioned ? h->part.local_to_global_tet[lt] : lt;
+    }
     return 0;
 }
 int tetsim_get_tet_order(tetsim_handle h, int32_t* out) {
@@ -946,6 +1028,59 @@ int tetsim_prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint3
     std::string e = validate_mesh(verts, nv, tets, nt, false);
     if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
     prep_rest(verts, nv, tets, nt, density, inv_mass, inv_rest_pose, inv_rest_volume);
+    return 0;
+}
+
+// ---- partition plan (host only) ---------------------------------------------------------------------------------
+struct tetsim_plan_s { Partition P; };
+
+int tetsim_plan_create(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
+                       const int32_t* vert_owner, tetsim_plan* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "null plan pointer");
+    *out = nullptr;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    tetsim_plan_s* p = new tetsim_plan_s();
+    e = build_partition(tets, nt, nv, part_count, part_index, vert_owner, &p->P);
+    if (!e.empty()) { delete p; return fail(nullptr, TETSIM_EINVAL, e); }
+    *out = p;
+    return 0;
+}
+void tetsim_plan_destroy(tetsim_plan p) { delete p; }
+int tetsim_plan_sizes(tetsim_plan p, TetSimPlanSizes* out) {
+    if (!p || !out) return TETSIM_EINVAL;
+    out->owned_particles = p->P.n_owned;
+    out->boundary_particles = p->P.n_boundary;
+    out->local_particles = static_cast<uint32_t>(p->P.local_to_global_vert.size());
+    out->local_elems = static_cast<uint32_t>(p->P.local_to_global_tet.size());
+    out->owned_elems = p->P.owned_tets;
+    out->num_neighbours = static_cast<uint32_t>(p->P.neigh.size());
+    return 0;
+}
+int tetsim_plan_arrays(tetsim_plan p, int32_t* l2gv, int32_t* l2gt, int32_t* ltets) {
+    if (!p) return TETSIM_EINVAL;
+    if (l2gv) std::copy(p->P.local_to_global_vert.begin(), p->P.local_to_global_vert.end(), l2gv);
+    if (l2gt) std::copy(p->P.local_to_global_tet.begin(), p->P.local_to_global_tet.end(), l2gt);
+    if (ltets) std::copy(p->P.local_tets.begin(), p->P.local_tets.end(), ltets);
+    return 0;
+}
+int tetsim_plan_neighbour(tetsim_plan p, uint32_t i, int32_t* rank, uint32_t* send_count, uint32_t* recv_start,
+                          uint32_t* recv_count, int32_t* contiguous) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (rank) *rank = nb.rank;
+    if (send_count) *send_count = static_cast<uint32_t>(nb.send_local.size());
+    if (recv_start) *recv_start = nb.recv_start;
+    if (recv_count) *recv_count = nb.recv_count;
+    if (contiguous) *contiguous = nb.send_contiguous ? 1 : 0;
+    return 0;
+}
+int tetsim_plan_neighbour_ids(tetsim_plan p, uint32_t i, int32_t* send_local, int32_t* send_global, int32_t* recv_global) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (send_local) std::copy(nb.send_local.begin(), nb.send_local.end(), send_local);
+    if (send_global) std::copy(nb.send_global.begin(), nb.send_global.end(), send_global);
+    if (recv_global) std::copy(nb.recv_global.begin(), nb.recv_global.end(), recv_global);
     return 0;
 }
 

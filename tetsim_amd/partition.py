@@ -1,0 +1,58 @@
+"""Host-side view of the domain-decomposition plan (include/tetsim.h tetsim_plan_*); GPU-free.
+
+The same C++ routine (csrc/host_prep.cpp build_partition) serves tetsim_create(part_count > 1), so a host that
+runs its own transport -- or a CPU test -- sees exactly the numbering and halo lists the device path uses.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def slab_owner(n_cells_xy, nz_cells, parts):
+    """Vertex owner for an n x n x nz Kuhn lattice cut into `parts` z-slabs of whole vertex planes."""
+    plane = (n_cells_xy + 1) * (n_cells_xy + 1)
+    k = np.arange(plane * (nz_cells + 1)) // plane
+    per = max(1, nz_cells // parts)
+    return np.minimum(k // per, parts - 1).astype(np.int32)
+
+
+class Neighbour:
+    __slots__ = ("rank", "send_local", "send_global", "recv_start", "recv_count", "recv_global", "contiguous")
+
+
+class PartitionPlan:
+    def __init__(self, tetIds, num_particles, part_count, part_index, vert_owner=None):
+        L = capi.lib()
+        tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        owner = None if vert_owner is None else np.ascontiguousarray(vert_owner, dtype=np.int32)
+        h = C.c_void_p()
+        capi.check(L.tetsim_plan_create(ip(tets), tets.size // 4, int(num_particles), part_count, part_index,
+                                        ip(owner) if owner is not None else None, C.byref(h)))
+        try:
+            sz = capi.TetSimPlanSizes()
+            capi.check(L.tetsim_plan_sizes(h, C.byref(sz)))
+            self.part_count, self.part_index = part_count, part_index
+            self.n_owned, self.n_boundary = sz.owned_particles, sz.boundary_particles
+            self.n_local, self.n_local_tets, self.n_owned_tets = sz.local_particles, sz.local_elems, sz.owned_elems
+            self.local_to_global_vert = np.empty(self.n_local, dtype=np.int32)
+            self.local_to_global_tet = np.empty(self.n_local_tets, dtype=np.int32)
+            self.local_tets = np.empty(4 * self.n_local_tets, dtype=np.int32)
+            capi.check(L.tetsim_plan_arrays(h, ip(self.local_to_global_vert), ip(self.local_to_global_tet), ip(self.local_tets)))
+            self.local_tets = self.local_tets.reshape(-1, 4)
+            self.neighbours = []
+            for i in range(sz.num_neighbours):
+                r, c = C.c_int32(), C.c_int32()
+                sc, rs, rc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+                capi.check(L.tetsim_plan_neighbour(h, i, C.byref(r), C.byref(sc), C.byref(rs), C.byref(rc), C.byref(c)))
+                nb = Neighbour()
+                nb.rank, nb.recv_start, nb.recv_count, nb.contiguous = r.value, rs.value, rc.value, bool(c.value)
+                nb.send_local = np.empty(sc.value, dtype=np.int32)
+                nb.send_global = np.empty(sc.value, dtype=np.int32)
+                nb.recv_global = np.empty(rc.value, dtype=np.int32)
+                capi.check(L.tetsim_plan_neighbour_ids(h, i, ip(nb.send_local), ip(nb.send_global), ip(nb.recv_global)))
+                self.neighbours.append(nb)
+        finally:
+            L.tetsim_plan_destroy(h)
