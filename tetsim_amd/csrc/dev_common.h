@@ -56,8 +56,8 @@ struct PJBlk {
     const uint32_t* lc_range = nullptr;      // per tile slot: first | end << 16 into the tile's entry list
     const uint2* lc_ent = nullptr;           // [nt] 4 x u16 per tet position: (tetLocal*4 + corner), grouped by slot
     float4* partial = nullptr;               // per tile slot: (sum V*goal, sum V)
-    const uint32_t* vp_off = nullptr;        // [nv_owned+1]
-    const uint32_t* vp_idx = nullptr;        // partial-sum indices of each owned particle
+    const uint32_t* vp_ell = nullptr;        // ELL [vp_cols][nv_pad]: partial-sum indices of each owned particle,
+    uint32_t vp_cols = 0, nv_pad = 0;        //   ascending tile, 0xffffffff = none
     float4* pos_pred = nullptr;
     float4* pos_final = nullptr;
     float4* vel = nullptr;

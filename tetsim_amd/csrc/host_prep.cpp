@@ -182,28 +182,58 @@ inline uint32_t spread3(uint32_t x) {  // 10 bits -> every third bit
 }
 }  // namespace
 
+namespace {
+struct Quantiser {
+    float lo[3], inv;
+    Quantiser(const float* xyz, uint32_t n) {
+        float hi[3] = {-1e30f, -1e30f, -1e30f};
+        lo[0] = lo[1] = lo[2] = 1e30f;
+        for (uint32_t v = 0; v < n; v++)
+            for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], xyz[3 * v + c]); hi[c] = std::max(hi[c], xyz[3 * v + c]); }
+        float ext = 1e-30f;
+        for (int c = 0; c < 3; c++) ext = std::max(ext, hi[c] - lo[c]);
+        inv = 1024.0f / ext;
+    }
+    uint32_t code(float x, float y, float z) const {
+        const float p[3] = {x, y, z};
+        uint32_t c = 0;
+        for (int a = 0; a < 3; a++) {
+            const uint32_t qv = static_cast<uint32_t>(std::min(1023.0f, std::max(0.0f, (p[a] - lo[a]) * inv)));
+            c |= spread3(qv) << a;
+        }
+        return c;
+    }
+};
+}  // namespace
+
+std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t first, uint32_t count) {
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (count < 2) return order;
+    const Quantiser Q(xyz, n);
+    std::vector<uint64_t> key(count);
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t v = first + i;
+        key[i] = (static_cast<uint64_t>(Q.code(xyz[3 * v], xyz[3 * v + 1], xyz[3 * v + 2])) << 32) | v;
+    }
+    std::sort(key.begin(), key.end());
+    for (uint32_t i = 0; i < count; i++) order[first + i] = static_cast<uint32_t>(key[i] & 0xffffffffu);
+    return order;
+}
+
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out) {
     BlockPlan& B = *out;
     B = BlockPlan();
     constexpr uint32_t kMaxTets = 256, kMaxVerts = 256;
     // 1. Morton order of rest centroids (quantised to 10 bits per axis over the bounding box)
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    for (uint32_t v = 0; v < nv; v++)
-        for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], verts[3 * v + c]); hi[c] = std::max(hi[c], verts[3 * v + c]); }
-    float ext = 1e-30f;
-    for (int c = 0; c < 3; c++) ext = std::max(ext, hi[c] - lo[c]);
+    const Quantiser Q(verts, nv);
     std::vector<uint64_t> key(nt);
     for (uint32_t e = 0; e < nt; e++) {
-        uint32_t code = 0;
-        for (int c = 0; c < 3; c++) {
-            float m = 0.0f;
-            for (int k = 0; k < 4; k++) m += verts[3 * tets[4 * e + k] + c];
-            const float u = (0.25f * m - lo[c]) / ext;
-            const uint32_t qv = static_cast<uint32_t>(std::min(1023.0f, std::max(0.0f, u * 1024.0f)));
-            code |= spread3(qv) << c;
-        }
-        key[e] = (static_cast<uint64_t>(code) << 32) | e;  // ties keep the caller's order
+        float m[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < 4; k++)
+            for (int c = 0; c < 3; c++) m[c] += verts[3 * tets[4 * e + k] + c];
+        key[e] = (static_cast<uint64_t>(Q.code(0.25f * m[0], 0.25f * m[1], 0.25f * m[2])) << 32) | e;  // ties keep the caller's order
     }
     std::sort(key.begin(), key.end());
     B.tet_perm.resize(nt);
@@ -234,12 +264,16 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
                 if (!seen) fresh++;
             }
             if (touched.size() + fresh > kMaxVerts) break;
-            for (int k = 0; k < 4; k++) {
-                if (slot_of[t[k]] < 0) { slot_of[t[k]] = static_cast<int32_t>(touched.size()); touched.push_back(t[k]); }
-                B.tet_lidx[4ull * i + k] = static_cast<uint8_t>(slot_of[t[k]]);
-            }
+            for (int k = 0; k < 4; k++)
+                if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); }
             i++;
         }
+        // LDS slots in ascending particle id: with Morton-numbered particles a tile's slots are a few contiguous
+        // runs of the position array, and a particle's partial sums sit next to its neighbours'
+        std::sort(touched.begin(), touched.end());
+        for (size_t u = 0; u < touched.size(); u++) slot_of[touched[u]] = static_cast<int32_t>(u);
+        for (uint32_t j = t0; j < i; j++)
+            for (int k = 0; k < 4; k++) B.tet_lidx[4ull * j + k] = static_cast<uint8_t>(slot_of[tets[4 * B.tet_perm[j] + k]]);
         const uint32_t ntb = i - t0, nu = static_cast<uint32_t>(touched.size());
         const uint32_t v0 = B.blk_vert_off.back();
         // per-slot entry lists: counting sort of the live (tetLocal, corner) pairs, tet order within a slot
@@ -274,6 +308,10 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     }
     B.vp_idx.reserve(B.vp_off[nv_sum]);
     for (uint32_t v = 0; v < nv_sum; v++) B.vp_idx.insert(B.vp_idx.end(), vert_partials[v].begin(), vert_partials[v].end());
+    B.nv_pad = (nv_sum + 63u) & ~63u;
+    B.vp_ell.assign(static_cast<size_t>(std::max(B.max_partials, 1u)) * B.nv_pad, 0xffffffffu);
+    for (uint32_t v = 0; v < nv_sum; v++)
+        for (size_t j = 0; j < vert_partials[v].size(); j++) B.vp_ell[j * B.nv_pad + v] = vert_partials[v][j];
 }
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats) {

@@ -54,6 +54,11 @@ struct Partition {
 std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
                             const int32_t* vert_owner, Partition* out);
 
+// Permutation that sorts points [first, first+count) of `xyz` along a Morton (Z-order) curve; entries outside that
+// range map to themselves.  order[new] = old.  Used to renumber particles internally so that particles that are
+// close in space are close in memory (tile staging and partial-sum gathers then touch near-contiguous runs).
+std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t first, uint32_t count);
+
 // Workgroup tiling for the blocked POLAR_JACOBI formulation (DESIGN.md "Blocked formulation").
 // Tets are sorted along a Morton curve of their rest centroids and cut into tiles of <= 256 tets that touch
 // <= 256 distinct vertices, so a tile's vertex set fits an LDS tile addressed by 8-bit local indices.
@@ -68,6 +73,8 @@ struct BlockPlan {
     std::vector<uint16_t> lc_ent;        // [4*nt] per tile: (tetLocal*4+corner) grouped by LDS slot, tet order inside
     std::vector<uint32_t> vp_off;        // [nv_sum+1] per summed vertex: range into vp_idx
     std::vector<uint32_t> vp_idx;        // indices into the partial-sum array, ascending tile
+    std::vector<uint32_t> vp_ell;        // the same lists as ELL [max_partials][nv_pad], 0xffffffff = none
+    uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions

@@ -95,14 +95,15 @@ __global__ __launch_bounds__(256) void pjb_vertex_kernel(PJBlk d, uint32_t first
     const uint32_t v = first + i;
     const DevParams& P = *d.params;
 
-    // P5 (SoftbodyGPU.js:302-320) from tile partial sums, ascending tile order
-    const uint32_t o0 = d.vp_off[v], o1 = d.vp_off[v + 1];
+    // P5 (SoftbodyGPU.js:302-320) from tile partial sums, ascending tile order.  The index lists are ELL
+    // (column-major, coalesced, no offset lookup first), fetched 4 columns at a time so 4 gathers are in flight.
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t o = o0; o < o1; o += 4u) {
+    const uint32_t* col = d.vp_ell + v;
+    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 4u) {
         uint32_t idx[4];
         float4 g[4];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) idx[j] = (o + j < o1) ? d.vp_idx[o + j] : 0xffffffffu;
+        for (uint32_t j = 0; j < 4u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll

@@ -94,6 +94,9 @@ struct tetsim_body {
     PJBlk blk;             // blocked formulation (FAST unless TETSIM_FLAG_GATHER_FORMULATION)
     bool blocked = false;
     std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
+    // Particles are renumbered on the device (Morton order inside the interior segment) for locality; the API keeps
+    // the caller's / the partition plan's numbering.  api2dev[a] = device index of API-local particle a.
+    std::vector<uint32_t> api2dev, dev2api;
     Partition part;
     bool partitioned = false;
     std::vector<int32_t> g2l_owned;  // global vertex -> local id (owned) or -1
@@ -161,8 +164,10 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
     }
     o->grab_local = -1;
     if (h->grab_global >= 0) {
-        if (!h->partitioned) o->grab_local = h->grab_global;
-        else if (static_cast<size_t>(h->grab_global) < h->g2l_owned.size()) o->grab_local = h->g2l_owned[h->grab_global];
+        int32_t a = -1;  // API-local index
+        if (!h->partitioned) a = h->grab_global;
+        else if (static_cast<size_t>(h->grab_global) < h->g2l_owned.size()) a = h->g2l_owned[h->grab_global];
+        if (a >= 0) o->grab_local = h->api2dev.empty() ? a : static_cast<int32_t>(h->api2dev[a]);
     }
     o->d_dt = dt;
     o->d_gravity = p.gravity;
@@ -289,7 +294,11 @@ int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     std::vector<float4> tmp(n);
     if (n) HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(float4), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; i++) { out[3 * i] = tmp[i].x; out[3 * i + 1] = tmp[i].y; out[3 * i + 2] = tmp[i].z; }
+    const bool perm = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI && !h->api2dev.empty();
+    for (uint32_t i = 0; i < n; i++) {
+        const float4& t = tmp[perm ? h->api2dev[i] : i];  // owned particles keep their segment: api2dev[i] < n
+        out[3 * i] = t.x; out[3 * i + 1] = t.y; out[3 * i + 2] = t.z;
+    }
     return 0;
 }
 
@@ -319,6 +328,19 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         ltets.assign(tets, tets + 4ull * nt);
         h->info.owned_elems = nt;
     }
+    // device numbering: Morton order inside the interior segment [nvb, nvo); boundary (halo sends stay contiguous
+    // runs) and ghosts (receive ranges) keep the plan's order
+    {
+        std::vector<float> lv(3ull * nvl);
+        for (uint32_t i = 0; i < nvl; i++) {
+            const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
+            lv[3 * i] = verts[3 * g]; lv[3 * i + 1] = verts[3 * g + 1]; lv[3 * i + 2] = verts[3 * g + 2];
+        }
+        h->dev2api = morton_vertex_order(lv.data(), nvl, nvb, nvo - nvb);
+        h->api2dev.resize(nvl);
+        for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
+        for (auto& id : ltets) id = static_cast<int32_t>(h->api2dev[id]);
+    }
     const bool quirk_here = ref_table && ntl > 0 && (!h->partitioned || l2g_t[0] == 0);
     Incidence inc = build_incidence(ltets.data(), ntl, nvl, quirk_here, ref_table);
     // Only owned vertices are averaged here; the table rows of ghosts are never read.
@@ -344,8 +366,9 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
 
     std::vector<float4> pos(nvl);
     std::vector<float> lverts(3ull * nvl);
-    for (uint32_t i = 0; i < nvl; i++) {
-        const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
+    for (uint32_t i = 0; i < nvl; i++) {  // i = device index
+        const uint32_t a = h->dev2api[i];
+        const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[a]) : a;
         pos[i] = make_float4(verts[3 * g], verts[3 * g + 1], verts[3 * g + 2], 0.0f);
         lverts[3 * i] = verts[3 * g]; lverts[3 * i + 1] = verts[3 * g + 1]; lverts[3 * i + 2] = verts[3 * g + 2];
     }
@@ -368,7 +391,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         PJBlk& k = h->blk;
         k.nb = B.num_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
-        uint32_t *bto, *bvo, *lcr, *vpo, *vpi;
+        uint32_t *bto, *bvo, *lcr, *vpe;
         int32_t* bv;
         uchar4* lidx;
         float* vol;
@@ -386,8 +409,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = dev_alloc(h, &lcr, nslots))) return rc;
         if ((rc = dev_alloc(h, &lce, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.partial, nslots))) return rc;
-        if ((rc = dev_alloc(h, &vpo, B.vp_off.size()))) return rc;
-        if ((rc = dev_alloc(h, &vpi, B.vp_idx.size()))) return rc;
+        if ((rc = dev_alloc(h, &vpe, B.vp_ell.size()))) return rc;
         std::vector<float4> ra(ntl), rb(ntl), rcv(ntl), quat(ntl, make_float4(0, 0, 0, 1));
         std::vector<float> volh(ntl);
         std::vector<uchar4> lidxh(ntl);
@@ -415,11 +437,10 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = upload(h, k.quat, quat))) return rc;
         if ((rc = upload(h, lcr, B.lc_range))) return rc;
         if ((rc = upload(h, lce, lceh))) return rc;
-        if ((rc = upload(h, vpo, B.vp_off))) return rc;
-        if ((rc = upload(h, vpi, B.vp_idx))) return rc;
+        if ((rc = upload(h, vpe, B.vp_ell))) return rc;
         HIPCHK(h, hipMemset(k.partial, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
         k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
-        k.lc_range = lcr; k.lc_ent = lce; k.vp_off = vpo; k.vp_idx = vpi;
+        k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
     } else {
         if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
@@ -738,8 +759,9 @@ int tetsim_write_state(tetsim_handle h, const float* pos, const float* vel) {
     const uint32_t n = pjs ? h->pj.nv_owned : h->nh.nv;
     std::vector<float4> p(n), v(n);
     for (uint32_t i = 0; i < n; i++) {
-        p[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pjs ? 0.0f : h->h_inv_mass[i]);
-        v[i] = make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.0f);
+        const uint32_t dv = (pjs && !h->api2dev.empty()) ? h->api2dev[i] : i;
+        p[dv] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pjs ? 0.0f : h->h_inv_mass[i]);
+        v[dv] = make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.0f);
     }
     if (pjs) {
         if (h->partitioned && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "write_state is not supported on partitioned bodies");
