@@ -185,13 +185,14 @@ def main():
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3
         achieved = TET_KERNEL_BYTES * len(tets) / (tet_us * 1e-6) / 1e9
         b_alg = TET_KERNEL_BYTES + VERTEX_BYTES * len(verts) / len(tets)
+        kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
         traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if present
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get("pj_tet_kernel_%s" % args.precision)
+                traffic = json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "pj_tet_kernel_%s" % args.precision,
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),

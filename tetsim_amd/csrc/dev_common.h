@@ -62,6 +62,7 @@ struct PJBlk {
     float4* pos_final = nullptr;
     float4* vel = nullptr;
     const DevParams* params = nullptr;
+    unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
 
 // ---- NEOHOOKEAN_GS device state ---------------------------------------------------------------------

@@ -4,7 +4,7 @@
 // scatter between the two kernels is restructured around workgroup tiles so that HBM traffic drops from
 // ~270 B to ~180 B per tet-solve and almost all random 16-byte gathers become LDS reads:
 //
-//   pjb_tet_kernel     one workgroup per tile (<= 256 tets, <= 256 distinct particles):
+//   pjb_tet_kernel     one workgroup per tile (<= 256 tets, <= 256 distinct particles), 8 workgroups per CU:
 //     1. the tile's particle positions are loaded once into LDS (one gather per distinct particle instead of
 //        one per corner: 131 instead of 1024 on the lattice);
 //     2. each lane solves one tet from LDS-resident corners (rotation extraction, goals), streams its carried
@@ -16,9 +16,17 @@
 //   pjb_vertex_kernel  one lane per particle: adds the 1..9 (2.9 on average) partial sums of the tiles that touch
 //        it instead of gathering ~23 goals, then collides / integrates exactly like the gather formulation.
 //
+// Tried and dropped (measured on the 1 M-tet lattice): (a) a persistent variant prefetching tile i+1
+// during tile i's solve, with scalar tile headers, a 3-deep index pipeline, a peeled first trip and counted
+// vmcnt waits: 49 us vs 42-44 us, its 0-iteration base is already slower (32.5 vs 28.5 us); (b) having the particle
+// pass scatter positions into the tile cells (no staging gather here): tet kernel 40.9 us but the particle pass
+// 9.8 -> 18.7 us; (c) staggering the first round of workgroups with s_sleep: strictly slower.
+//
 // Result differs from the gather formulation only by summation order (tile partials) -- tolerance-level, FAST
 // mode only; PRECISE keeps the reference's slot order.
 #define TETSIM_FAST 1
+#include <cstdlib>
+
 #include "dev_common.h"
 
 namespace tetsim {
@@ -26,23 +34,48 @@ namespace {
 
 #include "pj_math.inc"
 
+// Streamed outputs (carried rest shape, quaternion, partial sums, particle state) are written WRITE-THROUGH
+// (sc0 sc1): a plain store leaves the line dirty in the XCD's 4 MiB L2, and a kernel that streams ~70 MB of
+// results then pays the write-back of whatever is still dirty at its end, outside the CUs' busy time (per-CU
+// s_memtime timelines: ~65k busy cycles inside a ~96k-cycle kernel).  With write-through the bytes leave while the
+// kernel is still computing.  The data is next read by OTHER CUs in the next kernel, so L2 residency is not needed.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float4* p, const float4& v) {
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd) { return (b & 7u) * tiles_per_xcd + (b >> 3); }
 
 constexpr uint32_t kTile = 256;
 
-__global__ __launch_bounds__(256) void pjb_tet_kernel(PJBlk d, uint32_t tiles_per_xcd) {
-    __shared__ float4 s_pos[kTile];        // staged particle positions, later reused for nothing else
-    __shared__ float4 s_goal[4 * kTile];   // (V*goal, V) per corner, plane-major: [corner][tet]
+// LDS per workgroup is kept at 19 KB (4 + 12 + 1 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
+// fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
+// `dbg` is a development knob for timing ablations (bits 0-3: rotation iterations, bit 4: skip the rest-shape
+// write-back); the product always passes 9 / 0 -- anything else produces wrong physics.
+__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tiles_per_xcd, uint32_t dbg) {
+    __shared__ float4 s_pos[kTile];        // staged particle positions
+    __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
+    __shared__ float s_gy[4 * kTile];
+    __shared__ float s_gz[4 * kTile];
+    __shared__ float s_v[kTile];           // V per tet
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
     const uint32_t b = xcd_tile(blockIdx.x, tiles_per_xcd);
     if (b >= d.nb) return;  // whole workgroup leaves together
     const uint32_t tid = threadIdx.x;
+#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    TETSIM_STAMP(0);
+    if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
 
-    // 1. stage the tile's particles; issue this lane's streaming loads before the barrier so they overlap it
-    if (tid < nu) s_pos[tid] = d.pos_pred[d.blk_verts[v0 + tid]];
+    // 1. stage the tile's particles; every global load of this lane is issued before the barrier
+    uint32_t range = 0;
+    if (tid < nu) {
+        s_pos[tid] = d.pos_pred[d.blk_verts[v0 + tid]];
+        range = d.lc_range[v0 + tid];
+    }
     const bool has_tet = tid < ntb;
     const uint32_t e = t0 + (has_tet ? tid : 0u);
     uchar4 li = make_uchar4(0, 0, 0, 0);
@@ -55,7 +88,9 @@ __global__ __launch_bounds__(256) void pjb_tet_kernel(PJBlk d, uint32_t tiles_pe
         V = d.vol[e];
         s_ent[tid] = d.lc_ent[e];
     }
+    TETSIM_STAMP(1);  // loads issued (and landed, for this wave)
     __syncthreads();
+    TETSIM_STAMP(2);  // tile staged
 
     // 2. solve
     if (has_tet) {
@@ -64,29 +99,60 @@ __global__ __launch_bounds__(256) void pjb_tet_kernel(PJBlk d, uint32_t tiles_pe
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
         float4 q_new;
-        pj_solve_tet(cur, rest, q_old, q_new, goal);
-        d.quat[e] = q_new;
-        d.rest_a[e] = make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x);
-        d.rest_b[e] = make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y);
-        d.rest_c[e] = make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z);
+        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u));
+        TETSIM_STAMP(3);  // solved
+        if (dbg & 32u) {  // A/B: plain stores
+            d.quat[e] = q_new;
+            d.rest_a[e] = make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x);
+            d.rest_b[e] = make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y);
+            d.rest_c[e] = make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z);
+        } else {
+            store_wt(&d.quat[e], q_new);
+            if (!(dbg & 16u)) {
+                store_wt(&d.rest_a[e], make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
+                store_wt(&d.rest_b[e], make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
+                store_wt(&d.rest_c[e], make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
+            }
+        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) s_goal[k * kTile + tid] = make_float4(goal[k].x * V, goal[k].y * V, goal[k].z * V, V);
+        for (int k = 0; k < 4; k++) {
+            s_gx[k * kTile + tid] = goal[k].x * V;
+            s_gy[k * kTile + tid] = goal[k].y * V;
+            s_gz[k * kTile + tid] = goal[k].z * V;
+        }
+        s_v[tid] = V;
     }
+    TETSIM_STAMP(4);  // stores issued
     __syncthreads();
+    TETSIM_STAMP(5);
 
-    // 3. one lane per tile particle: fixed-order sum of its corner goals
+    // 3. one lane per tile particle: fixed-order sum of its corner goals -> one partial per (tile, particle)
     if (tid < nu) {
-        const uint32_t range = d.lc_range[v0 + tid];
         const uint32_t first = range & 0xffffu, last = range >> 16;
         const uint16_t* ent = reinterpret_cast<const uint16_t*>(s_ent);
+        // 4 entries per trip: the 4 index reads, then the 16 value reads, are independent LDS ops in flight together
+        // (one entry at a time is a ~9-deep chain of dependent LDS round trips: 4.9k cycles per tile in the
+        // s_memtime trace).  Accumulation order stays entry order, i.e. deterministic.
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (uint32_t i = first; i < last; i++) {
-            const uint32_t en = ent[i];
-            const float4 g = s_goal[(en & 3u) * kTile + (en >> 2)];
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        for (uint32_t i = first; i < last; i += 4u) {
+            uint32_t en[4];
+            float gx[4], gy[4], gz[4], gv[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) en[j] = ent[min(i + j, last - 1u)];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t at = (en[j] & 3u) * kTile + (en[j] >> 2);
+                gx[j] = s_gx[at]; gy[j] = s_gy[at]; gz[j] = s_gz[at]; gv[j] = s_v[en[j] >> 2];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (i + j < last) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; acc.w += gv[j]; }
         }
-        d.partial[v0 + tid] = acc;
+        if (dbg & 32u) d.partial[v0 + tid] = acc;
+        else store_wt(&d.partial[v0 + tid], acc);
     }
+    TETSIM_STAMP(6);
+#undef TETSIM_STAMP
 }
 
 __global__ __launch_bounds__(256) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) {
@@ -128,10 +194,10 @@ __global__ __launch_bounds__(256) void pjb_vertex_kernel(PJBlk d, uint32_t first
     // P7, :364-372, then P1 + P2 of the next substep
     const float rdt = __builtin_amdgcn_rcpf(P.dt);
     const f3 vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * P.dt;
-    d.pos_final[v] = make_float4(p.x, p.y, p.z, 0.0f);
-    d.vel[v] = make_float4(vel.x, vel.y, vel.z, 0.0f);
+    store_wt(&d.pos_final[v], make_float4(p.x, p.y, p.z, 0.0f));
+    store_wt(&d.vel[v], make_float4(vel.x, vel.y, vel.z, 0.0f));
     const f3 pred = p + vel * P.dt;
-    d.pos_pred[v] = make_float4(pred.x, pred.y, pred.z, 0.0f);
+    store_wt(&d.pos_pred[v], make_float4(pred.x, pred.y, pred.z, 0.0f));
 }
 
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
@@ -146,7 +212,14 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 void pjb_launch_tet(hipStream_t s, const PJBlk& d) {
     if (d.nb == 0) return;
     const uint32_t per_xcd = (d.nb + 7u) / 8u;
-    hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, per_xcd);
+    static int dbg = -1;
+    if (dbg < 0) {  // timing ablations only (see kernel comment); unset => 9 iterations, all stores
+        const char* it = getenv("TETSIM_DEBUG_ITERS");
+        const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
+        const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
+        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0);
+    }
+    hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, per_xcd, static_cast<uint32_t>(dbg));
 }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count) {
     if (count == 0) return;

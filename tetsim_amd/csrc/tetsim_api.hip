@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -442,6 +444,10 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
+        if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
+            if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
+            HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));
+        }
     } else {
         if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
         if ((rc = dev_alloc(h, &d.elem, 4ull * d.nt_pad))) return rc;
@@ -664,6 +670,11 @@ void tetsim_destroy(tetsim_handle h) {
     (void)hipSetDevice(h->opt.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->blk.trace && getenv("TETSIM_DEBUG_TRACE")) {
+        std::vector<unsigned long long> tr(8ull * h->blk.nb);
+        if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
+    }
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : h->allocs) (void)hipFree(p);

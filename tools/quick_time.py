@@ -12,7 +12,8 @@ dt = (1.0 / 60.0) / 20
 print("lattice", n, "tets", len(t), "verts", len(v))
 for nbytes in (64 << 20, 1 << 30):
     print("copy bw %5d MiB: %.0f GB/s" % (nbytes >> 20, measure_copy_bandwidth(nbytes, 20)))
-for prec in ("precise", "fast"):
+fastonly = len(sys.argv) > 2
+for prec in (("fast",) if fastonly else ("precise", "fast")):
     t0 = time.time()
     b = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision=prec)
     t1 = time.time()
@@ -22,7 +23,7 @@ for prec in ("precise", "fast"):
     print("polar %-7s create %.2fs  frame(20) %.3f ms  -> %.1f M tet-solves/s | tet %.1f us vertex %.1f us per substep"
           % (prec, t1 - t0, ms, len(t) * 20 / ms / 1e3, pr["tet_ms"] / 20 * 1e3, pr["vertex_ms"] / 20 * 1e3))
     b.close()
-for prec in ("precise", "fast"):
+for prec in (() if fastonly else ("precise", "fast")):
     t0 = time.time()
     b = SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision=prec, order="coloured")
     t1 = time.time()
