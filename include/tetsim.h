@@ -198,6 +198,11 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t *id_out);
 
 /* Run n substeps eagerly with HIP events around every kernel on the handle's own stream. */
 int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, TetSimProfile *out);
+/* Kernel-only timing: `reps` back-to-back launches of the per-tet kernel(s) of one substep inside ONE HIP-event
+ * pair on the handle's stream, then the same for the per-particle kernel(s); kernel_ms[] = total / reps.  No event
+ * sits between kernels, so the figure is comparable with rocprofv3's per-kernel average.  The body is left in a
+ * finite but NON-PHYSICAL state (kernels are repeated out of sequence): call it on a scratch body. */
+int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimParams *params, TetSimProfile *out);
 /* n substeps through the production path (tetsim_step_n), bracketed by HIP events on the handle's
  * stream; returns elapsed milliseconds.  Synchronises. */
 int tetsim_time_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, double *ms_out);

@@ -1,0 +1,44 @@
+"""The Node.js side of the drop-in boundary: N-API shim (tetsim_amd/node/tetsim_napi.cc) + SoftBodyHIP.js."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+NODE = shutil.which("node")
+NODE_DIR = os.path.join(ROOT, "tetsim_amd", "node")
+
+
+def _addon():
+    from tetsim_amd.node.build_addon import build_addon
+    try:
+        return build_addon()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed on this host")
+def test_addon_loads_and_fails_loudly_without_gpu():
+    _addon()
+    js = ("const a=require(%r); const keys=Object.keys(a).sort().join(',');"
+          "console.log('KEYS '+keys); console.log('ABI '+a.load(%r));"
+          "try{a.create(new Float32Array([0,0,0,1,0,0,0,1,0,0,0,1]),new Int32Array([0,1,2,3]),{});console.log('CREATED');}"
+          "catch(e){console.log('THROWN '+e.message);}") % (os.path.join(NODE_DIR, "tetsim_napi.node"),
+                                                         os.path.join(ROOT, "tetsim_amd", "libtetsim_hip.so"))
+    out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120).stdout
+    assert "KEYS create,destroy,info,load,readPositions,readQuats,readVelocities,readVolError,setGrab,startGrab,step,stepN,sync" in out
+    assert "ABI 1" in out
+    assert "CREATED" in out or "no CPU fallback" in out  # on a GPU host creation succeeds; otherwise it must throw
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed on this host")
+def test_softbodyhip_js_bit_exact_vs_reference_goldens():
+    """SoftBodyHIP.js (reference constructor + simulate/endFrame/grab surface) over N-API on the GPU:
+    Neo-Hookean PRECISE == Softbody.js goldens bit for bit; polar frame loop + grab."""
+    _addon()
+    r = subprocess.run([NODE, os.path.join(NODE_DIR, "test_softbody.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "node boundary ok" in r.stdout

@@ -59,7 +59,7 @@ SYMBOLS = [
     "tetsim_read_positions", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_grab",
-    "tetsim_start_grab", "tetsim_profile", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
+    "tetsim_start_grab", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
     "tetsim_prep_slot_table", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
@@ -104,6 +104,7 @@ def lib():
     L.tetsim_set_grab.argtypes = [H, i32, fp]
     L.tetsim_start_grab.argtypes = [H, fp, ip]
     L.tetsim_profile.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]
+    L.tetsim_time_kernels.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]
     L.tetsim_time_step_n.argtypes = [H, u32, dbl, PP, dp]
     L.tetsim_measure_copy_bandwidth.argtypes = [i32, C.c_uint64, u32, dp]
     L.tetsim_comm_unique_id.argtypes = [C.c_void_p]

@@ -901,6 +901,49 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     return 0;
 }
 
+int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimParams* params, TetSimProfile* out) {
+    if (!h || !out || reps == 0) return fail(h, TETSIM_EINVAL, "bad argument");
+    if (h->comm && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "time a partitioned body through rocprofv3 instead");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    std::memset(out, 0, sizeof(*out));
+    int rc = push_params(h, dt, params);
+    if (rc) return rc;
+    if ((rc = ensure_prediction(h, dt))) return rc;
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    auto tet_once = [&]() {
+        if (pjs) { pj_tet(h); return 1u; }
+        for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
+            const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
+            h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        }
+        return static_cast<uint32_t>(h->level_off.size() - 1);
+    };
+    auto vert_once = [&]() {
+        if (pjs) { pj_vertex(h, 0, h->pj.nv_owned); return 1u; }
+        h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
+        h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+        return 2u;
+    };
+    float ms = 0.0f;
+    for (int which = 0; which < 2; which++) {
+        (which == 0 ? tet_once() : vert_once());  // warm
+        HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
+        uint32_t launches = 0;
+        for (uint32_t r = 0; r < reps; r++) launches += which == 0 ? tet_once() : vert_once();
+        HIPCHK(h, hipEventRecord(h->ev_b, h->stream));
+        HIPCHK(h, hipEventSynchronize(h->ev_b));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+        const int k = which == 0 ? TETSIM_K_TET : TETSIM_K_VERTEX;
+        out->kernel_ms[k] = ms;
+        out->launches[k] = launches;
+        out->total_ms += ms;
+    }
+    out->substeps = reps;
+    h->pred_any_dt = false;
+    h->dt_pred = std::nanf("");  // the prediction no longer matches the state
+    return 0;
+}
+
 int tetsim_time_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params, double* ms_out) {
     if (!h || !ms_out) return fail(h, TETSIM_EINVAL, "null argument");
     HIPCHK(h, hipSetDevice(h->opt.device));

@@ -1,0 +1,142 @@
+'use strict';
+// SoftBodyHIP.js -- Node.js twin of the reference's solver objects, backed by libtetsim_hip.so through the N-API
+// shim (tetsim_napi.cc -> include/tetsim.h).  Drop-in for
+//     new SoftBody(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial)          (Softbody.js:4-5)
+//     new SoftBodyGPU(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial, world)  (SoftbodyGPU.js:5-6)
+// in the driver loop of main.js:52-96: `.simulate(dt, physicsParams)` per substep, `.endFrame()` per frame,
+// `.startGrab/.moveGrabbed/.endGrab`, fields `.edgeMesh .visMesh .pos .grabId .grabPos .numParticles .numElems .volError`.
+//
+// three.js is INJECTED, never bundled: pass it as `world.THREE` (or set SoftBodyHIP.THREE = require('three')).  Without it
+// the body is headless (physics only; edgeMesh / visMesh stay null).
+//
+// Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
+//     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured', device: 0 }
+// default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
+const path = require('path');
+
+const SOLVER = { polar: 0, neohookean: 1 };
+const PRECISION = { precise: 0, fast: 1 };
+const ORDER = { original: 0, coloured: 1 };
+const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2;
+
+let addon = null;
+function loadTetSim(libPath) {
+    if (addon) return addon;
+    addon = require(path.join(__dirname, 'tetsim_napi.node'));
+    addon.load(libPath || process.env.TETSIM_HIP_LIB || path.join(__dirname, '..', 'libtetsim_hip.so'));
+    return addon;
+}
+
+class SoftBodyHIP {
+    constructor(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial, world) {
+        const api = loadTetSim();
+        this.physicsParams = physicsParams || {};
+        const opt = this.physicsParams.tetsim || {};
+        this.numParticles = vertices.length / 3;   // Softbody.js:9
+        this.numElems = tetIds.length / 4;         // Softbody.js:10
+        this.tetIds = tetIds;                      // held by reference, as the reference does (Softbody.js:19)
+        this.pos = Float32Array.from(vertices);    // vertices.slice(0), Softbody.js:12
+        this.grabPos = new Float32Array(3);
+        this.grabId = -1;
+        this.volError = 0.0;
+        this._api = api;
+        this._solver = opt.solver || 'polar';
+        const verts32 = vertices instanceof Float32Array ? vertices : Float32Array.from(vertices);
+        const tets32 = tetIds instanceof Int32Array ? tetIds : Int32Array.from(tetIds);
+        this._h = api.create(verts32, tets32, {
+            solver: SOLVER[this._solver], precision: PRECISION[opt.precision || 'precise'], order: ORDER[opt.order || 'original'],
+            flags: FLAG_REF_SLOT_TABLE | FLAG_REF_FIXED_BOUNDS, device: opt.device || 0,
+            density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
+        });
+        this._dirty = false;
+
+        // display objects (Softbody.js:36-57 / SoftbodyGPU.js:415-461), only when three.js was injected
+        const THREE = (world && world.THREE) || SoftBodyHIP.THREE || null;
+        this.edgeMesh = null;
+        this.visMesh = null;
+        this.visVerts = visVerts || new Float32Array(0);
+        this.numVisVerts = this.visVerts.length / 4;
+        if (THREE) {
+            let geometry = new THREE.BufferGeometry();
+            // the reference aliases the caller's `vertices` array here and overwrites it every frame (Softbody.js:37,252)
+            geometry.setAttribute('position', new THREE.BufferAttribute(vertices, 3));
+            geometry.setIndex(tetEdgeIds);
+            this.edgeMesh = new THREE.LineSegments(geometry);
+            this.edgeMesh.userData = this;   // for raycasting
+            this.edgeMesh.layers.enable(1);
+            this.edgeMesh.visible = true;
+            geometry = new THREE.BufferGeometry();
+            geometry.setAttribute('position', new THREE.BufferAttribute(new Float32Array(3 * this.numVisVerts), 3));
+            geometry.setIndex(visTriIds);
+            this.visMesh = new THREE.Mesh(geometry, visMaterial);
+            this.visMesh.castShadow = true;
+            this.visMesh.userData = this;
+            this.visMesh.layers.enable(1);
+            geometry.computeVertexNormals();
+            this.updateVisMesh();
+        }
+    }
+
+    // ---- the hot path ------------------------------------------------------------------------------------------
+    simulate(dt, physicsParams) {                       // ONE substep, asynchronous (Softbody.js:195 / SoftbodyGPU.js:610)
+        const pp = physicsParams || this.physicsParams;
+        if (this._solver === 'polar') pp.dt = dt;       // SoftbodyGPU.js:611 writes dt back into the caller's object
+        this._api.step(this._h, dt, pp);
+        this._dirty = true;
+    }
+    simulateSubsteps(n, dt, physicsParams) {            // the whole loop of main.js:79-84 as one FFI crossing / graph launch
+        this._api.stepN(this._h, n, dt, physicsParams || this.physicsParams);
+        this._dirty = true;
+    }
+    endFrame() {                                        // Softbody.js:244-247
+        this.readToCPU();
+        if (this.edgeMesh) this.updateEdgeMesh();
+        if (this.visMesh) this.updateVisMesh();
+    }
+    readToCPU() {                                       // SoftbodyGPU.js:649-653
+        if (this._dirty) {
+            this._api.readPositions(this._h, this.pos);
+            if (this._solver === 'neohookean') this.volError = this._api.readVolError(this._h);
+            this._dirty = false;
+        }
+        return this.pos;
+    }
+    updateEdgeMesh() {                                  // Softbody.js:249-257
+        const positions = this.edgeMesh.geometry.attributes.position.array;
+        positions.set(this.pos);
+        this.edgeMesh.geometry.attributes.position.needsUpdate = true;
+        this.edgeMesh.geometry.computeBoundingSphere();
+    }
+    updateVisMesh() {                                   // Softbody.js:259-277: barycentric skinning of the embedded mesh
+        const positions = this.visMesh.geometry.attributes.position.array;
+        const vv = this.visVerts, p = this.pos, t = this.tetIds;
+        for (let i = 0, nr = 0; i < this.numVisVerts; i++) {
+            const tetNr = vv[nr++] * 4, b0 = vv[nr++], b1 = vv[nr++], b2 = vv[nr++], b3 = 1.0 - b0 - b1 - b2;
+            const i0 = 3 * t[tetNr], i1 = 3 * t[tetNr + 1], i2 = 3 * t[tetNr + 2], i3 = 3 * t[tetNr + 3];
+            for (let c = 0; c < 3; c++) positions[3 * i + c] = p[i0 + c] * b0 + p[i1 + c] * b1 + p[i2 + c] * b2 + p[i3 + c] * b3;
+        }
+        if (this.physicsParams.computeNormals !== false) this.visMesh.geometry.computeVertexNormals();
+        this.visMesh.geometry.attributes.position.needsUpdate = true;
+        this.visMesh.geometry.computeBoundingSphere();
+    }
+
+    // ---- grab (Softbody.js:279-298) ------------------------------------------------------------------------------
+    startGrab(pos) {
+        this.grabId = this._api.startGrab(this._h, pos.x, pos.y, pos.z);   // nearest particle, on the latest positions
+        this.grabPos[0] = pos.x; this.grabPos[1] = pos.y; this.grabPos[2] = pos.z;
+    }
+    moveGrabbed(pos) {
+        this.grabPos[0] = pos.x; this.grabPos[1] = pos.y; this.grabPos[2] = pos.z;
+        this._api.setGrab(this._h, this.grabId, pos.x, pos.y, pos.z);
+    }
+    endGrab() {
+        this.grabId = -1;
+        this._api.setGrab(this._h, -1, 0, 0, 0);
+    }
+
+    info() { return this._api.info(this._h); }
+    dispose() { if (this._h) { this._api.destroy(this._h); this._h = null; } }
+}
+SoftBodyHIP.THREE = null;
+
+module.exports = { SoftBodyHIP, loadTetSim };

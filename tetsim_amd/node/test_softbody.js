@@ -1,0 +1,53 @@
+'use strict';
+// Node-side parity check of the N-API boundary (run on a GPU host):  node tetsim_amd/node/test_softbody.js
+// Neo-Hookean PRECISE through SoftBodyHIP must reproduce, bit for bit, golden vectors recorded from the reference's
+// Softbody.js (tests/golden/make_golden.mjs); the polar path must stay finite and honour grab/endFrame.
+const fs = require('fs');
+const path = require('path');
+const assert = require('assert');
+const { SoftBodyHIP } = require('./SoftBodyHIP.js');
+
+const G = path.join(__dirname, '..', '..', 'tests', 'golden');
+const f32 = n => { const b = fs.readFileSync(path.join(G, n)); return new Float32Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)); };
+const i32 = n => { const b = fs.readFileSync(path.join(G, n)); return new Int32Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)); };
+const bitsEqual = (a, b) => { const x = new Uint32Array(a.buffer, a.byteOffset, a.length), y = new Uint32Array(b.buffer, b.byteOffset, b.length); for (let i = 0; i < x.length; i++) if (x[i] !== y[i]) return i; return -1; };
+
+const verts = f32('dragon_verts.f32'), tets = Array.from(i32('dragon_tets.i32'));   // the reference passes a plain Array
+const pp = { gravity: -9.81, timeScale: 1.0, timeStep: 1.0 / 60.0, numSubsteps: 10, friction: 1000.0, density: 1000.0,
+             devCompliance: 1.0 / 100000.0, volCompliance: 0.0, worldBounds: [-2.5, -1.0, -2.5, 2.5, 10.0, 2.5] };
+const dt = (pp.timeScale * pp.timeStep) / pp.numSubsteps;   // main.js:79
+
+// 1. Softbody.js mirror, exact
+pp.tetsim = { solver: 'neohookean', precision: 'precise' };
+let body = new SoftBodyHIP(verts.slice(0), tets, [], pp, new Float32Array(0), [], null);
+assert.strictEqual(body.numParticles, 1234); assert.strictEqual(body.numElems, 3840);
+for (let step = 1; step <= 100; step++) {
+    body.simulate(dt, pp);
+    if (step === 1 || step === 10 || step === 100) {
+        body.endFrame();
+        assert.strictEqual(bitsEqual(body.pos, f32(`dragon_pos_${step}.f32`)), -1, `positions differ from Softbody.js at substep ${step}`);
+    }
+}
+const golden = JSON.parse(fs.readFileSync(path.join(G, 'golden.json'))).cases.dragon.steps['100'];
+assert.strictEqual(body.volError, golden.volError);
+body.dispose();
+console.log('neohookean/precise: bit-exact vs Softbody.js goldens at substeps 1, 10, 100 (volError', golden.volError + ')');
+
+// 2. SoftbodyGPU.js mirror: frame loop, grab, dt write-back
+pp.tetsim = { solver: 'polar', precision: 'fast' };
+pp.numSubsteps = 20;
+body = new SoftBodyHIP(verts.slice(0), tets, [], pp, new Float32Array(0), [], null, {});
+const dt20 = (pp.timeScale * pp.timeStep) / pp.numSubsteps;
+for (let frame = 0; frame < 5; frame++) { body.simulateSubsteps(pp.numSubsteps, dt20, pp); body.endFrame(); }
+body.startGrab({ x: 0.0, y: 1.2, z: 0.0 });
+assert.ok(body.grabId >= 0 && body.grabId < body.numParticles);
+body.moveGrabbed({ x: 0.05, y: 1.25, z: 0.0 });
+body.simulate(dt20, pp); body.endFrame();
+assert.strictEqual(pp.dt, dt20);
+const g = body.grabId;
+assert.ok(Math.abs(body.pos[3 * g] - 0.05) < 1e-7 && Math.abs(body.pos[3 * g + 1] - 1.25) < 1e-6);
+body.endGrab();
+for (let i = 0; i < body.pos.length; i++) assert.ok(Number.isFinite(body.pos[i]));
+console.log('polar/fast: 5 frames x 20 substeps + grab ok; info', JSON.stringify(body.info()));
+body.dispose();
+console.log('node boundary ok');

@@ -1,0 +1,286 @@
+// tetsim_napi.cc -- thin N-API shim over the C ABI of libtetsim_hip.so (include/tetsim.h).
+//
+// Host orchestration stays in Node.js (the reference's driver is main.js:74-96); this addon only marshals
+// Float32Array / Int32Array backing stores and plain numbers into the C entry points, 1:1, without copying on the
+// JS side.  It links nothing: libtetsim_hip.so is dlopen()ed next to the package (or from TETSIM_HIP_LIB), so the
+// addon also loads on hosts without ROCm -- every compute call then fails loudly (no CPU fallback).
+//
+// Build: g++ -std=c++17 -shared -fPIC -I/usr/include/node tetsim_napi.cc -o tetsim_napi.node -ldl
+#include <dlfcn.h>
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/tetsim.h"
+
+namespace {
+
+struct Api {
+    void* lib = nullptr;
+    decltype(&tetsim_default_options) default_options = nullptr;
+    decltype(&tetsim_default_params) default_params = nullptr;
+    decltype(&tetsim_create) create = nullptr;
+    decltype(&tetsim_destroy) destroy = nullptr;
+    decltype(&tetsim_last_error) last_error = nullptr;
+    decltype(&tetsim_get_info) get_info = nullptr;
+    decltype(&tetsim_step) step = nullptr;
+    decltype(&tetsim_step_n) step_n = nullptr;
+    decltype(&tetsim_sync) sync = nullptr;
+    decltype(&tetsim_read_positions) read_positions = nullptr;
+    decltype(&tetsim_read_velocities) read_velocities = nullptr;
+    decltype(&tetsim_read_quats) read_quats = nullptr;
+    decltype(&tetsim_read_vol_error) read_vol_error = nullptr;
+    decltype(&tetsim_get_local_tets) get_local_tets = nullptr;
+    decltype(&tetsim_set_grab) set_grab = nullptr;
+    decltype(&tetsim_start_grab) start_grab = nullptr;
+    decltype(&tetsim_abi_version) abi_version = nullptr;
+    std::string err;
+} g;
+
+bool load_lib(const std::string& hint) {
+    if (g.lib) return true;
+    const char* env = getenv("TETSIM_HIP_LIB");
+    std::string path = env ? env : hint;
+    g.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!g.lib) { g.err = std::string("cannot load ") + path + ": " + dlerror(); return false; }
+#define SYM(field, name) g.field = reinterpret_cast<decltype(g.field)>(dlsym(g.lib, name)); if (!g.field) { g.err = std::string("libtetsim_hip lacks ") + name; return false; }
+    SYM(default_options, "tetsim_default_options") SYM(default_params, "tetsim_default_params") SYM(create, "tetsim_create")
+    SYM(destroy, "tetsim_destroy") SYM(last_error, "tetsim_last_error") SYM(get_info, "tetsim_get_info") SYM(step, "tetsim_step")
+    SYM(step_n, "tetsim_step_n") SYM(sync, "tetsim_sync") SYM(read_positions, "tetsim_read_positions")
+    SYM(read_velocities, "tetsim_read_velocities") SYM(read_quats, "tetsim_read_quats") SYM(read_vol_error, "tetsim_read_vol_error")
+    SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
+    SYM(abi_version, "tetsim_abi_version")
+#undef SYM
+    if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
+    return true;
+}
+
+napi_value throw_err(napi_env env, const std::string& msg) {
+    napi_throw_error(env, "TETSIM", msg.c_str());
+    return nullptr;
+}
+bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) {
+        throw_err(env, "wrong number of arguments");
+        return false;
+    }
+    return true;
+}
+template <class T>
+bool typed_array(napi_env env, napi_value v, napi_typedarray_type want, T** data, size_t* len) {
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return false;
+    napi_typedarray_type type;
+    void* p = nullptr;
+    napi_value ab;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &type, len, &p, &ab, &off) != napi_ok || type != want) return false;
+    *data = static_cast<T*>(p);
+    return true;
+}
+bool get_double(napi_env env, napi_value obj, const char* key, double* out) {
+    napi_value v;
+    bool has = false;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return false;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok) return false;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_number) return false;
+    return napi_get_value_double(env, v, out) == napi_ok;
+}
+tetsim_handle handle_of(napi_env env, napi_value v) {
+    void* p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { throw_err(env, "not a tetsim handle (or already destroyed)"); return nullptr; }
+    return *static_cast<tetsim_handle*>(p);
+}
+// physicsParams object (main.js:22-36) -> TetSimParams
+void params_of(napi_env env, napi_value obj, TetSimParams* p) {
+    g.default_params(p);
+    get_double(env, obj, "gravity", &p->gravity);
+    get_double(env, obj, "friction", &p->friction);
+    get_double(env, obj, "devCompliance", &p->devCompliance);
+    get_double(env, obj, "volCompliance", &p->volCompliance);
+    napi_value wb;
+    bool has = false, isarr = false;
+    if (napi_has_named_property(env, obj, "worldBounds", &has) == napi_ok && has &&
+        napi_get_named_property(env, obj, "worldBounds", &wb) == napi_ok && napi_is_array(env, wb, &isarr) == napi_ok && isarr)
+        for (uint32_t i = 0; i < 6; i++) {
+            napi_value e;
+            if (napi_get_element(env, wb, i, &e) == napi_ok) napi_get_value_double(env, e, &p->worldBounds[i]);
+        }
+}
+napi_value check(napi_env env, int rc, tetsim_handle h) {
+    if (rc == TETSIM_OK) { napi_value u; napi_get_undefined(env, &u); return u; }
+    return throw_err(env, std::string("tetsim error ") + std::to_string(rc) + ": " + g.last_error(h));
+}
+void finalize_handle(napi_env, void* data, void*) {
+    tetsim_handle* hp = static_cast<tetsim_handle*>(data);
+    if (*hp) g.destroy(*hp);
+    delete hp;
+}
+
+// load(path) -> abi version
+napi_value Load(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    char buf[4096];
+    size_t n = 0;
+    if (napi_get_value_string_utf8(env, a[0], buf, sizeof(buf), &n) != napi_ok) return throw_err(env, "load(path): path must be a string");
+    if (!load_lib(buf)) return throw_err(env, g.err);
+    napi_value v;
+    napi_create_int32(env, g.abi_version(), &v);
+    return v;
+}
+
+// create(Float32Array verts, Int32Array tets, {solver, precision, order, flags, device, density}) -> handle
+napi_value Create(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    float* verts; int32_t* tets; size_t nvf, ntf;
+    if (!typed_array(env, a[0], napi_float32_array, &verts, &nvf)) return throw_err(env, "vertices must be a Float32Array");
+    if (!typed_array(env, a[1], napi_int32_array, &tets, &ntf)) return throw_err(env, "tetIds must be an Int32Array");
+    if (nvf % 3 || ntf % 4) return throw_err(env, "vertices need 3 floats per particle, tetIds 4 ids per tet");
+    TetSimOptions o;
+    g.default_options(&o);
+    double d;
+    if (get_double(env, a[2], "solver", &d)) o.solver = static_cast<int32_t>(d);
+    if (get_double(env, a[2], "precision", &d)) o.precision = static_cast<int32_t>(d);
+    if (get_double(env, a[2], "order", &d)) o.order = static_cast<int32_t>(d);
+    if (get_double(env, a[2], "flags", &d)) o.flags = static_cast<uint32_t>(d);
+    if (get_double(env, a[2], "device", &d)) o.device = static_cast<int32_t>(d);
+    if (get_double(env, a[2], "density", &d)) o.density = d;
+    tetsim_handle h = nullptr;
+    const int rc = g.create(verts, static_cast<uint32_t>(nvf / 3), tets, static_cast<uint32_t>(ntf / 4), &o, &h);
+    if (rc != TETSIM_OK) return check(env, rc, nullptr);
+    tetsim_handle* hp = new tetsim_handle(h);
+    napi_value ext;
+    napi_create_external(env, hp, finalize_handle, nullptr, &ext);
+    return ext;
+}
+napi_value Destroy(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    void* p = nullptr;
+    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
+        tetsim_handle* hp = static_cast<tetsim_handle*>(p);
+        if (*hp) { g.destroy(*hp); *hp = nullptr; }
+    }
+    napi_value u; napi_get_undefined(env, &u); return u;
+}
+// step(handle, dt, physicsParams)  /  stepN(handle, n, dt, physicsParams)
+napi_value Step(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    double dt; napi_get_value_double(env, a[1], &dt);
+    TetSimParams p; params_of(env, a[2], &p);
+    return check(env, g.step(h, dt, &p), h);
+}
+napi_value StepN(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    uint32_t n; napi_get_value_uint32(env, a[1], &n);
+    double dt; napi_get_value_double(env, a[2], &dt);
+    TetSimParams p; params_of(env, a[3], &p);
+    return check(env, g.step_n(h, n, dt, &p), h);
+}
+napi_value Sync(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    return h ? check(env, g.sync(h), h) : nullptr;
+}
+template <int (*Api::*Fn)(tetsim_handle, float*), int Per, bool Tets>
+napi_value ReadF32(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    float* out; size_t n;
+    if (!typed_array(env, a[1], napi_float32_array, &out, &n)) return throw_err(env, "output must be a Float32Array");
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    const size_t need = static_cast<size_t>(Per) * (Tets ? inf.local_elems : inf.owned_particles);
+    if (n < need) return throw_err(env, "output array too small");
+    return check(env, (g.*Fn)(h, out), h);
+}
+napi_value ReadVolError(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    double v = 0.0;
+    const int rc = g.read_vol_error(h, &v);
+    if (rc) return check(env, rc, h);
+    napi_value r; napi_create_double(env, v, &r); return r;
+}
+// setGrab(handle, id, x, y, z)
+napi_value SetGrab(napi_env env, napi_callback_info info) {
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    int32_t id; napi_get_value_int32(env, a[1], &id);
+    double x, y, z; napi_get_value_double(env, a[2], &x); napi_get_value_double(env, a[3], &y); napi_get_value_double(env, a[4], &z);
+    const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
+    return check(env, g.set_grab(h, id, p), h);
+}
+// startGrab(handle, x, y, z) -> particle id
+napi_value StartGrab(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    double x, y, z; napi_get_value_double(env, a[1], &x); napi_get_value_double(env, a[2], &y); napi_get_value_double(env, a[3], &z);
+    const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
+    int32_t id = -1;
+    const int rc = g.start_grab(h, p, &id);
+    if (rc) return check(env, rc, h);
+    napi_value r; napi_create_int32(env, id, &r); return r;
+}
+napi_value Info(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    TetSimInfo inf;
+    const int rc = g.get_info(h, &inf);
+    if (rc) return check(env, rc, h);
+    napi_value o; napi_create_object(env, &o);
+    auto set = [&](const char* k, double v) { napi_value x; napi_create_double(env, v, &x); napi_set_named_property(env, o, k, x); };
+    set("numParticles", inf.num_particles); set("numElems", inf.num_elems); set("ownedParticles", inf.owned_particles);
+    set("localElems", inf.local_elems); set("numLevels", inf.num_levels); set("maxValence", inf.max_valence);
+    set("droppedSlots", inf.dropped_slots); set("deviceBytes", static_cast<double>(inf.device_bytes));
+    set("solver", inf.solver); set("precision", inf.precision);
+    return o;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+    const napi_property_descriptor props[] = {
+        {"load", nullptr, Load, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"stepN", nullptr, StepN, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"sync", nullptr, Sync, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readPositions", nullptr, ReadF32<&Api::read_positions, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readVelocities", nullptr, ReadF32<&Api::read_velocities, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readQuats", nullptr, ReadF32<&Api::read_quats, 4, true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"startGrab", nullptr, StartGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"info", nullptr, Info, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

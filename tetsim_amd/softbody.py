@@ -219,6 +219,15 @@ class SoftBodyHIP:
         return dict(total_ms=pr.total_ms, tet_ms=pr.kernel_ms[capi.K_TET], vertex_ms=pr.kernel_ms[capi.K_VERTEX],
                     tet_launches=pr.launches[capi.K_TET], vertex_launches=pr.launches[capi.K_VERTEX], substeps=pr.substeps)
 
+    def timeKernels(self, reps, dt, physicsParams=None):
+        """Kernel-only timing (back-to-back launches, one event pair per kernel class).  Scratch bodies only."""
+        pp = self.physicsParams if physicsParams is None else physicsParams
+        pr = capi.TetSimProfile()
+        capi.check(self._L.tetsim_time_kernels(self._h, int(reps), float(dt), C.byref(make_params(pp)), C.byref(pr)), self._h)
+        return dict(tet_us=pr.kernel_ms[capi.K_TET] / pr.launches[capi.K_TET] * 1e3,
+                    vertex_us=pr.kernel_ms[capi.K_VERTEX] / pr.launches[capi.K_VERTEX] * 1e3,
+                    tet_launches_per_substep=pr.launches[capi.K_TET] // reps)
+
     def timeSubsteps(self, n, dt, physicsParams=None):
         pp = self.physicsParams if physicsParams is None else physicsParams
         ms = C.c_double()
