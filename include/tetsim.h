@@ -196,7 +196,8 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t *id_out);
 
 /* --- measurement ----------------------------------------------------------------------------- */
 
-/* Run n substeps eagerly with HIP events around every kernel on the handle's own stream. */
+/* Run n substeps eagerly on the handle's own stream; every POLAR_JACOBI kernel carries its own begin/end HIP
+ * events (hipExtLaunchKernelGGL), so kernel_ms[] sums the kernels' own durations in the real launch sequence. */
 int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, TetSimProfile *out);
 /* Kernel-only timing: `reps` back-to-back launches of the per-tet kernel(s) of one substep inside ONE HIP-event
  * pair on the handle's stream, then the same for the per-particle kernel(s); kernel_ms[] = total / reps.  No event

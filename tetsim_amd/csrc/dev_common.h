@@ -1,5 +1,6 @@
 // dev_common.h -- structures shared between the C-ABI host code and the gfx950 kernels.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -81,15 +82,17 @@ struct NHDev {
 };
 
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
-void pj_launch_tet_precise(hipStream_t s, const PJDev& d);
-void pj_launch_tet_fast(hipStream_t s, const PJDev& d);
-void pj_launch_vertex_precise(hipStream_t s, const PJDev& d, uint32_t first, uint32_t count);
-void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32_t count);
+// e0/e1 (optional): HIP events that timestamp the kernel's own begin and end (hipExtLaunchKernelGGL), for
+// tetsim_profile; normal launches pass none.
+void pj_launch_tet_precise(hipStream_t s, const PJDev& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_launch_tet_fast(hipStream_t s, const PJDev& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_launch_vertex_precise(hipStream_t s, const PJDev& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_launch_repredict_precise(hipStream_t s, const PJDev& d);
 void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
 
-void pjb_launch_tet(hipStream_t s, const PJBlk& d);
-void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count);
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);

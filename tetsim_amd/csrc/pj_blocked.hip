@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 
 }  // namespace
 
-void pjb_launch_tet(hipStream_t s, const PJBlk& d) {
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;
     const uint32_t per_xcd = (d.nb + 7u) / 8u;
     static int dbg = -1;
@@ -219,11 +219,13 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d) {
         const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
         dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0);
     }
-    hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, per_xcd, static_cast<uint32_t>(dbg));
+    if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, per_xcd, static_cast<uint32_t>(dbg));
+    else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, per_xcd, static_cast<uint32_t>(dbg));
 }
-void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count) {
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
     if (count == 0) return;
-    hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, d, first, count);
+    if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, e0, e1, 0, d, first, count);
+    else hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, d, first, count);
 }
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d) {
     if (d.nv_owned == 0) return;

@@ -193,13 +193,13 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
 }
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
-void pj_tet(tetsim_body* h) {
-    if (h->blocked) pjb_launch_tet(h->stream, h->blk);
-    else h->fast ? pj_launch_tet_fast(h->stream, h->pj) : pj_launch_tet_precise(h->stream, h->pj);
+void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (h->blocked) pjb_launch_tet(h->stream, h->blk, e0, e1);
+    else h->fast ? pj_launch_tet_fast(h->stream, h->pj, e0, e1) : pj_launch_tet_precise(h->stream, h->pj, e0, e1);
 }
-void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count) {
-    if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count);
-    else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count) : pj_launch_vertex_precise(h->stream, h->pj, first, count);
+void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
+    else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count, e0, e1) : pj_launch_vertex_precise(h->stream, h->pj, first, count, e0, e1);
 }
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
@@ -861,40 +861,50 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
-    std::vector<hipEvent_t> ev(3ull * n + 1);
+    // POLAR_JACOBI: every kernel carries its own begin/end events (hipExtLaunchKernelGGL), so kernel_ms is the sum of
+    // the kernels' OWN durations inside the real tet -> particle -> tet ... sequence (what rocprofv3 reports), not the
+    // spacing of event markers.  NEOHOOKEAN_GS: one span per kernel class (hundreds of tiny level launches).
+    std::vector<hipEvent_t> ev(4ull * n + 2);
     for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
-    HIPCHK(h, hipEventRecord(ev[0], h->stream));
+    hipEvent_t first_ev = ev[4ull * n], last_ev = ev[4ull * n + 1];
+    HIPCHK(h, hipEventRecord(first_ev, h->stream));
     for (uint32_t i = 0; i < n; i++) {
         if (pjs) {
-            pj_tet(h);
-            HIPCHK(h, hipEventRecord(ev[3 * i + 1], h->stream));
-            pj_vertex(h, 0, h->pj.nv_owned);
-            HIPCHK(h, hipEventRecord(ev[3 * i + 2], h->stream));
-            HIPCHK(h, hipEventRecord(ev[3 * i + 3], h->stream));
+            pj_tet(h, ev[4 * i], ev[4 * i + 1]);
+            pj_vertex(h, 0, h->pj.nv_owned, ev[4 * i + 2], ev[4 * i + 3]);
         } else {
+            HIPCHK(h, hipEventRecord(ev[4 * i], h->stream));
             h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
-            HIPCHK(h, hipEventRecord(ev[3 * i + 1], h->stream));
+            HIPCHK(h, hipEventRecord(ev[4 * i + 1], h->stream));
             for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
                 const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
                 h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
             }
-            HIPCHK(h, hipEventRecord(ev[3 * i + 2], h->stream));
+            HIPCHK(h, hipEventRecord(ev[4 * i + 2], h->stream));
             h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
-            HIPCHK(h, hipEventRecord(ev[3 * i + 3], h->stream));
+            HIPCHK(h, hipEventRecord(ev[4 * i + 3], h->stream));
         }
     }
+    HIPCHK(h, hipEventRecord(last_ev, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.0f;
     for (uint32_t i = 0; i < n; i++) {
         float a = 0, b = 0, c = 0;
-        HIPCHK(h, hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
-        HIPCHK(h, hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
-        HIPCHK(h, hipEventElapsedTime(&c, ev[3 * i + 2], ev[3 * i + 3]));
-        if (pjs) { out->kernel_ms[TETSIM_K_TET] += a; out->kernel_ms[TETSIM_K_VERTEX] += b; out->launches[TETSIM_K_TET]++; out->launches[TETSIM_K_VERTEX]++; }
-        else { out->kernel_ms[TETSIM_K_VERTEX] += a + c; out->kernel_ms[TETSIM_K_TET] += b; out->launches[TETSIM_K_VERTEX] += 2; out->launches[TETSIM_K_TET] += static_cast<uint32_t>(h->level_off.size() - 1); }
+        if (pjs) {
+            HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
+            HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
+            out->kernel_ms[TETSIM_K_TET] += a; out->kernel_ms[TETSIM_K_VERTEX] += b;
+            out->launches[TETSIM_K_TET]++; out->launches[TETSIM_K_VERTEX]++;
+        } else {
+            HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
+            HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 1], ev[4 * i + 2]));
+            HIPCHK(h, hipEventElapsedTime(&c, ev[4 * i + 2], ev[4 * i + 3]));
+            out->kernel_ms[TETSIM_K_VERTEX] += a + c; out->kernel_ms[TETSIM_K_TET] += b;
+            out->launches[TETSIM_K_VERTEX] += 2; out->launches[TETSIM_K_TET] += static_cast<uint32_t>(h->level_off.size() - 1);
+        }
     }
-    HIPCHK(h, hipEventElapsedTime(&ms, ev[0], ev[3ull * n]));
+    HIPCHK(h, hipEventElapsedTime(&ms, first_ev, last_ev));
     out->total_ms = ms;
     out->substeps = n;
     for (auto& e : ev) (void)hipEventDestroy(e);
