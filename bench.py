@@ -112,8 +112,6 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from tetsim_amd import SoftBodyHIP, make_lattice, measure_copy_bandwidth
-    from tetsim_amd import _capi as capi
-    import ctypes as C
 
     # ---- workload ------------------------------------------------------------------------------------
     nz = CELLS * world
@@ -123,19 +121,20 @@ def main():
     if world > 1:
         plane = (CELLS + 1) * (CELLS + 1)
         owner = np.minimum((np.arange(len(verts)) // plane) // CELLS, world - 1).astype(np.int32)
-        kw = dict(part_count=world, part_index=rank, vert_owner=owner)
+        # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
+        # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
+        PP["worldBounds"] = [-2.5, -1.0, -(0.5 * world + 2.0), 2.5, 10.0, 0.5 * world + 2.0]
+        kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
     body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
                        device=local_rank, **kw)
     if world > 1:
         import torch
+        from tetsim_amd import comm_init, comm_unique_id
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
-            buf = (C.c_char * 128)()
-            capi.check(capi.lib().tetsim_comm_unique_id(buf))
-            uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+            uid.copy_(torch.tensor(list(comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
-        raw = bytes(uid.cpu().numpy().tobytes())
-        capi.check(capi.lib().tetsim_comm_init(body._h, raw, rank, world), body._h)
+        comm_init(body, bytes(uid.cpu().tolist()), rank, world)
 
     def barrier():
         body.sync()

@@ -218,6 +218,9 @@ int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps,
  * partitions every substep (grouped ncclSend/ncclRecv on a dedicated stream). */
 int tetsim_comm_unique_id(void *id128);
 int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t nranks);
+/* Send 1 KiB to this handle's own rank and receive it back through the initialised communicator, on the halo
+ * stream, and verify the bytes: exercises the run-time-resolved RCCL entry points on hosts with a single GPU. */
+int tetsim_comm_selftest(tetsim_handle h);
 /* In-process transport for partitions living on one device (tests; "multi-GPU without a cluster"):
  * after every handle has been stepped ONE substep, copy owned interface positions into the
  * neighbours' ghost ranges.  handles[i] must be partition i of the same mesh. */

@@ -186,6 +186,18 @@ def test_partition_irregular_mesh():
         assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
 
 
+def test_rccl_transport_selftest():
+    """The RCCL entry points are resolved with dlopen at run time; a 1-rank communicator + a send/recv to self on
+    the halo stream proves they work on this host (real multi-rank halos need >1 GPU: driver's scaling run)."""
+    from tetsim_amd import comm_init, comm_selftest, comm_unique_id
+    v, t = make_lattice(3)
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    comm_init(body, comm_unique_id(), 0, 1)
+    comm_selftest(body)
+    body.simulateSubsteps(5, DT20, PP)
+    assert np.isfinite(body.pos).all()
+
+
 def test_lattice_1m_properties():
     """BASELINE config 3 at full size: size-independent properties instead of a CPU run."""
     v, t = make_lattice(55)

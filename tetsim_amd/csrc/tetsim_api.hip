@@ -1027,6 +1027,35 @@ int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t n
     return 0;
 }
 
+int tetsim_comm_selftest(tetsim_handle h) {
+    if (!h) return TETSIM_EINVAL;
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    constexpr size_t kN = 256;  // floats
+    float *src = nullptr, *dst = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), kN * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), kN * sizeof(float)));
+    std::vector<float> host(kN), back(kN, 0.0f);
+    for (size_t i = 0; i < kN; i++) host[i] = static_cast<float>(i) * 0.5f + static_cast<float>(h->comm_rank);
+    int rc = TETSIM_OK;
+    if (hipMemcpy(src, host.data(), kN * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(dst, 0, kN * sizeof(float)) != hipSuccess) rc = fail(h, TETSIM_EHIP, "selftest upload failed");
+    if (!rc) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(src, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) rc = rccl_fail(h, r, "selftest send/recv");
+    }
+    if (!rc && (hipStreamSynchronize(h->comm_stream) != hipSuccess ||
+                hipMemcpy(back.data(), dst, kN * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(h, TETSIM_EHIP, "selftest download failed");
+    if (!rc && back != host) rc = fail(h, TETSIM_ECOMM, "selftest: received bytes differ from the bytes sent");
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}
+
 int tetsim_get_halo_plan(tetsim_handle h, int32_t* neigh, int32_t* send_counts, int32_t* recv_counts, int32_t* send_ids, int32_t* recv_ids) {
     if (!h) return TETSIM_EINVAL;
     size_t so = 0, ro = 0;

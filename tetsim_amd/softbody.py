@@ -235,6 +235,21 @@ class SoftBodyHIP:
         return ms.value
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it; the host distributes it to every rank)."""
+    buf = (C.c_char * 128)()
+    capi.check(capi.lib().tetsim_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def comm_init(body, uid, rank, nranks):
+    capi.check(capi.lib().tetsim_comm_init(body._h, bytes(uid), int(rank), int(nranks)), body._h)
+
+
+def comm_selftest(body):
+    capi.check(capi.lib().tetsim_comm_selftest(body._h), body._h)
+
+
 def measure_copy_bandwidth(nbytes, reps=20, device=0):
     g = C.c_double()
     capi.check(capi.lib().tetsim_measure_copy_bandwidth(device, int(nbytes), int(reps), C.byref(g)))
