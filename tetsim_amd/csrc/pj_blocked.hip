@@ -155,8 +155,10 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tiles
 #undef TETSIM_STAMP
 }
 
-__global__ __launch_bounds__(256) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+// 64-thread workgroups: 175,616 particles are only 2,744 waves (2.7 per SIMD); one-wave workgroups spread over the
+// 256 CUs evenly (10.7 per CU) where 256-thread ones leave some CUs with 3 and others with 2.
+__global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = first + i;
     const DevParams& P = *d.params;
@@ -224,8 +226,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1)
 }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
     if (count == 0) return;
-    if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, e0, e1, 0, d, first, count);
-    else hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, d, first, count);
+    if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count);
+    else hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count);
 }
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d) {
     if (d.nv_owned == 0) return;
