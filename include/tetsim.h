@@ -186,6 +186,18 @@ int tetsim_get_level_offsets(tetsim_handle h, int32_t *out);
 /* rest data as the reference computes it (Softbody.js:60-87): invMass [nv] */
 int tetsim_read_inv_mass(tetsim_handle h, float *out);
 
+/* --- embedded visual mesh --------------------------------------------------------- */
+
+/* Attach the embedded visual mesh: vis_verts = [4*nvis] rows (tetNr, b0, b1, b2) exactly as the reference's
+ * `visVerts` (Dragon.js:1705; Softbody.js:46,263-267).  rest_normals = [3*nvis] object-space normals or NULL.
+ * Unpartitioned bodies only. */
+int tetsim_set_visual_mesh(tetsim_handle h, const float *vis_verts, uint32_t nvis, const float *rest_normals);
+/* Skin on the device and read back.  positions_out [3*nvis]: sum_k b_k * pos[tet corner k] with b3 = 1-b0-b1-b2,
+ * evaluated like updateVisMesh (Softbody.js:259-277: f64 accumulate, f32 store per step; NEOHOOKEAN_GS + PRECISE is
+ * bit-exact with it) or like the vertex shader of SoftbodyGPU.js:429-435 (POLAR_JACOBI, f32).
+ * normals_out [3*nvis] (may be NULL): Rotate(rest_normal, quat[tetNr]) as SoftbodyGPU.js:440 -- POLAR_JACOBI only. */
+int tetsim_read_visual_mesh(tetsim_handle h, float *positions_out, float *normals_out);
+
 /* --- grab (Softbody.js:279-298 ; SoftbodyGPU.js:692-712) --------------------------------------- */
 
 /* Pin global particle `id` (-1 = none, endGrab) at xyz: consumed by the next substeps

@@ -65,6 +65,18 @@ async function main() {
         golden.cases[c.name] = out;
         console.log(c.name, JSON.stringify(out.steps[Object.keys(out.steps).pop()]));
     }
+    // Embedded visual mesh (row (f)-1): the reference's updateVisMesh (Softbody.js:259-277) on the Dragon after 10 substeps.
+    {
+        const pp = Object.assign({ timeScale: 1.0, timeStep: 1.0 / 60.0, numSubsteps: 10 }, cases[0].params);
+        const body = new SoftBody(D.dragonTetVerts.slice(0), D.dragonTetIds, [], pp, D.dragonAttachedVerts, D.dragonAttachedTriIds, null);
+        const dt = (pp.timeScale * pp.timeStep) / pp.numSubsteps;
+        for (let i = 0; i < 10; i++) body.simulate(dt, pp);
+        body.endFrame();
+        const vis = body.visMesh.geometry.attributes.position.array;
+        writeF32('dragon_vispos_10.f32', vis);
+        golden.vis = { dragon_vispos_10: sha(vis), numVisVerts: body.numVisVerts };
+        console.log('vis', golden.vis);
+    }
     fs.writeFileSync(path.join(outDir, 'golden.json'), JSON.stringify(golden, null, 1));
 }
 main().catch(e => { console.error(e); process.exit(1); });

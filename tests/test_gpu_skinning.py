@@ -1,0 +1,57 @@
+"""Row (f)-1: embedded visual-mesh skinning on the device vs the reference's updateVisMesh (Softbody.js:259-277)."""
+import numpy as np
+import pytest
+
+from conftest import load_f32, load_mesh, sha16
+from oracle import OraclePJ
+from tetsim_amd import SoftBodyHIP
+
+pytestmark = pytest.mark.gpu
+PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
+          worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+
+
+def test_neohookean_skinning_bit_exact_vs_reference(golden):
+    """29,800 embedded vertices of the Dragon after 10 substeps: bit-identical to the reference's visMesh positions."""
+    v, t = load_mesh("dragon")
+    vis = load_f32("dragon_vis.f32").reshape(-1, 4)
+    body = SoftBodyHIP(v, t, None, dict(PP), vis, solver="neohookean", precision="precise")
+    assert body.numVisVerts == 29800
+    dt = (1.0 * (1.0 / 60.0)) / 10
+    for _ in range(10):
+        body.simulate(dt, PP)
+    got = body.visualPositions()
+    ref = load_f32("dragon_vispos_10.f32").reshape(-1, 3)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert sha16(got) == "8df79c236ba69d61"
+
+
+@pytest.mark.parametrize("precision", ["precise", "fast"])
+def test_polar_skinning_and_normals(precision):
+    """Vertex-shader formula of SoftbodyGPU.js:429-440 evaluated on the device: positions from the (internally
+    renumbered) particles, normals rotated by the quaternion of the vertex's tet (tile-ordered in FAST)."""
+    v, t = load_mesh("dragon")
+    vis = load_f32("dragon_vis.f32").reshape(-1, 4)
+    rng = np.random.default_rng(7)
+    n0 = rng.standard_normal((len(vis), 3)).astype(np.float32)
+    n0 /= np.linalg.norm(n0, axis=1, keepdims=True)
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision)
+    body.setVisualMesh(vis, n0)
+    orc = OraclePJ(v, t, PP)
+    dt = (1.0 / 60.0) / 20
+    for _ in range(40):
+        body.simulate(dt, PP)
+        orc.simulate(dt, PP)
+    pos, nrm = body.visualPositions(with_normals=True)
+    p, q = orc.pos, orc.quats
+    tn = vis[:, 0].astype(np.int64)
+    b = vis[:, 1:4]
+    b3 = np.float32(1.0) - ((b[:, 0] + b[:, 1]) + b[:, 2])
+    c = t[tn]
+    ref = ((p[c[:, 0]] * b[:, :1] + p[c[:, 1]] * b[:, 1:2]) + p[c[:, 2]] * b[:, 2:3]) + p[c[:, 3]] * b3[:, None]
+    assert np.abs(pos - ref).max() < (1e-6 if precision == "precise" else 1e-4)
+    qq = q[tn]
+    qv, w = qq[:, :3], qq[:, 3:]
+    refn = n0 + 2.0 * np.cross(qv, np.cross(qv, n0) + w * n0)
+    assert np.abs(nrm - refn).max() < (1e-5 if precision == "precise" else 1e-3)
+    assert np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-4

@@ -31,6 +31,7 @@ UNITS = {
     "nh_precise.hip": ["-ffp-contract=off"],
     "nh_fast.hip": ["-ffp-contract=fast"],
     "util_kernels.hip": [],
+    "skin_kernels.hip": ["-ffp-contract=off"],
 }
 HEADERS = ["dev_common.h", "host_prep.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
 

@@ -102,6 +102,19 @@ void nh_launch_level_fast(hipStream_t s, const NHDev& d, uint32_t first, uint32_
 void nh_launch_post_precise(hipStream_t s, const NHDev& d);
 void nh_launch_post_fast(hipStream_t s, const NHDev& d);
 
+// embedded visual mesh skinning (skin_kernels.hip)
+struct SkinDev {
+    uint32_t nvis = 0;
+    const int4* corner = nullptr;    // device particle index of the 4 tet corners of each visual vertex
+    const float4* weight = nullptr;  // b0, b1, b2, (unused)
+    const int32_t* qidx = nullptr;   // device tet position (quaternion index), polar only
+    const float4* normal0 = nullptr; // rest normals (may be null)
+    float4* out_pos = nullptr;
+    float4* out_nrm = nullptr;
+};
+// js_order: Softbody.js:259-277 arithmetic (f64 accumulate, f32 store per step); else SoftbodyGPU.js:431-435 (f32)
+void skin_launch(hipStream_t s, const SkinDev& d, const float4* pos, const float4* quat, bool js_order);
+
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n);
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 

@@ -108,6 +108,8 @@ struct tetsim_body {
     ncclComm_t comm = nullptr;
     int comm_rank = -1, comm_size = 0;
 
+    SkinDev skin;  // embedded visual mesh
+
     // NEOHOOKEAN_GS
     NHDev nh;
     std::vector<uint32_t> level_off;
@@ -821,6 +823,75 @@ int tetsim_read_inv_mass(tetsim_handle h, float* out) {
     const uint32_t nv = h->info.num_particles, nt = h->info.num_elems;
     std::vector<float> irp(9ull * nt), irv(nt);
     prep_rest(h->h_verts.data(), nv, h->h_tets.data(), nt, h->opt.density, out, irp.data(), irv.data());
+    return 0;
+}
+
+int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvis, const float* rest_normals) {
+    if (!h || (nvis && !vis_verts)) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->partitioned) return fail(h, TETSIM_ESTATE, "visual meshes are supported on unpartitioned bodies only");
+    if (h->skin.nvis) return fail(h, TETSIM_ESTATE, "a visual mesh is already attached");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    const uint32_t nt = h->info.num_elems;
+    std::vector<int32_t> tet_pos;  // caller's tet id -> device tet position (quaternion index)
+    if (pjs) {
+        tet_pos.resize(nt);
+        for (uint32_t i = 0; i < nt; i++) tet_pos[h->blocked ? h->tet_perm[i] : i] = static_cast<int32_t>(i);
+    }
+    std::vector<int4> corner(nvis);
+    std::vector<float4> weight(nvis), n0(nvis);
+    std::vector<int32_t> qidx(nvis, 0);
+    for (uint32_t i = 0; i < nvis; i++) {
+        const float tn = vis_verts[4 * i];
+        if (!(tn >= 0.0f) || tn >= static_cast<float>(nt) || tn != std::floor(tn)) return fail(h, TETSIM_EINVAL, "visual vertex " + std::to_string(i) + " references a tet outside the mesh");
+        const uint32_t e = static_cast<uint32_t>(tn);
+        int32_t c[4];
+        for (int k = 0; k < 4; k++) {
+            const int32_t v = h->h_tets[4 * e + k];
+            c[k] = (pjs && !h->api2dev.empty()) ? static_cast<int32_t>(h->api2dev[v]) : v;
+        }
+        corner[i] = make_int4(c[0], c[1], c[2], c[3]);
+        weight[i] = make_float4(vis_verts[4 * i + 1], vis_verts[4 * i + 2], vis_verts[4 * i + 3], 0.0f);
+        if (pjs) qidx[i] = tet_pos[e];
+        if (rest_normals) n0[i] = make_float4(rest_normals[3 * i], rest_normals[3 * i + 1], rest_normals[3 * i + 2], 0.0f);
+    }
+    SkinDev& k = h->skin;
+    int4* dc; float4 *dw, *dn = nullptr; int32_t* dq;
+    int rc;
+    if ((rc = dev_alloc(h, &dc, nvis))) return rc;
+    if ((rc = dev_alloc(h, &dw, nvis))) return rc;
+    if ((rc = dev_alloc(h, &dq, nvis))) return rc;
+    if ((rc = dev_alloc(h, &k.out_pos, nvis))) return rc;
+    if ((rc = upload(h, dc, corner))) return rc;
+    if ((rc = upload(h, dw, weight))) return rc;
+    if ((rc = upload(h, dq, qidx))) return rc;
+    if (rest_normals && pjs) {
+        if ((rc = dev_alloc(h, &dn, nvis))) return rc;
+        if ((rc = dev_alloc(h, &k.out_nrm, nvis))) return rc;
+        if ((rc = upload(h, dn, n0))) return rc;
+    }
+    k.corner = dc; k.weight = dw; k.qidx = dq; k.normal0 = dn;
+    k.nvis = nvis;
+    return 0;
+}
+
+int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normals_out) {
+    if (!h || !positions_out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->skin.nvis) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    if (normals_out && !h->skin.out_nrm) return fail(h, TETSIM_ESTATE, "normals need POLAR_JACOBI and rest normals at tetsim_set_visual_mesh");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    // Softbody.js arithmetic for the solver that mirrors Softbody.js, the vertex-shader arithmetic for the other
+    skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t n = h->skin.nvis;
+    std::vector<float4> tmp(n);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->skin.out_pos, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { positions_out[3 * i] = tmp[i].x; positions_out[3 * i + 1] = tmp[i].y; positions_out[3 * i + 2] = tmp[i].z; }
+    if (normals_out) {
+        HIPCHK(h, hipMemcpy(tmp.data(), h->skin.out_nrm, n * sizeof(float4), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) { normals_out[3 * i] = tmp[i].x; normals_out[3 * i + 1] = tmp[i].y; normals_out[3 * i + 2] = tmp[i].z; }
+    }
     return 0;
 }
 

@@ -49,6 +49,7 @@ class SoftBodyHIP {
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
         });
         this._dirty = false;
+        this._visOnDevice = false;
 
         // display objects (Softbody.js:36-57 / SoftbodyGPU.js:415-461), only when three.js was injected
         const THREE = (world && world.THREE) || SoftBodyHIP.THREE || null;
@@ -56,6 +57,10 @@ class SoftBodyHIP {
         this.visMesh = null;
         this.visVerts = visVerts || new Float32Array(0);
         this.numVisVerts = this.visVerts.length / 4;
+        if (this.numVisVerts > 0) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1)
+            api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
+            this._visOnDevice = true;
+        }
         if (THREE) {
             let geometry = new THREE.BufferGeometry();
             // the reference aliases the caller's `vertices` array here and overwrites it every frame (Softbody.js:37,252)
@@ -107,17 +112,18 @@ class SoftBodyHIP {
         this.edgeMesh.geometry.attributes.position.needsUpdate = true;
         this.edgeMesh.geometry.computeBoundingSphere();
     }
-    updateVisMesh() {                                   // Softbody.js:259-277: barycentric skinning of the embedded mesh
-        const positions = this.visMesh.geometry.attributes.position.array;
-        const vv = this.visVerts, p = this.pos, t = this.tetIds;
-        for (let i = 0, nr = 0; i < this.numVisVerts; i++) {
-            const tetNr = vv[nr++] * 4, b0 = vv[nr++], b1 = vv[nr++], b2 = vv[nr++], b3 = 1.0 - b0 - b1 - b2;
-            const i0 = 3 * t[tetNr], i1 = 3 * t[tetNr + 1], i2 = 3 * t[tetNr + 2], i3 = 3 * t[tetNr + 3];
-            for (let c = 0; c < 3; c++) positions[3 * i + c] = p[i0 + c] * b0 + p[i1 + c] * b1 + p[i2 + c] * b2 + p[i3 + c] * b3;
-        }
+    updateVisMesh() {                                   // Softbody.js:259-277: barycentric skinning of the embedded mesh,
+        const positions = this.visMesh.geometry.attributes.position.array;   // done by the device kernel
+        this.readVisualPositions(positions);
         if (this.physicsParams.computeNormals !== false) this.visMesh.geometry.computeVertexNormals();
         this.visMesh.geometry.attributes.position.needsUpdate = true;
         this.visMesh.geometry.computeBoundingSphere();
+    }
+
+    readVisualPositions(out) {                          // Float32Array [3*numVisVerts], skinned on the GPU
+        out = out || new Float32Array(3 * this.numVisVerts);
+        if (this._visOnDevice) this._api.readVisualMesh(this._h, out, null);
+        return out;
     }
 
     // ---- grab (Softbody.js:279-298) ------------------------------------------------------------------------------

@@ -30,6 +30,13 @@ for (let step = 1; step <= 100; step++) {
 }
 const golden = JSON.parse(fs.readFileSync(path.join(G, 'golden.json'))).cases.dragon.steps['100'];
 assert.strictEqual(body.volError, golden.volError);
+// embedded visual mesh: device skinning == the reference's updateVisMesh output (29,800 vertices, after 10 substeps)
+{
+    const b2 = new SoftBodyHIP(verts.slice(0), tets, [], pp, f32('dragon_vis.f32'), [], null);
+    for (let step = 0; step < 10; step++) b2.simulate(dt, pp);
+    assert.strictEqual(bitsEqual(b2.readVisualPositions(), f32('dragon_vispos_10.f32')), -1, 'visual mesh differs from updateVisMesh');
+    b2.dispose();
+}
 body.dispose();
 console.log('neohookean/precise: bit-exact vs Softbody.js goldens at substeps 1, 10, 100 (volError', golden.volError + ')');
 

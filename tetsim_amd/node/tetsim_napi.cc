@@ -33,6 +33,8 @@ struct Api {
     decltype(&tetsim_read_quats) read_quats = nullptr;
     decltype(&tetsim_read_vol_error) read_vol_error = nullptr;
     decltype(&tetsim_get_local_tets) get_local_tets = nullptr;
+    decltype(&tetsim_set_visual_mesh) set_visual_mesh = nullptr;
+    decltype(&tetsim_read_visual_mesh) read_visual_mesh = nullptr;
     decltype(&tetsim_set_grab) set_grab = nullptr;
     decltype(&tetsim_start_grab) start_grab = nullptr;
     decltype(&tetsim_abi_version) abi_version = nullptr;
@@ -51,6 +53,7 @@ bool load_lib(const std::string& hint) {
     SYM(step_n, "tetsim_step_n") SYM(sync, "tetsim_sync") SYM(read_positions, "tetsim_read_positions")
     SYM(read_velocities, "tetsim_read_velocities") SYM(read_quats, "tetsim_read_quats") SYM(read_vol_error, "tetsim_read_vol_error")
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
+    SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(abi_version, "tetsim_abi_version")
 #undef SYM
     if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
@@ -220,6 +223,28 @@ napi_value ReadVolError(napi_env env, napi_callback_info info) {
     if (rc) return check(env, rc, h);
     napi_value r; napi_create_double(env, v, &r); return r;
 }
+// setVisualMesh(handle, Float32Array visVerts [tetNr,b0,b1,b2]*, Float32Array restNormals | null)
+napi_value SetVisualMesh(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    float *vv, *nn = nullptr; size_t nv4, nn3 = 0;
+    if (!typed_array(env, a[1], napi_float32_array, &vv, &nv4) || nv4 % 4) return throw_err(env, "visVerts must be a Float32Array of (tetNr,b0,b1,b2) rows");
+    if (typed_array(env, a[2], napi_float32_array, &nn, &nn3) && nn3 != nv4 / 4 * 3) return throw_err(env, "restNormals must hold 3 floats per visual vertex");
+    return check(env, g.set_visual_mesh(h, vv, static_cast<uint32_t>(nv4 / 4), nn3 ? nn : nullptr), h);
+}
+// readVisualMesh(handle, Float32Array positionsOut, Float32Array normalsOut | null)
+napi_value ReadVisualMesh(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    float *po, *no = nullptr; size_t np = 0, nn = 0;
+    if (!typed_array(env, a[1], napi_float32_array, &po, &np)) return throw_err(env, "positions output must be a Float32Array");
+    typed_array(env, a[2], napi_float32_array, &no, &nn);
+    return check(env, g.read_visual_mesh(h, po, nn ? no : nullptr), h);
+}
 // setGrab(handle, id, x, y, z)
 napi_value SetGrab(napi_env env, napi_callback_info info) {
     napi_value a[5];
@@ -273,6 +298,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"readVelocities", nullptr, ReadF32<&Api::read_velocities, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readQuats", nullptr, ReadF32<&Api::read_quats, 4, true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"startGrab", nullptr, StartGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"info", nullptr, Info, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

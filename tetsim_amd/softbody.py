@@ -91,6 +91,9 @@ class SoftBodyHIP:
         self.info = capi.TetSimInfo()
         capi.check(L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
         self._L = L
+        self.numVisVerts = 0
+        if visVerts is not None and len(visVerts):   # Softbody.js:46-47: rows (tetNr, b0, b1, b2)
+            self.setVisualMesh(visVerts)
 
     # -- lifecycle ------------------------------------------------------------------------------------
     def close(self):
@@ -187,6 +190,20 @@ class SoftBodyHIP:
     def writeState(self, pos, vel):
         p, v = _f32(pos).reshape(-1), _f32(vel).reshape(-1)
         capi.check(self._L.tetsim_write_state(self._h, _fp(p), _fp(v)), self._h)
+
+    # -- embedded visual mesh (Softbody.js:259-277 / SoftbodyGPU.js:424-448), skinned on the device ---------------
+    def setVisualMesh(self, visVerts, restNormals=None):
+        vv = _f32(visVerts).reshape(-1)
+        self.numVisVerts = vv.size // 4
+        n0 = None if restNormals is None else _f32(restNormals).reshape(-1)
+        capi.check(self._L.tetsim_set_visual_mesh(self._h, _fp(vv), self.numVisVerts, _fp(n0) if n0 is not None else None), self._h)
+        self._has_normals = n0 is not None
+
+    def visualPositions(self, with_normals=False):
+        out = np.empty(3 * self.numVisVerts, dtype=np.float32)
+        nrm = np.empty(3 * self.numVisVerts, dtype=np.float32) if with_normals else None
+        capi.check(self._L.tetsim_read_visual_mesh(self._h, _fp(out), _fp(nrm) if with_normals else None), self._h)
+        return (out.reshape(-1, 3), nrm.reshape(-1, 3)) if with_normals else out.reshape(-1, 3)
 
     # -- grab (Softbody.js:279-298) -------------------------------------------------------------------
     def startGrab(self, pos):
