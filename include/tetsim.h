@@ -233,6 +233,11 @@ int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t n
 /* Send 1 KiB to this handle's own rank and receive it back through the initialised communicator, on the halo
  * stream, and verify the bytes: exercises the run-time-resolved RCCL entry points on hosts with a single GPU. */
 int tetsim_comm_selftest(tetsim_handle h);
+/* All partitions of one decomposition living in ONE process (one or several devices): n substeps with the SAME
+ * stream/event choreography as the RCCL path -- interior tiles, wait for the previous halo, boundary tiles, boundary
+ * particles, start the halo on a second stream, interior particles -- with asynchronous device copies standing in
+ * for ncclSend/ncclRecv.  handles[i] must be partition i.  Asynchronous; reads synchronise. */
+int tetsim_group_step_n(tetsim_handle *handles, uint32_t count, uint32_t n, double dt, const TetSimParams *params);
 /* In-process transport for partitions living on one device (tests; "multi-GPU without a cluster"):
  * after every handle has been stepped ONE substep, copy owned interface positions into the
  * neighbours' ghost ranges.  handles[i] must be partition i of the same mesh. */

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import load_mesh
 from oracle import OraclePJ
-from tetsim_amd import SoftBodyHIP, halo_exchange_local, make_lattice
+from tetsim_amd import SoftBodyHIP, group_step_n, halo_exchange_local, make_lattice
 
 pytestmark = pytest.mark.gpu
 
@@ -156,6 +156,49 @@ def test_partitioned_fast_blocked_within_tolerance():
     ref = mono.pos
     for b in bodies:
         assert np.abs(b.pos - ref[b.ownedIds]).max() < 2e-5
+
+
+@pytest.mark.parametrize("precision,parts", [("precise", 2), ("precise", 5), ("fast", 2), ("fast", 4), ("fast", 8)])
+def test_group_stepping_uses_the_rccl_choreography(precision, parts):
+    """tetsim_group_step_n drives all partitions with the SAME stream/event sequence as the RCCL path (interior tiles,
+    wait for the previous halo, boundary tiles, boundary particles, halo on a second stream, interior particles); only
+    ncclSend/ncclRecv are replaced by asynchronous copies.  PRECISE must equal the monolithic body bit for bit (any
+    missing dependency shows up as a stale ghost), FAST/blocked to summation-order rounding."""
+    n = 10
+    v, t = make_lattice(n, nz=2 * n, y0=0.05)
+    plane = (n + 1) * (n + 1)
+    owner = np.minimum((np.arange(len(v)) // plane) * parts // (2 * n + 1), parts - 1).astype(np.int32)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision)
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision, part_count=parts, part_index=p,
+                          vert_owner=owner) for p in range(parts)]
+    if precision == "fast":
+        assert all(b.info.local_elems > 0 for b in bodies)
+    for _ in range(6):
+        mono.simulateSubsteps(10, DT20, PP)
+        group_step_n(bodies, 10, DT20, PP)
+    ref = mono.pos
+    for b in bodies:
+        got = b.pos
+        if precision == "precise":
+            assert np.array_equal(got.view(np.uint32), ref[b.ownedIds].view(np.uint32))
+        else:
+            assert np.abs(got - ref[b.ownedIds]).max() < 5e-5
+    from tetsim_amd import TetSimError
+    with pytest.raises(TetSimError):
+        bodies[0].simulate(DT20, PP)  # grouped bodies are stepped through the group only
+
+
+def test_group_stepping_irregular_partition():
+    v, t = load_mesh("dragon")
+    parts = 3
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", part_count=parts, part_index=p) for p in range(parts)]
+    for _ in range(4):
+        mono.simulateSubsteps(10, DT20, PP)
+        group_step_n(bodies, 10, DT20, PP)
+    ref = mono.pos
+    for b in bodies:
+        assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
 
 
 def test_quats_follow_local_tet_order():

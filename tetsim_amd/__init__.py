@@ -5,5 +5,5 @@ Product code: tetsim_amd/csrc (HIP kernels + C ABI, include/tetsim.h), this thin
 imported from here.
 """
 from .lattice import make_lattice  # noqa: F401
-from .softbody import (SoftBodyHIP, TetSimError, comm_init, comm_selftest, comm_unique_id, halo_exchange_local,  # noqa: F401
+from .softbody import (SoftBodyHIP, TetSimError, comm_init, comm_selftest, comm_unique_id, group_step_n, halo_exchange_local,  # noqa: F401
                        make_params, measure_copy_bandwidth)

@@ -61,7 +61,7 @@ SYMBOLS = [
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
     "tetsim_read_visual_mesh", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
-    "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
+    "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
     "tetsim_prep_slot_table", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
@@ -113,6 +113,7 @@ def lib():
     L.tetsim_comm_unique_id.argtypes = [C.c_void_p]
     L.tetsim_comm_init.argtypes = [H, C.c_void_p, i32, i32]
     L.tetsim_comm_selftest.argtypes = [H]
+    L.tetsim_group_step_n.argtypes = [C.POINTER(H), u32, u32, dbl, PP]
     L.tetsim_halo_exchange_local.argtypes = [C.POINTER(H), u32]
     L.tetsim_get_halo_plan.argtypes = [H, ip, ip, ip, ip, ip]
     L.tetsim_halo_export.argtypes = [H, u32, fp]

@@ -44,7 +44,7 @@ struct PJDev {
 // particle (fixed order: deterministic), and the per-particle pass adds the few partial sums of the tiles
 // that touch it.
 struct PJBlk {
-    uint32_t nb = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0;
+    uint32_t nb = 0, nb_interior = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0;  // tiles >= nb_interior touch ghosts
     const uint32_t* blk_tet_off = nullptr;   // [nb+1]
     const uint32_t* blk_vert_off = nullptr;  // [nb+1]
     const int32_t* blk_verts = nullptr;      // particle id of every tile slot
@@ -91,7 +91,8 @@ void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32
 void pj_launch_repredict_precise(hipStream_t s, const PJDev& d);
 void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
 
-void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
+                    hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 

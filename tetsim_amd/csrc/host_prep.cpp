@@ -243,31 +243,63 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     std::vector<uint8_t> live(4ull * nt, 0);
     for (int32_t enc : inc.slot) live[enc] = 1;
 
-    // 2. greedy tiling along the curve
+    // 2. greedy tiling along the curve: tile = a run [begin, end) of the sorted tets
     std::vector<int32_t> slot_of(nv, -1);
     std::vector<int32_t> touched;
+    struct Run { uint32_t begin, end; bool ghost; };
+    std::vector<Run> runs;
+    {
+        uint32_t i = 0;
+        while (i < nt) {
+            const uint32_t t0 = i;
+            touched.clear();
+            bool ghost = false;
+            while (i < nt && i - t0 < kMaxTets) {
+                const int32_t* t = &tets[4 * B.tet_perm[i]];
+                uint32_t fresh = 0;
+                for (int k = 0; k < 4; k++) {
+                    bool seen = slot_of[t[k]] >= 0;
+                    for (int j = 0; j < k && !seen; j++) seen = t[j] == t[k];
+                    if (!seen) fresh++;
+                }
+                if (touched.size() + fresh > kMaxVerts) break;
+                for (int k = 0; k < 4; k++)
+                    if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); ghost |= static_cast<uint32_t>(t[k]) >= nv_sum; }
+                i++;
+            }
+            for (int32_t v : touched) slot_of[v] = -1;
+            runs.push_back({t0, i, ghost});
+        }
+    }
+    // tiles that touch a ghost particle go last: a partitioned body solves the others while the halo is in flight
+    std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.ghost < b.ghost; });
+    {
+        std::vector<int32_t> perm2(nt);
+        uint32_t o = 0;
+        for (Run& r : runs) {
+            std::copy(B.tet_perm.begin() + r.begin, B.tet_perm.begin() + r.end, perm2.begin() + o);
+            const uint32_t len = r.end - r.begin;
+            r.begin = o; r.end = o + len;
+            o += len;
+        }
+        B.tet_perm.swap(perm2);
+    }
+
+    // 3. emit per-tile tables
     B.tet_lidx.resize(4ull * nt);
     B.lc_ent.resize(4ull * nt);
     B.blk_tet_off.push_back(0);
     B.blk_vert_off.push_back(0);
     std::vector<std::vector<uint32_t>> vert_partials(nv_sum);
-    uint32_t i = 0;
-    while (i < nt) {
-        const uint32_t t0 = i;
+    for (const Run& r : runs) {
+        const uint32_t t0 = r.begin, i = r.end;
+        if (!r.ghost) B.num_interior_blocks++;
         touched.clear();
-        while (i < nt && i - t0 < kMaxTets) {
-            const int32_t* t = &tets[4 * B.tet_perm[i]];
-            uint32_t fresh = 0;
+        for (uint32_t j = t0; j < i; j++)
             for (int k = 0; k < 4; k++) {
-                bool seen = slot_of[t[k]] >= 0;
-                for (int j = 0; j < k && !seen; j++) seen = t[j] == t[k];
-                if (!seen) fresh++;
+                const int32_t v = tets[4 * B.tet_perm[j] + k];
+                if (slot_of[v] < 0) { slot_of[v] = 0; touched.push_back(v); }
             }
-            if (touched.size() + fresh > kMaxVerts) break;
-            for (int k = 0; k < 4; k++)
-                if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); }
-            i++;
-        }
         // LDS slots in ascending particle id: with Morton-numbered particles a tile's slots are a few contiguous
         // runs of the position array, and a particle's partial sums sit next to its neighbours'
         std::sort(touched.begin(), touched.end());

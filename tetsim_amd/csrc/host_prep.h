@@ -76,6 +76,7 @@ struct BlockPlan {
     std::vector<uint32_t> vp_ell;        // the same lists as ELL [max_partials][nv_pad], 0xffffffff = none
     uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
+    uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no particle >= nv_sum (no ghost)
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
 // it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).

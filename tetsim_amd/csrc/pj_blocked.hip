@@ -53,7 +53,8 @@ constexpr uint32_t kTile = 256;
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // `dbg` is a development knob for timing ablations (bits 0-3: rotation iterations, bit 4: skip the rest-shape
 // write-back); the product always passes 9 / 0 -- anything else produces wrong physics.
-__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tiles_per_xcd, uint32_t dbg) {
+__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                        uint32_t tiles_per_xcd, uint32_t dbg) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -61,8 +62,9 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tiles
     __shared__ float s_v[kTile];           // V per tet
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
-    const uint32_t b = xcd_tile(blockIdx.x, tiles_per_xcd);
-    if (b >= d.nb) return;  // whole workgroup leaves together
+    const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
+    if (rel >= tile_count) return;  // whole workgroup leaves together
+    const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
 #define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     TETSIM_STAMP(0);
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 
 }  // namespace
 
-void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
-    if (d.nb == 0) return;
-    const uint32_t per_xcd = (d.nb + 7u) / 8u;
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
+    if (tile_count == 0) return;
+    const uint32_t per_xcd = (tile_count + 7u) / 8u;
     static int dbg = -1;
     if (dbg < 0) {  // timing ablations only (see kernel comment); unset => 9 iterations, all stores
         const char* it = getenv("TETSIM_DEBUG_ITERS");
@@ -221,8 +223,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1)
         const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
         dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0);
     }
-    if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, per_xcd, static_cast<uint32_t>(dbg));
-    else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, per_xcd, static_cast<uint32_t>(dbg));
+    if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
+    else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
 }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
     if (count == 0) return;

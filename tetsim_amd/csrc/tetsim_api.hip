@@ -77,7 +77,11 @@ struct tetsim_body {
     TetSimOptions opt{};
     TetSimInfo info{};
     hipStream_t stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_boundary = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
+    // halo choreography events, double buffered by substep parity: an event is never re-recorded while a wait that
+    // other streams enqueued on its previous record may still be pending
+    hipEvent_t ev_boundary2[2] = {nullptr, nullptr}, ev_packed2[2] = {nullptr, nullptr}, ev_sent2[2] = {nullptr, nullptr};
+    uint32_t halo_parity = 0;
     DevParams* d_params = nullptr;
     DevParams* h_ring = nullptr;  // pinned [kRing]
     hipEvent_t ring_ev[kRing] = {};
@@ -107,6 +111,8 @@ struct tetsim_body {
     float dt_pred = 0.0f;
     ncclComm_t comm = nullptr;
     int comm_rank = -1, comm_size = 0;
+    bool halo_pending = false;            // a halo was started and nobody has waited for it yet
+    std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
 
     SkinDev skin;  // embedded visual mesh
 
@@ -196,7 +202,7 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
 void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-    if (h->blocked) pjb_launch_tet(h->stream, h->blk, e0, e1);
+    if (h->blocked) pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb, e0, e1);
     else h->fast ? pj_launch_tet_fast(h->stream, h->pj, e0, e1) : pj_launch_tet_precise(h->stream, h->pj, e0, e1);
 }
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -212,43 +218,105 @@ int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
     return fail(h, TETSIM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
 }
 
-// Ghost positions travel once per substep: owned interface predictions -> the neighbours' ghost ranges.
-// Issued after the boundary vertices are final; the interior vertex kernel overlaps the transfer.
-int halo_rccl(tetsim_body* h) {
+// Start this substep's halo: owned interface predictions -> the neighbours' ghost ranges, on the halo stream.
+// Two transports share this choreography: RCCL (one process per GPU) and, for partitions living in ONE process
+// (tests, "multi-GPU without a cluster"), asynchronous device copies issued by the sender.
+//
+// Dependencies (p = substep parity; all partitions of a group advance in lock-step on the host, so parities agree):
+//   boundary[p]  recorded on the main stream after this substep's boundary-particle pass (hence after its tet kernels)
+//   packed[p]    = boundary[p] + the pack kernels of non-contiguous send lists
+//   a transfer into partition D's ghosts waits for D's boundary[p]: D's tet kernels of this substep have read them
+//   sent[p]      recorded on the halo stream after this partition's transfers (RCCL: sends AND receives)
+//   the next substep's first ghost-reading tet kernel waits for every neighbour's sent[p] -- and for OUR sent[p], because
+//   our next boundary pass overwrites the very buffer our transfer reads
+int halo_start(tetsim_body* h) {
+    const uint32_t p = h->halo_parity;
     for (auto& nb : h->neigh)
         if (!nb.contiguous && nb.send_count) util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
-    HIPCHK(h, hipEventRecord(h->ev_boundary, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
-    ncclResult_t r = g_rccl.GroupStart();
-    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
-    for (auto& nb : h->neigh) {
-        if (nb.send_count) {
-            const float4* src = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
-            r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
-            if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
+    HIPCHK(h, hipEventRecord(h->ev_packed2[p], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_packed2[p], 0));
+    if (h->comm) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
+        for (auto& nb : h->neigh) {
+            if (nb.send_count) {
+                const float4* src = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
+                r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+                if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
+            }
+            if (nb.recv_count) {
+                // posted on OUR halo stream, i.e. after our boundary pass of this substep: the ghosts are overwritten only
+                // once this partition's tet kernels (which read them) are done
+                r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+                if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
+            }
         }
-        if (nb.recv_count) {
-            r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
-            if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
+        r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
+    } else {  // in-process group: sender-driven copies with the ordering guarantees a posted receive gives
+        for (auto& nb : h->neigh) {
+            if (!nb.send_count) continue;
+            tetsim_body* dst = h->group[nb.rank];
+            const NeighDev* back = nullptr;
+            for (auto& r : dst->neigh) if (r.rank == h->opt.part_index) back = &r;
+            if (!back || back->recv_count != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan");
+            HIPCHK(h, hipStreamWaitEvent(h->comm_stream, dst->ev_boundary2[p], 0));  // receiver finished reading its ghosts
+            const float4* from = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
+            HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream));
         }
     }
-    r = g_rccl.GroupEnd();
-    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
-    HIPCHK(h, hipEventRecord(h->ev_halo, h->comm_stream));
+    HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream));
+    h->halo_pending = true;
+    return 0;
+}
+// Make this partition's main stream wait until the previous substep's halo is complete (see halo_start).
+int halo_wait(tetsim_body* h) {
+    if (!h->halo_pending) return 0;
+    const uint32_t p = h->halo_parity ^ 1u;  // the previous substep's parity
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sent2[p], 0));  // our own transfers (RCCL: includes our receives)
+    if (!h->comm)
+        for (auto& nb : h->neigh)
+            if (nb.recv_count) HIPCHK(h, hipStreamWaitEvent(h->stream, h->group[nb.rank]->ev_sent2[p], 0));
+    h->halo_pending = false;
+    return 0;
+}
+bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
+
+// In-process groups must issue every partition's boundary pass before anyone's sends (a send waits for the RECEIVER's
+// boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
+int enqueue_phase_a(tetsim_body* h) {  // tet kernels + boundary particles
+    if (h->blocked) {
+        // interior tiles read no ghost: they run while the previous substep's halo is still in flight
+        pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
+        int rc = halo_wait(h);
+        if (rc) return rc;
+        pjb_launch_tet(h->stream, h->blk, h->blk.nb_interior, h->blk.nb - h->blk.nb_interior);
+    } else {
+        int rc = halo_wait(h);
+        if (rc) return rc;
+        pj_tet(h);
+    }
+    pj_vertex(h, 0, h->pj.nv_boundary);
+    HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream));
+    return 0;
+}
+int enqueue_phase_b(tetsim_body* h) {  // halo start + interior particles
+    int rc = halo_start(h);
+    if (rc) return rc;
+    pj_vertex(h, h->pj.nv_boundary, h->pj.nv_owned - h->pj.nv_boundary);
+    h->halo_parity ^= 1u;
     return 0;
 }
 
 // one substep's launches (parameters already on the device)
 int enqueue_substep(tetsim_body* h) {
     if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
-        pj_tet(h);
-        if (h->comm && !h->neigh.empty()) {
-            pj_vertex(h, 0, h->pj.nv_boundary);
-            int rc = halo_rccl(h);
+        if (has_transport(h)) {
+            int rc = enqueue_phase_a(h);
+            if (!rc) rc = enqueue_phase_b(h);
             if (rc) return rc;
-            pj_vertex(h, h->pj.nv_boundary, h->pj.nv_owned - h->pj.nv_boundary);
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_halo, 0));  // next tet kernel gathers the ghosts
         } else {
+            pj_tet(h);
             pj_vertex(h, 0, h->pj.nv_owned);
         }
     } else {
@@ -393,7 +461,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
         h->tet_perm = B.tet_perm;
         PJBlk& k = h->blk;
-        k.nb = B.num_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
+        k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         uint32_t *bto, *bvo, *lcr, *vpe;
         int32_t* bv;
@@ -650,7 +718,10 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     if (!hipok(hipSetDevice(o.device), "hipSetDevice")) return bail(TETSIM_EHIP);
     if (!hipok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(TETSIM_EHIP);
     if (!hipok(hipEventCreate(&h->ev_a), "hipEventCreate") || !hipok(hipEventCreate(&h->ev_b), "hipEventCreate")) return bail(TETSIM_EHIP);
-    if (!hipok(hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
+    for (int i = 0; i < 2; i++)
+        if (!hipok(hipEventCreateWithFlags(&h->ev_boundary2[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hipok(hipEventCreateWithFlags(&h->ev_packed2[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hipok(hipEventCreateWithFlags(&h->ev_sent2[i], hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
     if (!hipok(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
     for (int i = 0; i < kRing; i++)
         if (!hipok(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
@@ -682,7 +753,8 @@ void tetsim_destroy(tetsim_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
-    for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_boundary, h->ev_halo}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
+                          h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -696,6 +768,7 @@ int tetsim_get_info(tetsim_handle h, TetSimInfo* info) {
 
 int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (!h) return TETSIM_EINVAL;
+    if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = push_params(h, dt, params);
     if (rc) return rc;
@@ -705,12 +778,13 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
 
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params) {
     if (!h) return TETSIM_EINVAL;
+    if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     if (n == 0) return 0;
     HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
-    if (h->comm && !h->neigh.empty()) {  // RCCL transfers are issued eagerly (two streams, no capture)
+    if (has_transport(h)) {  // halo transfers are issued eagerly (two streams, no capture)
         for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
         return rc;
     }
@@ -926,7 +1000,7 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
 
 int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params, TetSimProfile* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->comm && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "profile a partitioned body through rocprofv3 instead");
+    if (has_transport(h)) return fail(h, TETSIM_ESTATE, "profile a partitioned body through rocprofv3 instead");
     HIPCHK(h, hipSetDevice(h->opt.device));
     std::memset(out, 0, sizeof(*out));
     int rc = push_params(h, dt, params);
@@ -984,7 +1058,7 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
 
 int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimParams* params, TetSimProfile* out) {
     if (!h || !out || reps == 0) return fail(h, TETSIM_EINVAL, "bad argument");
-    if (h->comm && !h->neigh.empty()) return fail(h, TETSIM_ESTATE, "time a partitioned body through rocprofv3 instead");
+    if (has_transport(h)) return fail(h, TETSIM_ESTATE, "time a partitioned body through rocprofv3 instead");
     HIPCHK(h, hipSetDevice(h->opt.device));
     std::memset(out, 0, sizeof(*out));
     int rc = push_params(h, dt, params);
@@ -1158,6 +1232,33 @@ int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
     if (!nb.recv_count) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->pj.pos_pred + nb.recv_start, in_xyzw, nb.recv_count * sizeof(float4), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
+    if (!hs || count == 0) return TETSIM_EINVAL;
+    for (uint32_t i = 0; i < count; i++) {
+        tetsim_body* h = hs[i];
+        if (!h || h->opt.part_count != static_cast<int32_t>(count) || h->opt.part_index != static_cast<int32_t>(i) || h->comm)
+            return fail(h, TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition without an RCCL communicator");
+        if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
+        if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream
+            h->group.assign(hs, hs + count);
+            if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        int rc = push_params(hs[i], dt, params);
+        if (!rc) rc = ensure_prediction(hs[i], dt);
+        if (rc) return rc;
+    }
+    static const bool dbg_sync = getenv("TETSIM_DEBUG_GROUP_SYNC") != nullptr;  // development: serialise every phase
+    for (uint32_t s = 0; s < n; s++) {
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_a(hs[i]); if (rc) return rc; }
+        if (dbg_sync) (void)hipDeviceSynchronize();
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
+        if (dbg_sync) (void)hipDeviceSynchronize();
+    }
     return 0;
 }
 

@@ -273,6 +273,12 @@ def measure_copy_bandwidth(nbytes, reps=20, device=0):
     return g.value
 
 
+def group_step_n(bodies, n, dt, physicsParams):
+    """n substeps of every partition of one decomposition (same choreography as the RCCL path, in-process copies)."""
+    arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
+    capi.check(capi.lib().tetsim_group_step_n(arr, len(bodies), int(n), float(dt), C.byref(make_params(physicsParams))))
+
+
 def halo_exchange_local(bodies):
     arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
     capi.check(capi.lib().tetsim_halo_exchange_local(arr, len(bodies)))
