@@ -42,7 +42,9 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt(float4* p, const float4& v) {
     const v4f x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+    // hipcc's hazard recogniser cannot see inside an asm statement: a VMEM store of more than 8 bytes needs 2 wait
+    // states before a VALU instruction may overwrite its data VGPRs (gfx940+), so they are part of the string.
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd) { return (b & 7u) * tiles_per_xcd + (b >> 3); }
