@@ -164,6 +164,11 @@ int tetsim_sync(tetsim_handle h);
 /* Replaces reading `.pos` (Softbody.js:12) / readToCPU (SoftbodyGPU.js:649-653): xyz of the OWNED
  * particles after the last completed substep, [3*owned_particles], in tetsim_get_owned_ids order. */
 int tetsim_read_positions(tetsim_handle h, float *out);
+/* Zero-copy variant: positions are packed to xyz on the device and copied straight into a pinned
+ * host buffer owned by the handle ([3*owned_particles] floats, valid until tetsim_destroy, overwritten by the next
+ * call).  *out receives its address: a host wraps it once (N-API external ArrayBuffer, numpy view) and every
+ * endFrame() is one device pack kernel + one DMA, no intermediate host copy.  Synchronises. */
+int tetsim_read_positions_pinned(tetsim_handle h, const float **out);
 int tetsim_read_prev_positions(tetsim_handle h, float *out); /* .prevPos */
 int tetsim_read_velocities(tetsim_handle h, float *out);     /* .vel */
 /* POLAR_JACOBI: per-tet rotation quaternion xyzw (textureQuat, SoftbodyGPU.js:55,181), [4*local_elems]
@@ -203,7 +208,9 @@ int tetsim_read_visual_mesh(tetsim_handle h, float *positions_out, float *normal
 /* Pin global particle `id` (-1 = none, endGrab) at xyz: consumed by the next substeps
  * (Softbody.js:233-235 ; SoftbodyGPU.js:345, with the exact particle index -- see DESIGN.md). */
 int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]);
-/* startGrab: nearest particle to xyz among the latest positions (device argmin); sets and returns it. */
+/* startGrab: nearest particle to xyz among the latest positions -- argmin on the device (f64 distances evaluated as
+ * Softbody.js:284-288 does, first minimum wins), only one candidate per 256 particles travels to the host; sets and
+ * returns the particle (no full read-back, unlike GPUGrabber.start, SoftbodyGPU.js:790-795). */
 int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t *id_out);
 
 /* --- measurement ----------------------------------------------------------------------------- */

@@ -97,3 +97,38 @@ def test_many_bodies_share_the_device():
     for _ in range(3):
         ref.simulateSubsteps(20, DT, PP)
     assert np.array_equal(bodies[2].pos.view(np.uint32), ref.pos.view(np.uint32))
+
+
+def test_device_grab_query_matches_reference_argmin():
+    """tetsim_start_grab runs the argmin of Softbody.js:279-291 on the device (f64 distances, first minimum wins),
+    including exact ties (symmetric lattice points) and after the internal Morton renumbering of the polar path."""
+    v, t = make_lattice(6, y0=0.1)
+    orc = OracleNH(v, t, PP)
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="neohookean"), SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")]
+    h = 1.0 / 6
+    queries = [(0.0, 0.6, 0.0), (0.5 * h, 0.1 + 0.5 * h, 0.5 * h), (-0.5, 0.1, -0.5), (3.0, 3.0, 3.0), (0.25 * h, 0.1 + 2.5 * h, -1.5 * h),
+               (0.013, 0.47, -0.21)]
+    for q in queries:
+        want = orc.startGrab(*[float(np.float32(c)) for c in q])   # the ABI carries the query point as f32
+        for b in bodies:
+            assert b.startGrab(np.float32(q)) == want, q
+    # after motion the query must see the LATEST positions
+    for b in bodies:
+        b.endGrab(); b.simulateSubsteps(30, DT, PP)
+    b = bodies[0]
+    orc2 = OracleNH(b.pos, t, PP)
+    assert b.startGrab(np.float32([0.1, 0.3, 0.1])) == orc2.startGrab(float(np.float32(0.1)), float(np.float32(0.3)), float(np.float32(0.1)))
+
+
+@pytest.mark.parametrize("solver,precision", [("polar", "fast"), ("polar", "precise"), ("neohookean", "precise")])
+def test_pinned_zero_copy_readback_equals_copying_readback(solver, precision):
+    v, t = load_mesh("dragon")
+    b = SoftBodyHIP(v, t, None, dict(PP), solver=solver, precision=precision)
+    b.simulateSubsteps(10, DT, PP)
+    view = b.posPinned
+    assert np.array_equal(view.view(np.uint32), b.pos.view(np.uint32))
+    addr = view.ctypes.data
+    b.simulateSubsteps(10, DT, PP)
+    view2 = b.posPinned
+    assert view2.ctypes.data == addr                      # same pinned memory, refreshed in place
+    assert np.array_equal(view2.view(np.uint32), b.pos.view(np.uint32))

@@ -56,7 +56,7 @@ class TetSimError(RuntimeError):
 SYMBOLS = [
     "tetsim_abi_version", "tetsim_default_options", "tetsim_default_params", "tetsim_create", "tetsim_destroy",
     "tetsim_last_error", "tetsim_get_info", "tetsim_step", "tetsim_step_n", "tetsim_sync",
-    "tetsim_read_positions", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
+    "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
     "tetsim_read_visual_mesh", "tetsim_set_grab",
@@ -98,6 +98,7 @@ def lib():
     L.tetsim_sync.argtypes = [H]
     for n in ("positions", "prev_positions", "velocities", "quats", "inv_mass"):
         getattr(L, "tetsim_read_" + n).argtypes = [H, fp]
+    L.tetsim_read_positions_pinned.argtypes = [H, C.POINTER(fp)]
     L.tetsim_read_vol_error.argtypes = [H, dp]
     L.tetsim_write_state.argtypes = [H, fp, fp]
     for n in ("owned_ids", "local_tets", "tet_order", "level_offsets"):

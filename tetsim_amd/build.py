@@ -30,7 +30,7 @@ UNITS = {
     "pj_blocked.hip": ["-ffp-contract=fast"],
     "nh_precise.hip": ["-ffp-contract=off"],
     "nh_fast.hip": ["-ffp-contract=fast"],
-    "util_kernels.hip": [],
+    "util_kernels.hip": ["-ffp-contract=off"],
     "skin_kernels.hip": ["-ffp-contract=off"],
 }
 HEADERS = ["dev_common.h", "host_prep.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]

@@ -116,6 +116,9 @@ struct SkinDev {
 // js_order: Softbody.js:259-277 arithmetic (f64 accumulate, f32 store per step); else SoftbodyGPU.js:431-435 (f32)
 void skin_launch(hipStream_t s, const SkinDev& d, const float4* pos, const float4* quat, bool js_order);
 
+void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map, float* out, uint32_t n);
+void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, uint32_t n, double px, double py, double pz,
+                         double* best_d2, uint32_t* best_id);
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n);
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 

@@ -115,6 +115,10 @@ struct tetsim_body {
     std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
 
     SkinDev skin;  // embedded visual mesh
+    float* pinned_pos = nullptr;   // tetsim_read_positions_pinned: host-pinned xyz
+    float* d_packed = nullptr;     //   and its device-side staging
+    uint32_t* d_api2dev = nullptr; // device copy of api2dev (pack / nearest kernels), null = identity
+    double* d_best = nullptr; uint32_t* d_best_id = nullptr;  // tetsim_start_grab candidates
 
     // NEOHOOKEAN_GS
     NHDev nh;
@@ -752,6 +756,7 @@ void tetsim_destroy(tetsim_handle h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->pinned_pos) (void)hipHostFree(h->pinned_pos);
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
@@ -810,6 +815,34 @@ int tetsim_read_positions(tetsim_handle h, float* out) {
     return h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI ? read_float4_as_xyz(h, h->pj.pos_final, h->pj.nv_owned, out)
                                                        : read_float4_as_xyz(h, h->nh.pos, h->nh.nv, out);
 }
+namespace {
+const float4* current_positions(tetsim_body* h) { return h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI ? h->pj.pos_final : h->nh.pos; }
+int ensure_index_map(tetsim_body* h) {  // internal Morton numbering -> API numbering, on the device
+    if (h->d_api2dev || h->api2dev.empty()) return 0;
+    int rc = dev_alloc(h, &h->d_api2dev, h->api2dev.size());
+    if (rc) return rc;
+    return upload(h, h->d_api2dev, h->api2dev);
+}
+}  // namespace
+
+int tetsim_read_positions_pinned(tetsim_handle h, const float** out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const uint32_t n = h->info.owned_particles;
+    int rc;
+    if (!h->pinned_pos) {
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned_pos), std::max<size_t>(3ull * n, 1) * sizeof(float), hipHostMallocDefault));
+        if ((rc = dev_alloc(h, &h->d_packed, 3ull * n))) return rc;
+        if ((rc = ensure_index_map(h))) return rc;
+    }
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    util_launch_pack_xyz(h->stream, current_positions(h), h->d_api2dev, h->d_packed, n);
+    if (n) HIPCHK(h, hipMemcpyAsync(h->pinned_pos, h->d_packed, 3ull * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = h->pinned_pos;
+    return 0;
+}
+
 int tetsim_read_prev_positions(tetsim_handle h, float* out) {
     if (!h) return TETSIM_EINVAL;
     if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI)
@@ -979,19 +1012,28 @@ int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {
 int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
     if (!h || !xyz) return fail(h, TETSIM_EINVAL, "null argument");
     if (h->partitioned) return fail(h, TETSIM_ESTATE, "start_grab on a partitioned body: pick the particle on the host and use tetsim_set_grab");
-    // As GPUGrabber.start does (SoftbodyGPU.js:790-795): read the positions back, then the argmin of
-    // Softbody.js:279-291 (f64 squared distance, first minimum wins).
-    const uint32_t n = h->info.num_particles;
-    std::vector<float> pos(3ull * n);
-    int rc = tetsim_read_positions(h, pos.data());
-    if (rc) return rc;
+    // argmin of Softbody.js:279-291 on the device: one (d2, index) candidate per 256 particles comes back
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const uint32_t n = h->info.num_particles, nblk = (n + 255u) / 256u;
+    int rc;
+    if (!h->d_best) {
+        if ((rc = dev_alloc(h, &h->d_best, nblk))) return rc;
+        if ((rc = dev_alloc(h, &h->d_best_id, nblk))) return rc;
+        if ((rc = ensure_index_map(h))) return rc;
+    }
+    util_launch_nearest(h->stream, current_positions(h), h->d_api2dev, n, static_cast<double>(xyz[0]), static_cast<double>(xyz[1]),
+                        static_cast<double>(xyz[2]), h->d_best, h->d_best_id);
+    std::vector<double> bd(nblk);
+    std::vector<uint32_t> bi(nblk);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (nblk) {
+        HIPCHK(h, hipMemcpy(bd.data(), h->d_best, nblk * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(bi.data(), h->d_best_id, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     double best = 1.7976931348623157e308;
     int32_t id = -1;
-    for (uint32_t i = 0; i < n; i++) {
-        const double a0 = static_cast<double>(xyz[0]) - pos[3 * i], a1 = static_cast<double>(xyz[1]) - pos[3 * i + 1], a2 = static_cast<double>(xyz[2]) - pos[3 * i + 2];
-        const double d2 = a0 * a0 + a1 * a1 + a2 * a2;
-        if (d2 < best) { best = d2; id = static_cast<int32_t>(i); }
-    }
+    for (uint32_t b = 0; b < nblk; b++)  // blocks are in ascending particle order: `<` keeps the first minimum
+        if (bd[b] < best) { best = bd[b]; id = static_cast<int32_t>(bi[b]); }
     h->grab_global = id;
     std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
     if (id_out) *id_out = id;

@@ -17,7 +17,56 @@ __global__ __launch_bounds__(256) void gather16_kernel(const float4* __restrict_
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// strip float4 particles to tightly packed xyz, un-permuting the internal (Morton) numbering: out[3*a..] = src[map[a]]
+__global__ __launch_bounds__(256) void pack_xyz_kernel(const float4* __restrict__ src, const uint32_t* __restrict__ map,
+                                                       float* __restrict__ out, uint32_t n) {
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    if (a >= n) return;
+    const float4 p = src[map ? map[a] : a];
+    out[3 * a] = p.x; out[3 * a + 1] = p.y; out[3 * a + 2] = p.z;
+}
+
+// startGrab (Softbody.js:279-291): argmin over particles of the squared distance, evaluated in f64 exactly as the
+// JS does (a0*a0 + a1*a1 + a2*a2, left to right; build with -ffp-contract=off), first minimum wins.  One candidate per
+// workgroup; the host finishes over the few hundred candidates in index order.
+__global__ __launch_bounds__(256) void nearest_kernel(const float4* __restrict__ pos, const uint32_t* __restrict__ map, uint32_t n,
+                                                      double px, double py, double pz, double* __restrict__ best_d2,
+                                                      uint32_t* __restrict__ best_id) {
+    __shared__ double s_d[256];
+    __shared__ uint32_t s_i[256];
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;  // API particle index: ties must resolve to the smallest one
+    double d2 = 1.7976931348623157e308;
+    if (a < n) {
+        const float4 p = pos[map ? map[a] : a];
+        const double a0 = px - static_cast<double>(p.x), a1 = py - static_cast<double>(p.y), a2 = pz - static_cast<double>(p.z);
+        d2 = a0 * a0 + a1 * a1 + a2 * a2;
+        if (d2 != d2) d2 = 1.7976931348623157e308;  // `d2 < minD2` is false for NaN: such a particle is never picked
+    }
+    s_d[threadIdx.x] = d2;
+    s_i[threadIdx.x] = a;
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            const double o = s_d[threadIdx.x + w];
+            const uint32_t oi = s_i[threadIdx.x + w];
+            if (o < s_d[threadIdx.x] || (o == s_d[threadIdx.x] && oi < s_i[threadIdx.x])) { s_d[threadIdx.x] = o; s_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best_d2[blockIdx.x] = s_d[0]; best_id[blockIdx.x] = s_i[0]; }
+}
+
 }  // namespace
+
+void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map, float* out, uint32_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_xyz_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, map, out, n);
+}
+void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, uint32_t n, double px, double py, double pz,
+                         double* best_d2, uint32_t* best_id) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(nearest_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, pos, map, n, px, py, pz, best_d2, best_id);
+}
 
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n) {
     if (n == 0) return;

@@ -100,7 +100,10 @@ class SoftBodyHIP {
     }
     readToCPU() {                                       // SoftbodyGPU.js:649-653
         if (this._dirty) {
-            this._api.readPositions(this._h, this.pos);
+            // zero copy: `pos` becomes a view of the handle's pinned host buffer on first use; afterwards a read-back is
+            // one device pack kernel + one DMA into that same memory
+            if (!this._mapped) { this.pos = this._api.mapPositions(this._h); this._mapped = true; }
+            else this._api.refreshPositions(this._h);
             if (this._solver === 'neohookean') this.volError = this._api.readVolError(this._h);
             this._dirty = false;
         }

@@ -29,6 +29,7 @@ struct Api {
     decltype(&tetsim_step_n) step_n = nullptr;
     decltype(&tetsim_sync) sync = nullptr;
     decltype(&tetsim_read_positions) read_positions = nullptr;
+    decltype(&tetsim_read_positions_pinned) read_positions_pinned = nullptr;
     decltype(&tetsim_read_velocities) read_velocities = nullptr;
     decltype(&tetsim_read_quats) read_quats = nullptr;
     decltype(&tetsim_read_vol_error) read_vol_error = nullptr;
@@ -50,7 +51,7 @@ bool load_lib(const std::string& hint) {
 #define SYM(field, name) g.field = reinterpret_cast<decltype(g.field)>(dlsym(g.lib, name)); if (!g.field) { g.err = std::string("libtetsim_hip lacks ") + name; return false; }
     SYM(default_options, "tetsim_default_options") SYM(default_params, "tetsim_default_params") SYM(create, "tetsim_create")
     SYM(destroy, "tetsim_destroy") SYM(last_error, "tetsim_last_error") SYM(get_info, "tetsim_get_info") SYM(step, "tetsim_step")
-    SYM(step_n, "tetsim_step_n") SYM(sync, "tetsim_sync") SYM(read_positions, "tetsim_read_positions")
+    SYM(step_n, "tetsim_step_n") SYM(sync, "tetsim_sync") SYM(read_positions, "tetsim_read_positions") SYM(read_positions_pinned, "tetsim_read_positions_pinned")
     SYM(read_velocities, "tetsim_read_velocities") SYM(read_quats, "tetsim_read_quats") SYM(read_vol_error, "tetsim_read_vol_error")
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
@@ -213,6 +214,32 @@ napi_value ReadF32(napi_env env, napi_callback_info info) {
     if (n < need) return throw_err(env, "output array too small");
     return check(env, (g.*Fn)(h, out), h);
 }
+// mapPositions(handle) -> Float32Array over the handle's PINNED host buffer (zero copy); the view stays
+// valid until destroy(handle); refreshPositions(handle) re-fills it (device pack kernel + one DMA).
+napi_value MapPositions(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    const float* p = nullptr;
+    const int rc = g.read_positions_pinned(h, &p);
+    if (rc) return check(env, rc, h);
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    napi_value ab, ta;
+    if (napi_create_external_arraybuffer(env, const_cast<float*>(p), sizeof(float) * 3 * inf.owned_particles, nullptr, nullptr, &ab) != napi_ok ||
+        napi_create_typedarray(env, napi_float32_array, 3 * inf.owned_particles, ab, 0, &ta) != napi_ok)
+        return throw_err(env, "cannot wrap the pinned buffer");
+    return ta;
+}
+napi_value RefreshPositions(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    const float* p = nullptr;
+    return check(env, g.read_positions_pinned(h, &p), h);
+}
 napi_value ReadVolError(napi_env env, napi_callback_info info) {
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return nullptr;
@@ -297,6 +324,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"readPositions", nullptr, ReadF32<&Api::read_positions, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVelocities", nullptr, ReadF32<&Api::read_velocities, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readQuats", nullptr, ReadF32<&Api::read_quats, 4, true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"mapPositions", nullptr, MapPositions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"refreshPositions", nullptr, RefreshPositions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -138,6 +138,14 @@ class SoftBodyHIP:
         return self._read3(self._L.tetsim_read_positions, self.info.owned_particles)
 
     @property
+    def posPinned(self):
+        """Zero-copy read-back: a numpy VIEW of the handle's pinned host buffer (valid until close(), refreshed by every
+        access): one device pack kernel + one DMA, no intermediate host copy."""
+        ptr = C.POINTER(C.c_float)()
+        capi.check(self._L.tetsim_read_positions_pinned(self._h, C.byref(ptr)), self._h)
+        return np.ctypeslib.as_array(ptr, shape=(self.info.owned_particles, 3))
+
+    @property
     def prevPos(self):
         return self._read3(self._L.tetsim_read_prev_positions, self.info.owned_particles)
 
