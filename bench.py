@@ -87,13 +87,41 @@ def cpu_baseline(verts, tets):
     return res
 
 
+class stdout_to_stderr:
+    """Route fd 1 to fd 2 while native libraries initialise (RCCL prints a version banner on stdout): rank 0's stdout
+    must carry exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
+    with stdout_to_stderr():
+        out, rank, dist, body = run()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        with stdout_to_stderr():
+            dist.barrier()
+            body.close()
+            dist.destroy_process_group()
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="fast", choices=["fast", "precise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +133,8 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -118,7 +147,7 @@ def main():
     verts, tets = make_lattice(CELLS, nz=nz)
     nt_global = len(tets)
     kw = {}
-    if world > 1:
+    if use_dist:
         plane = (CELLS + 1) * (CELLS + 1)
         owner = np.minimum((np.arange(len(verts)) // plane) // CELLS, world - 1).astype(np.int32)
         # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
@@ -127,7 +156,7 @@ def main():
         kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
     body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
                        device=local_rank, **kw)
-    if world > 1:
+    if use_dist:
         import torch
         from tetsim_amd import comm_init, comm_unique_id
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -205,12 +234,7 @@ def main():
         if not args.no_cpu_baseline:
             body.close()
             out["cpu_baseline"] = cpu_baseline(verts, tets)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        body.close()
-        dist.destroy_process_group()
+    return out, rank, dist, body
 
 
 if __name__ == "__main__":
