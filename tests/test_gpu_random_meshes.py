@@ -1,0 +1,81 @@
+"""Parity on irregular meshes: seeded random point clouds tetrahedralised with Delaunay (ragged valence, some particles
+beyond the reference's 36-slot scatter table, badly shaped tets), both solvers, partitions included."""
+import numpy as np
+import pytest
+from scipy.spatial import Delaunay
+
+from oracle import OracleNH, OraclePJ
+from tetsim_amd import SoftBodyHIP, group_step_n
+
+pytestmark = pytest.mark.gpu
+PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
+          worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+DT = (1.0 / 60.0) / 20
+
+
+def random_mesh(seed, npts, min_vol=2e-6):
+    rng = np.random.default_rng(seed)
+    pts = (rng.random((npts, 3)) * [0.8, 0.6, 0.7] + [-0.4, 0.15, -0.35]).astype(np.float32)
+    tets = Delaunay(pts.astype(np.float64)).simplices.astype(np.int32)
+    d = pts[tets[:, 1:]].astype(np.float64) - pts[tets[:, :1]].astype(np.float64)
+    vol = np.linalg.det(d) / 6.0
+    flip = vol < 0
+    tets[flip] = tets[flip][:, [0, 1, 3, 2]]          # make every rest volume positive
+    tets = tets[np.abs(vol) > min_vol]                 # drop slivers (near-zero rest volume)
+    used = np.unique(tets)                             # and the points only slivers referenced
+    remap = np.full(npts, -1, dtype=np.int32)
+    remap[used] = np.arange(len(used), dtype=np.int32)
+    return np.ascontiguousarray(pts[used]), np.ascontiguousarray(remap[tets])
+
+
+@pytest.mark.parametrize("seed,npts", [(1, 60), (2, 400), (3, 2500)])
+def test_neohookean_precise_bit_exact_on_random_meshes(seed, npts):
+    v, t = random_mesh(seed, npts)
+    for order in ("original", "coloured"):
+        body = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="precise", order=order)
+        orc = OracleNH(v, t[body.tetOrder], PP)
+        for _ in range(25):
+            body.simulate(DT * 2, PP)
+            orc.simulate(DT * 2, PP)
+        assert np.array_equal(body.pos.view(np.uint32), orc.pos.view(np.uint32)), (seed, order)
+        assert body.volError == orc.volError
+        assert np.array_equal(body.invMass.view(np.uint32), orc.invMass.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed,npts", [(4, 80), (5, 500), (6, 3000)])
+def test_polar_on_random_meshes(seed, npts):
+    v, t = random_mesh(seed, npts)
+    orc = OraclePJ(v, t, PP, slot_quirk=True)
+    valence = np.bincount(t.ravel(), minlength=len(v))
+    prec = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+    fast = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    gath = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", gather=True)
+    # the 36-slot cap and the slot-0 quirk drop exactly what the reference's table drops
+    expect_dropped = int(np.maximum(valence - 36, 0).sum()) + 1
+    assert prec.info.dropped_slots == expect_dropped == fast.info.dropped_slots
+    assert np.array_equal((orc.slots >= 0).sum(axis=1), np.minimum(valence, 36) - (np.arange(len(v)) == t[0, 0]) * (valence[t[0, 0]] > 1))
+    for step in range(1, 61):
+        for b in (prec, fast, gath, orc):
+            b.simulate(DT, PP)
+        if step in (1, 20, 60):
+            ref = orc.pos
+            assert np.abs(prec.pos - ref).max() <= {1: 1e-6, 20: 5e-6, 60: 5e-5}[step], (seed, step)
+            assert np.abs(fast.pos - ref).max() <= {1: 2e-6, 20: 5e-5, 60: 5e-4}[step], (seed, step)
+            assert np.abs(gath.pos - ref).max() <= {1: 2e-6, 20: 5e-5, 60: 5e-4}[step], (seed, step)
+
+
+def test_random_mesh_partitions_bitwise():
+    """Ragged ownership (k-means-free: split by x coordinate) on an irregular mesh, RCCL-path choreography."""
+    v, t = random_mesh(7, 1500)
+    parts = 3
+    owner = np.minimum(((v[:, 0] + 0.4) / 0.8 * parts).astype(np.int32), parts - 1)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", part_count=parts, part_index=p,
+                          vert_owner=owner) for p in range(parts)]
+    assert sum(b.info.owned_particles for b in bodies) == len(v)
+    for _ in range(3):
+        mono.simulateSubsteps(10, DT, PP)
+        group_step_n(bodies, 10, DT, PP)
+    ref = mono.pos
+    for b in bodies:
+        assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
