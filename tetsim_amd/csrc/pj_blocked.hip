@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
         float4 q_new;
-        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u));
+        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u), !(dbg & 64u));
         TETSIM_STAMP(3);  // solved
         if (dbg & 32u) {  // A/B: plain stores
             d.quat[e] = q_new;
@@ -223,7 +223,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
         const char* it = getenv("TETSIM_DEBUG_ITERS");
         const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
         const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
-        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0);
+        const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
+        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0) | ((np && np[0] == '1') ? 64 : 0);
     }
     if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
     else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
