@@ -15,6 +15,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Fresh checkout: build libtetsim_hip.so in-tree (hipcc cross-compiles without a GPU; no-op when up to date)."""
+    from tetsim_amd.build import build
+    build()
+
+
 def load_mesh(name):
     v = np.fromfile(os.path.join(GOLDEN, name + "_verts.f32"), dtype="<f4").reshape(-1, 3)
     t = np.fromfile(os.path.join(GOLDEN, name + "_tets.i32"), dtype="<i4").reshape(-1, 4)

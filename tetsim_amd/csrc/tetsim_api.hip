@@ -286,9 +286,14 @@ int halo_wait(tetsim_body* h) {
 }
 bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
 
-// In-process groups must issue every partition's boundary pass before anyone's sends (a send waits for the RECEIVER's
+// Host cost matters here: a substep is ~42 us of GPU work and every launch / event call costs 1.5-4 us, so the eager
+// halo path issues as few operations as possible -- 3 kernel launches (interior tiles, boundary tiles, ONE particle pass),
+// 1 event record + 1 cross-stream wait to start the transfer, 1 record after it, 1 wait before the next boundary tiles.
+// The transfer overlaps the NEXT substep's interior tet kernel (~30 us), which is ample for a 200 KB message.
+//
+// In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
-int enqueue_phase_a(tetsim_body* h) {  // tet kernels + boundary particles
+int enqueue_phase_a(tetsim_body* h) {  // tet kernels + particles
     if (h->blocked) {
         // interior tiles read no ghost: they run while the previous substep's halo is still in flight
         pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
@@ -300,14 +305,13 @@ int enqueue_phase_a(tetsim_body* h) {  // tet kernels + boundary particles
         if (rc) return rc;
         pj_tet(h);
     }
-    pj_vertex(h, 0, h->pj.nv_boundary);
-    HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream));
+    pj_vertex(h, 0, h->pj.nv_owned);
+    if (!h->comm) HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream));  // group transport only
     return 0;
 }
-int enqueue_phase_b(tetsim_body* h) {  // halo start + interior particles
+int enqueue_phase_b(tetsim_body* h) {  // halo start
     int rc = halo_start(h);
     if (rc) return rc;
-    pj_vertex(h, h->pj.nv_boundary, h->pj.nv_owned - h->pj.nv_boundary);
     h->halo_parity ^= 1u;
     return 0;
 }
