@@ -121,6 +121,8 @@ def run():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="fast", choices=["fast", "precise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--constant-rest-shape", action="store_true",
+                    help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     args = ap.parse_args()
 
@@ -154,6 +156,8 @@ def run():
         # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
         PP["worldBounds"] = [-2.5, -1.0, -(0.5 * world + 2.0), 2.5, 10.0, 0.5 * world + 2.0]
         kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
+    if args.constant_rest_shape:
+        kw["constant_rest_shape"] = True
     body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
                        device=local_rank, **kw)
     if use_dist:
@@ -202,7 +206,8 @@ def run():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
                                    "%d substeps/frame, dt=1/1200 s" % (CELLS, CELLS, nz, nt_global, nv_global, SUBSTEPS),
-                       "solver": "polar_jacobi", "arithmetic": args.precision, "substeps_per_step": SUBSTEPS,
+                       "solver": "polar_jacobi", "arithmetic": args.precision,
+                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (carried world-space rest shape)", "substeps_per_step": SUBSTEPS,
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
         }
@@ -212,20 +217,22 @@ def run():
         pr = body.profile(SUBSTEPS * 3, DT, PP)
         tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3
-        achieved = TET_KERNEL_BYTES * len(tets) / (tet_us * 1e-6) / 1e9
-        b_alg = TET_KERNEL_BYTES + VERTEX_BYTES * len(verts) / len(tets)
+        # constant-rest-shape option: the 48 B/tet shape is read only (never written back): 148 - 48 = 100 B/tet
+        tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)
+        achieved = tet_bytes * len(tets) / (tet_us * 1e-6) / 1e9
+        b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
+                traffic = None if args.constant_rest_shape else json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
-                           "alg_bytes_per_launch": TET_KERNEL_BYTES * len(tets),
+                           "alg_bytes_per_launch": tet_bytes * len(tets),
                            "substep_alg_bytes_per_tet": round(b_alg, 1),
                            "substep_achieved": round(b_alg * value * 1e6 / 1e9, 1),
                            "substep_frac": round(b_alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 4),

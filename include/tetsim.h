@@ -77,7 +77,12 @@ enum {
     TETSIM_FLAG_REF_FIXED_BOUNDS = 1u << 1,
     /* POLAR_JACOBI + FAST normally runs the blocked formulation (workgroup tiles, LDS-staged particles,
      * per-tile partial sums).  This flag keeps the gather formulation (reference slot order). */
-    TETSIM_FLAG_GATHER_FORMULATION = 1u << 2
+    TETSIM_FLAG_GATHER_FORMULATION = 1u << 2,
+    /* POLAR_JACOBI + FAST + blocked: do not carry the rotated rest shape in world space (48 B/tet read + 48 B/tet written
+     * per substep, as the reference's textureElem does) but re-derive it as R(q) * rest0 from the quaternion and a constant
+     * centred rest shape (SURVEY.md 8(a) design note): identical in exact arithmetic, ~30% less tet-kernel traffic;
+     * rounding differs (tolerance-level).  Measured +4% tet-solves/s (the tet kernel is issue-bound).  Off by default: the benchmark measures the reference formulation. */
+    TETSIM_FLAG_CONSTANT_REST_SHAPE = 1u << 3
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */

@@ -66,6 +66,47 @@ def test_fast_tolerance(gather):
             assert err <= tol[step], (step, err)
 
 
+def test_constant_rest_shape_option():
+    """TETSIM_FLAG_CONSTANT_REST_SHAPE: R(q) * rest0 instead of the carried world-space shape.  Equal in exact
+    arithmetic, so it must sit inside the same FAST envelope against the oracle (which carries the shape, as the
+    reference does), stay close to the default formulation, and keep unit quaternions."""
+    v, t = load_mesh("dragon")
+    body, orc = _pair(v, t, precision="fast", constant_rest_shape=True)
+    ref = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    tol = {1: 2e-6, 20: 5e-5, 200: 2e-3}
+    for step in range(1, 201):
+        body.simulate(DT20, PP)
+        ref.simulate(DT20, PP)
+        orc.simulate(DT20, PP)
+        if step in tol:
+            assert np.abs(body.pos - orc.pos).max() <= tol[step], step
+            assert np.abs(body.pos - ref.pos).max() <= tol[step], step
+    assert np.abs(np.linalg.norm(body.quats, axis=1) - 1.0).max() < 1e-6
+    # graph path (step_n) and a partitioned body take the same kernels
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", constant_rest_shape=True)
+    a.simulateSubsteps(200, DT20, PP)
+    assert np.array_equal(a.pos, body.pos)
+    for kw in (dict(precision="precise"), dict(precision="fast", gather=True), dict(solver="neohookean")):
+        args = dict(solver="polar")
+        args.update(kw)
+        with pytest.raises(Exception, match="CONSTANT_REST_SHAPE"):
+            SoftBodyHIP(v, t, None, dict(PP), constant_rest_shape=True, **args)
+
+
+def test_constant_rest_shape_rigid_fall_keeps_edges():
+    """A rigid fall (no floor contact): both formulations keep edge lengths at their rest values to f32 position
+    rounding (measured 4e-6 for both at 100 substeps; the shape is re-derived, not carried, in the option)."""
+    v, t = make_lattice(8, y0=3.0)
+    e0 = np.linalg.norm(v[t[:, 0]] - v[t[:, 1]], axis=1)
+    for lean in (False, True):
+        body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", constant_rest_shape=lean, ref_slot_table=False)
+        body.simulateSubsteps(100, DT20, PP)
+        p = body.pos
+        assert p[:, 1].min() > 2.5
+        e1 = np.linalg.norm(p[t[:, 0]] - p[t[:, 1]], axis=1)
+        assert np.abs(e1 - e0).max() < 1e-5, lean
+
+
 def test_floor_grab_and_bounds():
     """Floor contact + friction + a dragged particle (grab at its current position, then 2 mm per substep, as a
     mouse drag does through startGrab/moveGrabbed, SoftbodyGPU.js:692-712)."""

@@ -13,7 +13,7 @@ OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
 PRECISE, FAST = 0, 1
 ORDER_ORIGINAL, ORDER_COLOURED = 0, 1
-FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION = 1, 2, 4
+FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE = 1, 2, 4, 8
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
 

@@ -63,6 +63,7 @@ struct PJBlk {
     float4* pos_final = nullptr;
     float4* vel = nullptr;
     const DevParams* params = nullptr;
+    bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
 

@@ -103,16 +103,16 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
         float4 q_new;
-        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u), !(dbg & 64u));
+        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u), !(dbg & 64u), (dbg & 128u) != 0u);
         TETSIM_STAMP(3);  // solved
-        if (dbg & 32u) {  // A/B: plain stores
+        if (dbg & 32u) {  // A/B: plain stores (development)
             d.quat[e] = q_new;
-            d.rest_a[e] = make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x);
+            if (!(dbg & 128u)) d.rest_a[e] = make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x);
             d.rest_b[e] = make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y);
             d.rest_c[e] = make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z);
         } else {
             store_wt(&d.quat[e], q_new);
-            if (!(dbg & 16u)) {
+            if (!(dbg & (16u | 128u))) {  // constant-rest-shape bodies never write the shape back
                 store_wt(&d.rest_a[e], make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
                 store_wt(&d.rest_b[e], make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
                 store_wt(&d.rest_c[e], make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
@@ -226,8 +226,9 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
         const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
         dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0) | ((np && np[0] == '1') ? 64 : 0);
     }
-    if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
-    else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, static_cast<uint32_t>(dbg));
+    const uint32_t mode = static_cast<uint32_t>(dbg) | (d.lean ? 128u : 0u);
+    if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, mode);
+    else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, mode);
 }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
     if (count == 0) return;

@@ -464,6 +464,8 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     };
 
     h->blocked = h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION);
+    if ((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && !h->blocked)
+        return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
     if (h->blocked) {
         BlockPlan B;
         build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
@@ -471,6 +473,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         PJBlk& k = h->blk;
         k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
+        k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
         uint32_t *bto, *bvo, *lcr, *vpe;
         int32_t* bv;
         uchar4* lidx;
@@ -498,9 +501,16 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const uint32_t lt = static_cast<uint32_t>(B.tet_perm[i]);
             const int32_t* c = &ltets[4 * lt];
             const float4 p0 = pos[c[0]], p1 = pos[c[1]], p2 = pos[c[2]], p3 = pos[c[3]];
-            ra[i] = make_float4(p0.x, p0.y, p0.z, p1.x);
-            rb[i] = make_float4(p1.y, p1.z, p2.x, p2.y);
-            rcv[i] = make_float4(p2.z, p3.x, p3.y, p3.z);
+            float4 r0 = p0, r1 = p1, r2 = p2, r3 = p3;
+            if (k.lean) {  // centred rest shape, with the arithmetic the kernel would use (f32, same association)
+                const float cx = (((p0.x + p1.x) + p2.x) + p3.x) * 0.25f, cy = (((p0.y + p1.y) + p2.y) + p3.y) * 0.25f,
+                            cz = (((p0.z + p1.z) + p2.z) + p3.z) * 0.25f;
+                r0 = make_float4(p0.x - cx, p0.y - cy, p0.z - cz, 0.0f); r1 = make_float4(p1.x - cx, p1.y - cy, p1.z - cz, 0.0f);
+                r2 = make_float4(p2.x - cx, p2.y - cy, p2.z - cz, 0.0f); r3 = make_float4(p3.x - cx, p3.y - cy, p3.z - cz, 0.0f);
+            }
+            ra[i] = make_float4(r0.x, r0.y, r0.z, r1.x);
+            rb[i] = make_float4(r1.y, r1.z, r2.x, r2.y);
+            rcv[i] = make_float4(r2.z, r3.x, r3.y, r3.z);
             volh[i] = rest_weight(lt);
             lidxh[i] = make_uchar4(B.tet_lidx[4ull * i], B.tet_lidx[4ull * i + 1], B.tet_lidx[4ull * i + 2], B.tet_lidx[4ull * i + 3]);
             const uint16_t* en = &B.lc_ent[4ull * i];
@@ -710,6 +720,8 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
         return fail(nullptr, TETSIM_ENODEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                                                    "); libtetsim_hip has no CPU fallback");
     if (o.device < 0 || o.device >= ndev) return fail(nullptr, TETSIM_ENODEVICE, "device ordinal out of range");
+    if ((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && o.solver != TETSIM_SOLVER_POLAR_JACOBI)
+        return fail(nullptr, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE applies to TETSIM_SOLVER_POLAR_JACOBI only");
 
     tetsim_body* h = new tetsim_body();
     h->opt = o;
