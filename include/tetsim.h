@@ -82,7 +82,12 @@ enum {
      * per substep, as the reference's textureElem does) but re-derive it as R(q) * rest0 from the quaternion and a constant
      * centred rest shape (SURVEY.md 8(a) design note): identical in exact arithmetic, ~30% less tet-kernel traffic;
      * rounding differs (tolerance-level).  Measured +4% tet-solves/s (the tet kernel is issue-bound).  Off by default: the benchmark measures the reference formulation. */
-    TETSIM_FLAG_CONSTANT_REST_SHAPE = 1u << 3
+    TETSIM_FLAG_CONSTANT_REST_SHAPE = 1u << 3,
+    /* POLAR_JACOBI: pin the particle(s) the reference's collision pass actually pins.  Its indexFromUV
+     * (SoftbodyGPU.js:335-338, "This isn't quite correct") maps texel (px,py) of the R x R position texture to
+     * int(uv.x*(R-1)) + int(uv.y*(R-1)*R), not to px + R*py, so `grabId` selects zero, one or two OTHER particles.
+     * Off by default (the library pins exactly grabId); on for bit-faithful replays of the reference's grab. */
+    TETSIM_FLAG_REF_GRAB_TEXEL = 1u << 4
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */
@@ -275,6 +280,9 @@ int tetsim_prep_colours(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *
  * ref_quirk != 0 reproduces the `<= 0.0` test.  Returns the number of dropped contributions. */
 int tetsim_prep_slot_table(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t ref_quirk,
                            int32_t *slots /*[nv*36]*/, uint32_t *dropped);
+/* The particle(s) SoftbodyGPU.js:335-338,345 pins for `grab_id` on a mesh with num_elems tets (texture side
+ * ceil(sqrt(num_elems))): out[0..1], -1 = none.  What TETSIM_FLAG_REF_GRAB_TEXEL uses. */
+int tetsim_prep_ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]);
 /* Rest data of Softbody.js:60-87 in JS number semantics: invMass[nv], invRestPose[9*nt] (column-major),
  * invRestVolume[nt]. */
 int tetsim_prep_rest(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt, double density,

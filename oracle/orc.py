@@ -63,6 +63,7 @@ def _load():
     lib.orc_pj_destroy.argtypes = [vp]
     lib.orc_pj_simulate.argtypes = [vp, C.c_double, C.POINTER(OrcParams)]
     lib.orc_pj_set_grab.argtypes = [vp, C.c_int, fp]
+    lib.orc_pj_set_ref_grab_texel.argtypes = [vp, C.c_int]
     for n in ("pos", "prev", "vel", "quat"):
         getattr(lib, "orc_pj_read_" + n).argtypes = [vp, fp]
     lib.orc_pj_read_elem.argtypes = [vp, C.c_int, fp]
@@ -177,13 +178,15 @@ class OracleNH(_Base):
 class OraclePJ(_Base):
     """Restatement of the reference `SoftBodyGPU` GLSL passes (SoftbodyGPU.js:59-376) -- physics only."""
 
-    def __init__(self, vertices, tetIds, physicsParams, slot_quirk=True):
+    def __init__(self, vertices, tetIds, physicsParams, slot_quirk=True, ref_grab_texel=False):
         super().__init__(vertices, tetIds)
         self._lib = _load()
         density = physicsParams.get("density", 1000.0) if isinstance(physicsParams, dict) else 1000.0
         self._h = self._lib.orc_pj_create(_fptr(self._verts), self.numParticles,
                                           self._tets.ctypes.data_as(C.POINTER(C.c_int32)), self.numElems,
                                           density, 1 if slot_quirk else 0)
+        # the reference's indexFromUV quirk (SoftbodyGPU.js:335-338): only for pinning against its golden vectors
+        self._lib.orc_pj_set_ref_grab_texel(self._h, 1 if ref_grab_texel else 0)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -16,8 +16,12 @@
  * Section G  "pj": shape-matching / polar-decomposition Jacobi -- follows the 7 GLSL passes
  *            /root/reference/src/SoftbodyGPU.js:59-376, the tables of :487-608 and the ping-pong
  *            semantics of /root/reference/src/MultiTargetGPUComputationRenderer.js:192-202,272-306.
- *            PARITY UNPINNED BY THE REFERENCE: the GLSL cannot run here (no WebGL) and the reference
- *            holds no golden data for it.  It is pinned only by this restatement + invariants.
+ *            PINNED against the reference RUN HERE: the reference's own SoftbodyGPU.js, pass scheduler and vendored
+ *            three.js execute under Node 12 with their GL calls served by Mesa's software rasteriser (softpipe,
+ *            IEEE f32; oracle/glsl_ref/, tests/golden/make_golden_gpu.sh).  Against those golden vectors this
+ *            restatement is bit-exact for the host tables and the first substep and tracks later substeps to
+ *            4e-5 m at 200-300 substeps (sin/rsqrt/division ulps of the GLSL implementation vs glibc feeding back);
+ *            tests/test_oracle_golden_glsl.py states the tolerance per horizon.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (see oracle/Makefile).
  * -ffp-contract=off matters: JS never fuses a*b+c, and the f32 section is meant to be plain IEEE.
@@ -385,6 +389,7 @@ typedef struct {
     int32_t *slots;       /* [nv][36] particleToElemVertsTable, -1 = empty */
     int grabId;
     float grabPos[3];
+    int ref_grab_texel;   /* 1: pin the texel(s) the reference's indexFromUV selects (SoftbodyGPU.js:335-338,345) */
     int biggestT;
     long long iter_hist[10];
 } OrcPJ;
@@ -563,15 +568,25 @@ void orc_pj_simulate(OrcPJ *s, double dt_js, const OrcParams *pp) {
         }
         s->cur_pos ^= 1;
     }
-    { /* P6 collision, :326-355.  Divergence (documented): the reference's indexFromUV (:335-338) is
-       * admittedly wrong and pins a different texel; the restatement pins exactly particle grabId. */
+    { /* P6 collision, :326-355.  The reference's indexFromUV (:335-338, "This isn't quite correct") maps a
+       * texel to int(uv.x*(R-1)) + int(uv.y*(R-1)*R), which is not the particle's index, so a different texel (or
+       * several, or none) is pinned.  Default: pin exactly particle grabId (what the library does, documented
+       * divergence).  ref_grab_texel: the reference's mapping, f32 operation by operation, R = texDim (:13). */
         const v3 *pos = s->pos[s->cur_pos], *prev = s->prev[s->cur_prev];
         v3 *out = s->pos[s->cur_pos ^ 1];
         const float fr = fminf(1.0f, dt * friction);
+        const int R = (int)ceil(sqrt((double)nt));
+        const float Rf = (float)R, Rm1 = Rf - 1.0f;
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < nv; i++) {
             v3 p = pos[i];
-            if (i == s->grabId) p = V3(s->grabPos[0], s->grabPos[1], s->grabPos[2]);
+            int grabbed = (i == s->grabId);
+            if (s->ref_grab_texel) {
+                const float ux = ((float)(i % R) + 0.5f) / Rf, uy = ((float)(i / R) + 0.5f) / Rf; /* gl_FragCoord.xy / resolution.xy */
+                const int idx = (int)(ux * Rm1) + (int)((uy * Rm1) * Rf);
+                grabbed = ((float)idx == (float)s->grabId);
+            }
+            if (grabbed) p = V3(s->grabPos[0], s->grabPos[1], s->grabPos[2]);
             p.x = fminf(fmaxf(p.x, -2.5f), 2.5f);
             p.y = fminf(fmaxf(p.y, -1.0f), 10.0f);
             p.z = fminf(fmaxf(p.z, -2.5f), 2.5f);
@@ -598,6 +613,7 @@ void orc_pj_simulate(OrcPJ *s, double dt_js, const OrcParams *pp) {
     }
 }
 
+void orc_pj_set_ref_grab_texel(OrcPJ *s, int on) { s->ref_grab_texel = on; }
 void orc_pj_set_grab(OrcPJ *s, int id, const float *xyz) {
     s->grabId = id;
     if (xyz) { s->grabPos[0] = xyz[0]; s->grabPos[1] = xyz[1]; s->grabPos[2] = xyz[2]; }

@@ -1,7 +1,8 @@
 """GPU parity, shape-matching polar-decomposition Jacobi (BASELINE configs 2, 3, 5), through the C ABI.
 
-The oracle is the GLSL-order CPU restatement (oracle/tetsim_oracle.c section G; parity UNPINNED by the
-reference: its WebGL passes cannot run here).  PRECISE mode performs the same IEEE f32 operations in the
+The oracle is the GLSL-order CPU restatement (oracle/tetsim_oracle.c section G), itself pinned to golden vectors
+recorded from the reference's WebGL passes (tests/test_oracle_golden_glsl.py); tests/test_gpu_polar_reference.py
+compares the device with those vectors directly.  PRECISE mode performs the same IEEE f32 operations in the
 same order; the only permitted difference is the last-ulp behaviour of sin() (device libm vs glibc).
 Tolerances are absolute position errors in metres, stated per horizon.
 """

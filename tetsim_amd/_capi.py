@@ -13,7 +13,7 @@ OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
 PRECISE, FAST = 0, 1
 ORDER_ORIGINAL, ORDER_COLOURED = 0, 1
-FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE = 1, 2, 4, 8
+FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE, FLAG_REF_GRAB_TEXEL = 1, 2, 4, 8, 16
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
 
@@ -63,7 +63,7 @@ SYMBOLS = [
     "tetsim_start_grab", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
-    "tetsim_prep_slot_table", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
+    "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
 ]
 
@@ -122,6 +122,7 @@ def lib():
     L.tetsim_prep_levels.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_colours.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
+    L.tetsim_prep_ref_grab_texels.argtypes = [i32, u32, u32, ip]
     L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]
     L.tetsim_plan_create.argtypes = [ip, u32, u32, i32, i32, ip, C.POINTER(H)]
     L.tetsim_plan_destroy.argtypes = [H]

@@ -16,6 +16,8 @@ struct DevParams {
     float hi[3], pad2;
     float grab[3];
     int32_t grab_local;  // local vertex index, -1 = none
+    int32_t grab_local2; // second pinned particle (TETSIM_FLAG_REF_GRAB_TEXEL can select two), -1 = none
+    int32_t pad3[3];
     // f64 view -- NEOHOOKEAN_GS: JS numbers (Softbody.js:195-240)
     double d_dt, d_gravity, d_friction, d_dev_compliance, d_vol_compliance;
     double d_lo[3], d_hi[3];

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first,
 
     // P6, :340-355
     const f3 prev = xyz(d.pos_final[v]);
-    if (static_cast<int32_t>(v) == P.grab_local) p = F3(P.grab[0], P.grab[1], P.grab[2]);
+    if (static_cast<int32_t>(v) == P.grab_local || static_cast<int32_t>(v) == P.grab_local2) p = F3(P.grab[0], P.grab[1], P.grab[2]);
     p.x = fminf(fmaxf(p.x, P.lo[0]), P.hi[0]);
     p.y = fminf(fmaxf(p.y, P.lo[1]), P.hi[1]);
     p.z = fminf(fmaxf(p.z, P.lo[2]), P.hi[2]);

@@ -88,6 +88,7 @@ struct tetsim_body {
     bool ring_used[kRing] = {};
     int ring_pos = 0;
     int32_t grab_global = -1;
+    int32_t grab_ref[2] = {-1, -1};  // particles the reference's indexFromUV pins for grab_global (TETSIM_FLAG_REF_GRAB_TEXEL)
     float grab_pos[3] = {0, 0, 0};
     std::map<uint32_t, hipGraphExec_t> graphs;
     std::vector<void*> allocs;
@@ -162,6 +163,29 @@ int upload(tetsim_body* h, Tp* dst, const std::vector<Tp>& src) {
     return 0;
 }
 
+// SoftbodyGPU.js:335-338,345: texel (px,py) of the R x R position texture is pinned when
+// float(int(uv.x*(R-1)) + int(uv.y*(R-1)*R)) == grabId with uv = (px+.5, py+.5)/R, all in f32.  Rows cannot collide
+// (the y term advances by R-1 per row and the x term is below R-1), columns px and px+1 can.
+void ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]) {
+    out[0] = out[1] = -1;
+    if (grab_id < 0) return;
+    const int R = static_cast<int>(std::ceil(std::sqrt(static_cast<double>(num_elems))));
+    const float Rf = static_cast<float>(R), Rm1 = Rf - 1.0f;
+    int n = 0;
+    for (int py = 0; py < R && n < 2; py++) {
+        const float uy = (static_cast<float>(py) + 0.5f) / Rf;
+        const int row = static_cast<int>((uy * Rm1) * Rf);
+        const int a = grab_id - row;
+        if (a < 0 || a >= R) continue;
+        for (int px = std::max(0, a - 1); px <= std::min(R - 1, a + 1) && n < 2; px++) {
+            const float ux = (static_cast<float>(px) + 0.5f) / Rf;
+            const int idx = static_cast<int>(ux * Rm1) + row;
+            const int64_t particle = static_cast<int64_t>(py) * R + px;
+            if (static_cast<float>(idx) == static_cast<float>(grab_id) && particle < static_cast<int64_t>(num_particles)) out[n++] = static_cast<int32_t>(particle);
+        }
+    }
+}
+
 void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevParams* o) {
     std::memset(o, 0, sizeof(*o));
     o->dt = static_cast<float>(dt);
@@ -176,12 +200,20 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
         o->d_hi[c] = p.worldBounds[3 + c];
         o->grab[c] = h->grab_pos[c];
     }
-    o->grab_local = -1;
-    if (h->grab_global >= 0) {
+    auto to_device = [&](int32_t global) -> int32_t {
+        if (global < 0) return -1;
         int32_t a = -1;  // API-local index
-        if (!h->partitioned) a = h->grab_global;
-        else if (static_cast<size_t>(h->grab_global) < h->g2l_owned.size()) a = h->g2l_owned[h->grab_global];
-        if (a >= 0) o->grab_local = h->api2dev.empty() ? a : static_cast<int32_t>(h->api2dev[a]);
+        if (!h->partitioned) a = global;
+        else if (static_cast<size_t>(global) < h->g2l_owned.size()) a = h->g2l_owned[global];
+        if (a < 0) return -1;
+        return h->api2dev.empty() ? a : static_cast<int32_t>(h->api2dev[a]);
+    };
+    o->grab_local = o->grab_local2 = -1;
+    if (h->grab_global >= 0) {
+        if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI && (h->opt.flags & TETSIM_FLAG_REF_GRAB_TEXEL)) {
+            o->grab_local = to_device(h->grab_ref[0]);
+            o->grab_local2 = to_device(h->grab_ref[1]);
+        } else o->grab_local = to_device(h->grab_global);
     }
     o->d_dt = dt;
     o->d_gravity = p.gravity;
@@ -1022,6 +1054,7 @@ int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {
     if (!h) return TETSIM_EINVAL;
     if (id >= static_cast<int32_t>(h->info.num_particles)) return fail(h, TETSIM_EINVAL, "grab id out of range");
     h->grab_global = id < 0 ? -1 : id;
+    ref_grab_texels(h->grab_global, h->info.num_elems, h->info.num_particles, h->grab_ref);
     if (xyz) std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
     return 0;
 }
@@ -1051,6 +1084,7 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
     for (uint32_t b = 0; b < nblk; b++)  // blocks are in ascending particle order: `<` keeps the first minimum
         if (bd[b] < best) { best = bd[b]; id = static_cast<int32_t>(bi[b]); }
     h->grab_global = id;
+    ref_grab_texels(h->grab_global, h->info.num_elems, h->info.num_particles, h->grab_ref);
     std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
     if (id_out) *id_out = id;
     return 0;
@@ -1366,6 +1400,11 @@ int tetsim_prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, int32_
     if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
     const uint32_t d = prep_slot_table(tets, nt, nv, ref_quirk != 0, slots);
     if (dropped) *dropped = d;
+    return 0;
+}
+int tetsim_prep_ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]) {
+    if (!out) return TETSIM_EINVAL;
+    ref_grab_texels(grab_id, num_elems, num_particles, out);
     return 0;
 }
 int tetsim_prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, double density, float* inv_mass, float* inv_rest_pose, float* inv_rest_volume) {
