@@ -10,14 +10,15 @@
 // the body is headless (physics only; edgeMesh / visMesh stay null).
 //
 // Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
-//     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured', device: 0 }
+//     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured', device: 0,
+//       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false }   (include/tetsim.h flags)
 // default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
 const path = require('path');
 
 const SOLVER = { polar: 0, neohookean: 1 };
 const PRECISION = { precise: 0, fast: 1 };
 const ORDER = { original: 0, coloured: 1 };
-const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2;
+const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2, FLAG_GATHER_FORMULATION = 4, FLAG_CONSTANT_REST_SHAPE = 8, FLAG_REF_GRAB_TEXEL = 16;
 
 let addon = null;
 function loadTetSim(libPath) {
@@ -45,7 +46,10 @@ class SoftBodyHIP {
         const tets32 = tetIds instanceof Int32Array ? tetIds : Int32Array.from(tetIds);
         this._h = api.create(verts32, tets32, {
             solver: SOLVER[this._solver], precision: PRECISION[opt.precision || 'precise'], order: ORDER[opt.order || 'original'],
-            flags: FLAG_REF_SLOT_TABLE | FLAG_REF_FIXED_BOUNDS, device: opt.device || 0,
+            flags: (opt.refSlotTable === false ? 0 : FLAG_REF_SLOT_TABLE) | (opt.refFixedBounds === false ? 0 : FLAG_REF_FIXED_BOUNDS) |
+                   (opt.gather ? FLAG_GATHER_FORMULATION : 0) | (opt.constantRestShape ? FLAG_CONSTANT_REST_SHAPE : 0) |
+                   (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0),
+            device: opt.device || 0,
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
         });
         this._dirty = false;

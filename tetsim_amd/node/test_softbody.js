@@ -57,4 +57,35 @@ body.endGrab();
 for (let i = 0; i < body.pos.length; i++) assert.ok(Number.isFinite(body.pos[i]));
 console.log('polar/fast: 5 frames x 20 substeps + grab ok; info', JSON.stringify(body.info()));
 body.dispose();
+
+// 3. SoftbodyGPU.js mirror against golden vectors recorded from the reference's own GLSL passes (tests/golden/make_golden_gpu.*):
+//    reference-faithful flags, the mouse-drag case, tolerances of tests/test_gpu_polar_reference.py
+{
+    const cases = JSON.parse(fs.readFileSync(path.join(G, 'cases_gpu.json')));
+    const gold = JSON.parse(fs.readFileSync(path.join(G, 'golden_gpu.json'))).cases;
+    const c = cases.find(x => x.name === 'dragon_grab'), gc = gold.dragon_grab;
+    const tol = { 10: 1e-5, 60: 1e-4 };
+    const p2 = Object.assign({ timeScale: c.timeScale, timeStep: c.timeStep, numSubsteps: c.numSubsteps }, c.params);
+    p2.tetsim = { solver: 'polar', precision: 'precise', refGrabTexel: true };
+    const b = new SoftBodyHIP(verts.slice(0), tets, [], p2, new Float32Array(0), [], null, {});
+    let start = null;
+    for (let step = 1; step <= c.nsteps; step++) {
+        for (const ev of c.grab) {
+            if (ev.at !== step) continue;
+            if (ev.op === 'start_id') { start = gc.grabStartPos; b.grabId = ev.id; b.moveGrabbed({ x: start[0], y: start[1], z: start[2] }); }
+            else if (ev.op === 'move_rel') b.moveGrabbed({ x: start[0] + ev.d[0], y: start[1] + ev.d[1], z: start[2] + ev.d[2] });
+            else if (ev.op === 'end') b.endGrab();
+        }
+        b.simulate(gc.dt, p2);
+        if (c.dumps.includes(step)) {
+            b.endFrame();
+            const want = f32(`dragon_grab_gpu_pos_${step}.f32`);
+            let err = 0;
+            for (let i = 0; i < want.length; i++) err = Math.max(err, Math.abs(b.pos[i] - want[i]));
+            assert.ok(err <= tol[step], `polar/precise vs reference GLSL at substep ${step}: ${err}`);
+            console.log(`polar/precise vs reference GLSL goldens, substep ${step}: max |dx| = ${err.toExponential(2)} m`);
+        }
+    }
+    b.dispose();
+}
 console.log('node boundary ok');
