@@ -20,7 +20,11 @@
 // during tile i's solve, with scalar tile headers, a 3-deep index pipeline, a peeled first trip and counted
 // vmcnt waits: 49 us vs 42-44 us, its 0-iteration base is already slower (32.5 vs 28.5 us); (b) having the particle
 // pass scatter positions into the tile cells (no staging gather here): tet kernel 40.9 us but the particle pass
-// 9.8 -> 18.7 us; (c) staggering the first round of workgroups with s_sleep: strictly slower.
+// 9.8 -> 18.7 us; (c) staggering the first round of workgroups with s_sleep: strictly slower; (d) two tets per lane on
+// packed f32 (every add/mul/fma a v_pk_*_f32, 128-thread workgroups, 114 VGPRs, no spills): the rotation loop got 14 %
+// cheaper (1.37 vs 1.60 us per iteration) but the 0-iteration base 1.2 us dearer, 37.9 vs 35.0 us overall.  On gfx950 a
+// wave64 v_pk_fma_f32 issues in 4.8 cycles against 2.8 for v_fma_f32 (tools/micro/valu_rate.hip,
+// profiles/r01e_valu_issue_rates.txt): packing buys at most 16 % of f32 throughput, not 2x.
 //
 // Result differs from the gather formulation only by summation order (tile partials) -- tolerance-level, FAST
 // mode only; PRECISE keeps the reference's slot order.
