@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TETSIM_ABI_VERSION 1
+#define TETSIM_ABI_VERSION 2
 
 typedef struct tetsim_body *tetsim_handle;
 
@@ -112,6 +112,10 @@ typedef struct TetSimOptions {
     int32_t part_count;
     int32_t part_index;
     const int32_t *vert_owner;
+    /* NEOHOOKEAN_GS + TETSIM_ORDER_COLOURED: a caller-supplied colour per tet, [num_elems], or NULL for the built-in greedy
+     * colouring.  ANY labelling is safe: the solve order is "stable sort by colour", and the parallel levels are derived
+     * from that order's true dependencies, so a poor colouring costs speed, never correctness (since ABI 2). */
+    const int32_t *tet_colour;
 } TetSimOptions;
 
 typedef struct TetSimInfo {
@@ -309,6 +313,39 @@ int tetsim_plan_neighbour(tetsim_plan p, uint32_t i, int32_t *rank, uint32_t *se
 int tetsim_plan_neighbour_ids(tetsim_plan p, uint32_t i, int32_t *send_local, int32_t *send_global, int32_t *recv_global);
 
 int tetsim_abi_version(void);
+
+/* --- .tetsim mesh container (GPU-free except tetsim_create_from_file) ---------------------------
+ * The five arrays of the reference's Dragon.js (:1 verts, :311 tetIds, :1080 tetEdgeIds, :1705 attachedVerts
+ * [tetNr,b0,b1,b2], :11640 attachedTriIds) as raw little-endian sections of one mmap-able file, plus optional
+ * preprocessing: a tet colouring and a vertex->partition map.  Layout in tetsim_amd/csrc/mesh_file.cpp. */
+typedef struct TetSimMeshArrays {
+    uint32_t num_particles;      /* verts        [3 * num_particles] f32  (required) */
+    uint32_t num_elems;          /* tets         [4 * num_elems]     i32  (required, may be empty) */
+    uint32_t num_edges;          /* edge_ids     [2 * num_edges]     i32  or NULL */
+    uint32_t num_vis_verts;      /* vis_verts    [4 * num_vis_verts] f32  or NULL */
+    uint32_t num_vis_tris;       /* vis_tri_ids  [3 * num_vis_tris]  i32  or NULL */
+    uint32_t part_count;         /* partitions addressed by vert_owner (0 when absent) */
+    const float *verts;
+    const int32_t *tets;
+    const int32_t *edge_ids;
+    const float *vis_verts;
+    const int32_t *vis_tri_ids;
+    const int32_t *tet_colour;   /* [num_elems] or NULL */
+    const int32_t *vert_owner;   /* [num_particles], values in [0, part_count), or NULL */
+} TetSimMeshArrays;
+typedef struct tetsim_mesh_file *tetsim_mesh;
+
+/* Write `a` to `path` (atomically: temp file + rename). */
+int tetsim_mesh_write(const char *path, const TetSimMeshArrays *a);
+/* Map a file read-only and validate it (magic, version, bounds, index ranges).  The arrays returned by
+ * tetsim_mesh_arrays point INTO the mapping and stay valid until tetsim_mesh_close. */
+int tetsim_mesh_open(const char *path, tetsim_mesh *out);
+int tetsim_mesh_arrays(tetsim_mesh m, TetSimMeshArrays *out);
+int tetsim_mesh_close(tetsim_mesh m);
+/* tetsim_create from a file: vertices/tets from the mapping; a stored colouring is used when opts->tet_colour is NULL
+ * and the solver/order take one; a stored partition map is used when opts->part_count > 1, opts->vert_owner is NULL
+ * and the stored part_count matches; a stored visual mesh is attached (tetsim_set_visual_mesh) on unpartitioned bodies. */
+int tetsim_create_from_file(const char *path, const TetSimOptions *opts, tetsim_handle *out);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.tetsim_abi_version() == 1
+    assert L.tetsim_abi_version() == 2
 
 
 def test_no_cpu_fallback():

@@ -28,8 +28,8 @@ def test_addon_loads_and_fails_loudly_without_gpu():
           "catch(e){console.log('THROWN '+e.message);}") % (os.path.join(NODE_DIR, "tetsim_napi.node"),
                                                          os.path.join(ROOT, "tetsim_amd", "libtetsim_hip.so"))
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120).stdout
-    assert "KEYS create,destroy,info,load,mapPositions,readPositions,readQuats,readVelocities,readVisualMesh,readVolError,refreshPositions,setGrab,setVisualMesh,startGrab,step,stepN,sync" in out
-    assert "ABI 1" in out
+    assert "KEYS create,createFromFile,destroy,info,load,mapPositions,readMesh,readPositions,readQuats,readVelocities,readVisualMesh,readVolError,refreshPositions,setGrab,setVisualMesh,startGrab,step,stepN,sync" in out
+    assert "ABI 2" in out
     assert "CREATED" in out or "no CPU fallback" in out  # on a GPU host creation succeeds; otherwise it must throw
 
 
@@ -39,6 +39,14 @@ def test_softbodyhip_js_bit_exact_vs_reference_goldens():
     """SoftBodyHIP.js (reference constructor + simulate/endFrame/grab surface) over N-API on the GPU:
     Neo-Hookean PRECISE == Softbody.js goldens bit for bit; polar frame loop + grab."""
     _addon()
-    r = subprocess.run([NODE, os.path.join(NODE_DIR, "test_softbody.js")], capture_output=True, text=True, timeout=600)
+    import tempfile
+    from conftest import load_f32, load_mesh
+    from tetsim_amd.meshfile import write_mesh
+    with tempfile.TemporaryDirectory() as tmp:   # a .tetsim container for SoftBodyHIP.fromFile (SURVEY.md 8(f)-3)
+        v, t = load_mesh("dragon")
+        mesh = os.path.join(tmp, "dragon.tetsim")
+        write_mesh(mesh, v, t, vis_verts=load_f32("dragon_vis.f32"))
+        r = subprocess.run([NODE, os.path.join(NODE_DIR, "test_softbody.js")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TETSIM_TEST_MESH=mesh))
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "node boundary ok" in r.stdout
+    assert "node boundary ok" in r.stdout and "fromFile" in r.stdout

@@ -25,7 +25,15 @@ class TetSimParams(C.Structure):
 class TetSimOptions(C.Structure):
     _fields_ = [("solver", C.c_int32), ("precision", C.c_int32), ("order", C.c_int32), ("flags", C.c_uint32),
                 ("device", C.c_int32), ("density", C.c_double), ("part_count", C.c_int32),
-                ("part_index", C.c_int32), ("vert_owner", C.POINTER(C.c_int32))]
+                ("part_index", C.c_int32), ("vert_owner", C.POINTER(C.c_int32)), ("tet_colour", C.POINTER(C.c_int32))]
+
+
+class TetSimMeshArrays(C.Structure):
+    _fields_ = [("num_particles", C.c_uint32), ("num_elems", C.c_uint32), ("num_edges", C.c_uint32),
+                ("num_vis_verts", C.c_uint32), ("num_vis_tris", C.c_uint32), ("part_count", C.c_uint32),
+                ("verts", C.POINTER(C.c_float)), ("tets", C.POINTER(C.c_int32)), ("edge_ids", C.POINTER(C.c_int32)),
+                ("vis_verts", C.POINTER(C.c_float)), ("vis_tri_ids", C.POINTER(C.c_int32)),
+                ("tet_colour", C.POINTER(C.c_int32)), ("vert_owner", C.POINTER(C.c_int32))]
 
 
 class TetSimInfo(C.Structure):
@@ -65,6 +73,7 @@ SYMBOLS = [
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
     "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
+    "tetsim_mesh_write", "tetsim_mesh_open", "tetsim_mesh_arrays", "tetsim_mesh_close", "tetsim_create_from_file",
 ]
 
 _lib = None
@@ -90,6 +99,11 @@ def lib():
     L.tetsim_create.argtypes = [fp, u32, ip, u32, C.POINTER(TetSimOptions), C.POINTER(H)]
     L.tetsim_destroy.argtypes = [H]
     L.tetsim_destroy.restype = None
+    L.tetsim_mesh_write.argtypes = [C.c_char_p, C.POINTER(TetSimMeshArrays)]
+    L.tetsim_mesh_open.argtypes = [C.c_char_p, C.POINTER(H)]
+    L.tetsim_mesh_arrays.argtypes = [H, C.POINTER(TetSimMeshArrays)]
+    L.tetsim_mesh_close.argtypes = [H]
+    L.tetsim_create_from_file.argtypes = [C.c_char_p, C.POINTER(TetSimOptions), C.POINTER(H)]
     L.tetsim_last_error.argtypes = [H]
     L.tetsim_last_error.restype = C.c_char_p
     L.tetsim_get_info.argtypes = [H, C.POINTER(TetSimInfo)]

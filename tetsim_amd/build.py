@@ -24,6 +24,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-paramet
           f"--offload-arch={ARCH}"]
 UNITS = {
     "host_prep.cpp": ["-ffp-contract=off", "-x", "hip"],
+    "mesh_file.cpp": ["-ffp-contract=off", "-x", "hip"],
     "tetsim_api.hip": ["-ffp-contract=off"],
     "pj_precise.hip": ["-ffp-contract=off"],
     "pj_fast.hip": ["-ffp-contract=fast"],
@@ -33,7 +34,7 @@ UNITS = {
     "util_kernels.hip": ["-ffp-contract=off"],
     "skin_kernels.hip": ["-ffp-contract=off"],
 }
-HEADERS = ["dev_common.h", "host_prep.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
+HEADERS = ["dev_common.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
 
 
 def _newest(paths):

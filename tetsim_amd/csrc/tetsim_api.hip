@@ -19,6 +19,7 @@
 #include "../../include/tetsim.h"
 #include "dev_common.h"
 #include "host_prep.h"
+#include "mesh_file.h"
 
 using namespace tetsim;
 
@@ -87,6 +88,7 @@ struct tetsim_body {
     hipEvent_t ring_ev[kRing] = {};
     bool ring_used[kRing] = {};
     int ring_pos = 0;
+    std::vector<int32_t> tet_colour;  // copy of TetSimOptions.tet_colour (create only)
     int32_t grab_global = -1;
     int32_t grab_ref[2] = {-1, -1};  // particles the reference's indexFromUV pins for grab_global (TETSIM_FLAG_REF_GRAB_TEXEL)
     float grab_pos[3] = {0, 0, 0};
@@ -635,7 +637,8 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     for (uint32_t e = 0; e < nt; e++) pre[e] = static_cast<int32_t>(e);
     if (o.order == TETSIM_ORDER_COLOURED) {
         std::vector<int32_t> colour(nt);
-        prep_colours(tets, nt, nv, colour.data());
+        if (h->tet_colour.size() == nt) colour = h->tet_colour;  // caller-supplied (TetSimOptions.tet_colour)
+        else prep_colours(tets, nt, nv, colour.data());
         std::stable_sort(pre.begin(), pre.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
     }
     std::vector<int32_t> ptets(4ull * nt);
@@ -709,6 +712,60 @@ extern "C" {
 
 int tetsim_abi_version(void) { return TETSIM_ABI_VERSION; }
 
+// ---- .tetsim mesh container ---------------------------------------------------------------------------------------
+struct tetsim_mesh_file { tetsim::MeshFile* m; };
+
+int tetsim_mesh_write(const char* path, const TetSimMeshArrays* a) {
+    if (!a) return fail(nullptr, TETSIM_EINVAL, "arrays is null");
+    const std::string e = mesh_write(path, *a);
+    return e.empty() ? TETSIM_OK : fail(nullptr, TETSIM_EINVAL, e);
+}
+int tetsim_mesh_open(const char* path, tetsim_mesh* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "out is null");
+    *out = nullptr;
+    tetsim::MeshFile* m = nullptr;
+    const std::string e = mesh_open(path, &m);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *out = new tetsim_mesh_file{m};
+    return TETSIM_OK;
+}
+int tetsim_mesh_arrays(tetsim_mesh m, TetSimMeshArrays* out) {
+    if (!m || !out) return fail(nullptr, TETSIM_EINVAL, "null argument");
+    *out = mesh_arrays(m->m);
+    return TETSIM_OK;
+}
+int tetsim_mesh_close(tetsim_mesh m) {
+    if (!m) return TETSIM_OK;
+    mesh_close(m->m);
+    delete m;
+    return TETSIM_OK;
+}
+int tetsim_create_from_file(const char* path, const TetSimOptions* opts, tetsim_handle* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "out handle pointer is null");
+    *out = nullptr;
+    tetsim::MeshFile* m = nullptr;
+    const std::string e = mesh_open(path, &m);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    const TetSimMeshArrays& a = mesh_arrays(m);
+    TetSimOptions o;
+    if (opts) o = *opts; else tetsim_default_options(&o);
+    if (!o.tet_colour && a.tet_colour && o.solver == TETSIM_SOLVER_NEOHOOKEAN_GS && o.order == TETSIM_ORDER_COLOURED) o.tet_colour = a.tet_colour;
+    if (o.part_count > 1 && !o.vert_owner && a.vert_owner) {
+        if (static_cast<uint32_t>(o.part_count) != a.part_count) {
+            mesh_close(m);
+            return fail(nullptr, TETSIM_EINVAL, std::string(path) + ": stored partition map is for " + std::to_string(a.part_count) + " parts, " + std::to_string(o.part_count) + " requested");
+        }
+        o.vert_owner = a.vert_owner;
+    }
+    int rc = tetsim_create(a.verts, a.num_particles, a.tets, a.num_elems, &o, out);
+    if (rc == TETSIM_OK && a.vis_verts && a.num_vis_verts && o.part_count <= 1) {
+        rc = tetsim_set_visual_mesh(*out, a.vis_verts, a.num_vis_verts, nullptr);
+        if (rc != TETSIM_OK) { g_create_error = (*out)->err; tetsim_destroy(*out); *out = nullptr; }
+    }
+    mesh_close(m);  // create copied what it keeps
+    return rc;
+}
+
 void tetsim_default_options(TetSimOptions* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
@@ -721,6 +778,7 @@ void tetsim_default_options(TetSimOptions* o) {
     o->part_count = 1;
     o->part_index = 0;
     o->vert_owner = nullptr;
+    o->tet_colour = nullptr;
 }
 
 void tetsim_default_params(TetSimParams* p) {  // main.js:22-36
@@ -758,6 +816,8 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     tetsim_body* h = new tetsim_body();
     h->opt = o;
     h->opt.vert_owner = nullptr;  // not retained
+    if (o.tet_colour && nt) h->tet_colour.assign(o.tet_colour, o.tet_colour + nt);
+    h->opt.tet_colour = nullptr;
     h->fast = o.precision == TETSIM_FAST;
     h->info.num_particles = nv;
     h->info.num_elems = nt;

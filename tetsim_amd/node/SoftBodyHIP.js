@@ -29,7 +29,7 @@ function loadTetSim(libPath) {
 }
 
 class SoftBodyHIP {
-    constructor(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial, world) {
+    constructor(vertices, tetIds, tetEdgeIds, physicsParams, visVerts, visTriIds, visMaterial, world, _meshFile) {
         const api = loadTetSim();
         this.physicsParams = physicsParams || {};
         const opt = this.physicsParams.tetsim || {};
@@ -44,14 +44,16 @@ class SoftBodyHIP {
         this._solver = opt.solver || 'polar';
         const verts32 = vertices instanceof Float32Array ? vertices : Float32Array.from(vertices);
         const tets32 = tetIds instanceof Int32Array ? tetIds : Int32Array.from(tetIds);
-        this._h = api.create(verts32, tets32, {
+        const createOptions = {
             solver: SOLVER[this._solver], precision: PRECISION[opt.precision || 'precise'], order: ORDER[opt.order || 'original'],
             flags: (opt.refSlotTable === false ? 0 : FLAG_REF_SLOT_TABLE) | (opt.refFixedBounds === false ? 0 : FLAG_REF_FIXED_BOUNDS) |
                    (opt.gather ? FLAG_GATHER_FORMULATION : 0) | (opt.constantRestShape ? FLAG_CONSTANT_REST_SHAPE : 0) |
                    (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0),
             device: opt.device || 0,
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
-        });
+        };
+        // fromFile: the library maps the .tetsim container itself (and picks up a stored colouring / visual mesh)
+        this._h = _meshFile ? api.createFromFile(_meshFile, createOptions) : api.create(verts32, tets32, createOptions);
         this._dirty = false;
         this._visOnDevice = false;
 
@@ -61,8 +63,8 @@ class SoftBodyHIP {
         this.visMesh = null;
         this.visVerts = visVerts || new Float32Array(0);
         this.numVisVerts = this.visVerts.length / 4;
-        if (this.numVisVerts > 0) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1)
-            api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
+        if (this.numVisVerts > 0) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1); createFromFile attached it already
+            if (!_meshFile) api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
             this._visOnDevice = true;
         }
         if (THREE) {
@@ -84,6 +86,14 @@ class SoftBodyHIP {
             geometry.computeVertexNormals();
             this.updateVisMesh();
         }
+    }
+
+    // Build the body from a .tetsim container (SURVEY.md §8(f)-3: the five Dragon.js arrays as raw sections of one
+    // mmap-able file, see tetsim_amd/meshfile.py / include/tetsim.h) instead of parsing 2.4 MB of array literals.
+    static fromFile(path, physicsParams, visMaterial, world) {
+        const m = loadTetSim().readMesh(path);
+        return new SoftBodyHIP(m.vertices, m.tetIds, m.tetEdgeIds || [], physicsParams, m.visVerts || new Float32Array(0),
+                               m.visTriIds || [], visMaterial, world, path);
     }
 
     // ---- the hot path ------------------------------------------------------------------------------------------

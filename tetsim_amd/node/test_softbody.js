@@ -88,4 +88,16 @@ body.dispose();
     }
     b.dispose();
 }
+// 4. SoftBodyHIP.fromFile: the same body from a .tetsim container (written by tests/test_node_boundary.py)
+if (process.env.TETSIM_TEST_MESH) {
+    const p4 = Object.assign({}, pp, { numSubsteps: 10, tetsim: { solver: 'neohookean', precision: 'precise' } });
+    const b = SoftBodyHIP.fromFile(process.env.TETSIM_TEST_MESH, p4, null, null);
+    assert.strictEqual(b.numParticles, 1234); assert.strictEqual(b.numElems, 3840); assert.strictEqual(b.numVisVerts, 29800);
+    for (let step = 1; step <= 10; step++) b.simulate(dt, p4);
+    b.endFrame();
+    assert.strictEqual(bitsEqual(b.pos, f32('dragon_pos_10.f32')), -1, 'fromFile body differs from Softbody.js at substep 10');
+    assert.strictEqual(bitsEqual(b.readVisualPositions(), f32('dragon_vispos_10.f32')), -1, 'fromFile visual mesh differs');
+    b.dispose();
+    console.log('fromFile: .tetsim container -> bit-exact vs Softbody.js goldens (positions + 29,800 skinned vertices)');
+}
 console.log('node boundary ok');

@@ -39,6 +39,10 @@ struct Api {
     decltype(&tetsim_set_grab) set_grab = nullptr;
     decltype(&tetsim_start_grab) start_grab = nullptr;
     decltype(&tetsim_abi_version) abi_version = nullptr;
+    decltype(&tetsim_mesh_open) mesh_open = nullptr;
+    decltype(&tetsim_mesh_arrays) mesh_arrays = nullptr;
+    decltype(&tetsim_mesh_close) mesh_close = nullptr;
+    decltype(&tetsim_create_from_file) create_from_file = nullptr;
     std::string err;
 } g;
 
@@ -56,6 +60,7 @@ bool load_lib(const std::string& hint) {
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(abi_version, "tetsim_abi_version")
+    SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
 #undef SYM
     if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
     return true;
@@ -139,6 +144,7 @@ napi_value Load(napi_env env, napi_callback_info info) {
 }
 
 // create(Float32Array verts, Int32Array tets, {solver, precision, order, flags, device, density}) -> handle
+void options_of(napi_env env, napi_value obj, TetSimOptions* o);
 napi_value Create(napi_env env, napi_callback_info info) {
     napi_value a[3];
     if (!get_args(env, info, 3, a)) return nullptr;
@@ -148,14 +154,7 @@ napi_value Create(napi_env env, napi_callback_info info) {
     if (!typed_array(env, a[1], napi_int32_array, &tets, &ntf)) return throw_err(env, "tetIds must be an Int32Array");
     if (nvf % 3 || ntf % 4) return throw_err(env, "vertices need 3 floats per particle, tetIds 4 ids per tet");
     TetSimOptions o;
-    g.default_options(&o);
-    double d;
-    if (get_double(env, a[2], "solver", &d)) o.solver = static_cast<int32_t>(d);
-    if (get_double(env, a[2], "precision", &d)) o.precision = static_cast<int32_t>(d);
-    if (get_double(env, a[2], "order", &d)) o.order = static_cast<int32_t>(d);
-    if (get_double(env, a[2], "flags", &d)) o.flags = static_cast<uint32_t>(d);
-    if (get_double(env, a[2], "device", &d)) o.device = static_cast<int32_t>(d);
-    if (get_double(env, a[2], "density", &d)) o.density = d;
+    options_of(env, a[2], &o);
     tetsim_handle h = nullptr;
     const int rc = g.create(verts, static_cast<uint32_t>(nvf / 3), tets, static_cast<uint32_t>(ntf / 4), &o, &h);
     if (rc != TETSIM_OK) return check(env, rc, nullptr);
@@ -163,6 +162,71 @@ napi_value Create(napi_env env, napi_callback_info info) {
     napi_value ext;
     napi_create_external(env, hp, finalize_handle, nullptr, &ext);
     return ext;
+}
+// options object -> TetSimOptions (shared by create / createFromFile)
+void options_of(napi_env env, napi_value obj, TetSimOptions* o) {
+    g.default_options(o);
+    double d;
+    if (get_double(env, obj, "solver", &d)) o->solver = static_cast<int32_t>(d);
+    if (get_double(env, obj, "precision", &d)) o->precision = static_cast<int32_t>(d);
+    if (get_double(env, obj, "order", &d)) o->order = static_cast<int32_t>(d);
+    if (get_double(env, obj, "flags", &d)) o->flags = static_cast<uint32_t>(d);
+    if (get_double(env, obj, "device", &d)) o->device = static_cast<int32_t>(d);
+    if (get_double(env, obj, "density", &d)) o->density = d;
+}
+// createFromFile(path, options) -> handle      (tetsim_create_from_file: the library maps the .tetsim container itself)
+napi_value CreateFromFile(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    char path[4096]; size_t n = 0;
+    if (napi_get_value_string_utf8(env, a[0], path, sizeof path, &n) != napi_ok) return throw_err(env, "path must be a string");
+    TetSimOptions o;
+    options_of(env, a[1], &o);
+    tetsim_handle h = nullptr;
+    const int rc = g.create_from_file(path, &o, &h);
+    if (rc != TETSIM_OK) return check(env, rc, nullptr);
+    tetsim_handle* hp = new tetsim_handle(h);
+    napi_value ext;
+    napi_create_external(env, hp, finalize_handle, nullptr, &ext);
+    return ext;
+}
+// readMesh(path) -> { vertices: Float32Array, tetIds: Int32Array, tetEdgeIds, visVerts, visTriIds, tetColour, vertOwner, partCount }
+// (copies out of the mapping: the JS arrays outlive it; absent sections are null)
+napi_value ReadMesh(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    char path[4096]; size_t n = 0;
+    if (napi_get_value_string_utf8(env, a[0], path, sizeof path, &n) != napi_ok) return throw_err(env, "path must be a string");
+    tetsim_mesh m = nullptr;
+    int rc = g.mesh_open(path, &m);
+    if (rc != TETSIM_OK) return check(env, rc, nullptr);
+    TetSimMeshArrays A;
+    g.mesh_arrays(m, &A);
+    napi_value obj; napi_create_object(env, &obj);
+    auto put = [&](const char* name, const void* src, size_t count, napi_typedarray_type type) {
+        napi_value v;
+        if (!src) napi_get_null(env, &v);
+        else {
+            void* dst = nullptr; napi_value ab;
+            napi_create_arraybuffer(env, count * 4, &dst, &ab);
+            if (count) std::memcpy(dst, src, count * 4);
+            napi_create_typedarray(env, type, count, ab, 0, &v);
+        }
+        napi_set_named_property(env, obj, name, v);
+    };
+    put("vertices", A.verts, 3ull * A.num_particles, napi_float32_array);
+    put("tetIds", A.tets, 4ull * A.num_elems, napi_int32_array);
+    put("tetEdgeIds", A.edge_ids, 2ull * A.num_edges, napi_int32_array);
+    put("visVerts", A.vis_verts, 4ull * A.num_vis_verts, napi_float32_array);
+    put("visTriIds", A.vis_tri_ids, 3ull * A.num_vis_tris, napi_int32_array);
+    put("tetColour", A.tet_colour, A.num_elems, napi_int32_array);
+    put("vertOwner", A.vert_owner, A.num_particles, napi_int32_array);
+    napi_value pc; napi_create_uint32(env, A.part_count, &pc);
+    napi_set_named_property(env, obj, "partCount", pc);
+    g.mesh_close(m);
+    return obj;
 }
 napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value a[1];
@@ -317,6 +381,8 @@ napi_value Init(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"load", nullptr, Load, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"createFromFile", nullptr, CreateFromFile, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readMesh", nullptr, ReadMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"stepN", nullptr, StepN, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

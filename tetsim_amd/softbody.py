@@ -56,10 +56,16 @@ class SoftBodyHIP:
 
     def __init__(self, vertices, tetIds, tetEdgeIds=None, physicsParams=None, visVerts=None, visTriIds=None,
                  visMaterial=None, world=None, *, solver="polar", precision="precise", order="original",
-                 ref_slot_table=True, ref_fixed_bounds=True, gather=False, constant_rest_shape=False, ref_grab_texel=False, device=0, part_count=1, part_index=0,
-                 vert_owner=None):
+                 ref_slot_table=True, ref_fixed_bounds=True, gather=False, constant_rest_shape=False, ref_grab_texel=False,
+                 device=0, part_count=1, part_index=0, vert_owner=None, tet_colour=None, mesh_file=None):
         L = capi.lib()
         self.physicsParams = physicsParams if physicsParams is not None else {}
+        if mesh_file is not None:   # SoftBodyHIP.fromFile: arrays come from the .tetsim container
+            from .meshfile import MeshFile
+            with MeshFile(mesh_file) as mf:
+                vertices, tetIds = mf.verts.copy(), mf.tets.copy()
+                if visVerts is None and mf.vis_verts is not None and part_count <= 1:
+                    visVerts = mf.vis_verts.copy()
         self._verts = _f32(vertices).reshape(-1)
         self._tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
         if self._verts.size % 3 or self._tets.size % 4:
@@ -86,16 +92,33 @@ class SoftBodyHIP:
         if vert_owner is not None:
             self._owner = np.ascontiguousarray(vert_owner, dtype=np.int32)
             o.vert_owner = _ip(self._owner)
+        self._colour = None
+        if tet_colour is not None:
+            self._colour = np.ascontiguousarray(tet_colour, dtype=np.int32)
+            if self._colour.size != self.numElems:
+                raise ValueError("tet_colour needs one entry per tet")
+            o.tet_colour = _ip(self._colour)
         self.solver = solver
         self._h = C.c_void_p()
-        capi.check(L.tetsim_create(_fp(self._verts), self.numParticles, _ip(self._tets), self.numElems,
-                                   C.byref(o), C.byref(self._h)))
+        if mesh_file is not None:   # the library maps the file itself and picks up a stored colouring / partition map
+            capi.check(L.tetsim_create_from_file(str(mesh_file).encode(), C.byref(o), C.byref(self._h)))
+        else:
+            capi.check(L.tetsim_create(_fp(self._verts), self.numParticles, _ip(self._tets), self.numElems,
+                                       C.byref(o), C.byref(self._h)))
         self.info = capi.TetSimInfo()
         capi.check(L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
         self._L = L
         self.numVisVerts = 0
         if visVerts is not None and len(visVerts):   # Softbody.js:46-47: rows (tetNr, b0, b1, b2)
-            self.setVisualMesh(visVerts)
+            if mesh_file is not None:   # tetsim_create_from_file attached the stored visual mesh already
+                self.numVisVerts, self._has_normals = len(np.asarray(visVerts).reshape(-1)) // 4, False
+            else:
+                self.setVisualMesh(visVerts)
+
+    @classmethod
+    def fromFile(cls, path, physicsParams=None, visMaterial=None, world=None, **kw):
+        """Build the body from a .tetsim container (tetsim_amd/meshfile.py) instead of the five Dragon.js arrays."""
+        return cls(None, None, None, physicsParams, None, None, visMaterial, world, mesh_file=path, **kw)
 
     # -- lifecycle ------------------------------------------------------------------------------------
     def close(self):
