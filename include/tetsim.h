@@ -254,6 +254,11 @@ int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t n
 /* Send 1 KiB to this handle's own rank and receive it back through the initialised communicator, on the halo
  * stream, and verify the bytes: exercises the run-time-resolved RCCL entry points on hosts with a single GPU. */
 int tetsim_comm_selftest(tetsim_handle h);
+/* Measurement helper: `reps` grouped ncclSend+ncclRecv of `bytes` to this rank itself on the halo stream, issued eagerly
+ * (use_graph = 0) or captured per_graph at a time into a HIP graph and replayed (use_graph = 1); checks the bytes.
+ * host_us = host time to issue one group, total_us = wall time per group.  Design input for DESIGN.md "Multi-GPU". */
+int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph,
+                      double *host_us, double *total_us);
 /* All partitions of one decomposition living in ONE process (one or several devices): n substeps with the SAME
  * stream/event choreography as the RCCL path -- interior tiles, wait for the previous halo, boundary tiles, boundary
  * particles, start the halo on a second stream, interior particles -- with asynchronous device copies standing in

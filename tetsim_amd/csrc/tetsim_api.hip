@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -78,6 +79,8 @@ struct tetsim_body {
     TetSimOptions opt{};
     TetSimInfo info{};
     hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
+    bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
     // halo choreography events, double buffered by substep parity: an event is never re-recorded while a wait that
     // other streams enqueued on its previous record may still be pending
@@ -235,8 +238,22 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
+    h->fork_needed = true;  // whatever the caller did on the main stream since the last call must be visible to the boundary stream
     return 0;
 }
+
+// Development: TETSIM_DEBUG_HOSTPROF=1 accumulates the host time of every call in the eager halo path, printed at destroy.
+struct HostProf {
+    bool on = [] { const char* e = getenv("TETSIM_DEBUG_HOSTPROF"); return e && e[0] == '1'; }();
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+    ~HostProf() { for (auto& kv : acc) fprintf(stderr, "[hostprof] %-28s %8.2f us avg over %llu calls\n", kv.first.c_str(), kv.second.first / kv.second.second, (unsigned long long)kv.second.second); }
+} g_hostprof;
+struct HostProfScope {
+    const char* label; std::chrono::steady_clock::time_point t0;
+    explicit HostProfScope(const char* l) : label(l) { if (g_hostprof.on) t0 = std::chrono::steady_clock::now(); }
+    ~HostProfScope() { if (g_hostprof.on) { auto& a = g_hostprof.acc[label]; a.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); a.second++; } }
+};
+#define HP(label) HostProfScope hp_scope_##__LINE__(label)
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
 void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -250,6 +267,18 @@ void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = n
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
     else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
+}
+
+// The halo stream carries the transfers AND the boundary tiles that consume them; high priority so that its few
+// workgroups are dispatched ahead of the interior kernel's backlog.
+int create_halo_stream(tetsim_body* h) {
+    if (h->comm_stream) return 0;
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_bnd_tet, hipEventDisableTiming));
+    return 0;
 }
 
 int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
@@ -271,8 +300,8 @@ int halo_start(tetsim_body* h) {
     const uint32_t p = h->halo_parity;
     for (auto& nb : h->neigh)
         if (!nb.contiguous && nb.send_count) util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
-    HIPCHK(h, hipEventRecord(h->ev_packed2[p], h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_packed2[p], 0));
+    { HP("record packed"); HIPCHK(h, hipEventRecord(h->ev_packed2[p], h->stream)); }
+    { HP("comm wait packed"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_packed2[p], 0)); }
     if (h->comm) {
         ncclResult_t r = g_rccl.GroupStart();
         if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
@@ -298,23 +327,24 @@ int halo_start(tetsim_body* h) {
             const NeighDev* back = nullptr;
             for (auto& r : dst->neigh) if (r.rank == h->opt.part_index) back = &r;
             if (!back || back->recv_count != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan");
-            HIPCHK(h, hipStreamWaitEvent(h->comm_stream, dst->ev_boundary2[p], 0));  // receiver finished reading its ghosts
+            { HP("comm wait dst boundary"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, dst->ev_boundary2[p], 0)); }  // receiver finished reading its ghosts
             const float4* from = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
-            HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream));
+            { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
         }
     }
-    HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream));
+    { HP("record sent"); HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream)); }
     h->halo_pending = true;
     return 0;
 }
 // Make this partition's main stream wait until the previous substep's halo is complete (see halo_start).
-int halo_wait(tetsim_body* h) {
+int halo_wait(tetsim_body* h, hipStream_t on) {
     if (!h->halo_pending) return 0;
     const uint32_t p = h->halo_parity ^ 1u;  // the previous substep's parity
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sent2[p], 0));  // our own transfers (RCCL: includes our receives)
+    // our own transfers (RCCL: includes our receives); implied by stream order when the consumer runs on the halo stream
+    if (on != h->comm_stream) { HP("wait own sent"); HIPCHK(h, hipStreamWaitEvent(on, h->ev_sent2[p], 0)); }
     if (!h->comm)
         for (auto& nb : h->neigh)
-            if (nb.recv_count) HIPCHK(h, hipStreamWaitEvent(h->stream, h->group[nb.rank]->ev_sent2[p], 0));
+            if (nb.recv_count) { HP("wait peer sent"); HIPCHK(h, hipStreamWaitEvent(on, h->group[nb.rank]->ev_sent2[p], 0)); }
     h->halo_pending = false;
     return 0;
 }
@@ -329,18 +359,42 @@ bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm 
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
 int enqueue_phase_a(tetsim_body* h) {  // tet kernels + particles
     if (h->blocked) {
-        // interior tiles read no ghost: they run while the previous substep's halo is still in flight
-        pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
-        int rc = halo_wait(h);
-        if (rc) return rc;
-        pjb_launch_tet(h->stream, h->blk, h->blk.nb_interior, h->blk.nb - h->blk.nb_interior);
+        const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
+        static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
+        if (nbnd && !one_stream) {
+            // Interior tiles read no ghost and start at once on the main stream.  The few boundary tiles (272 of 3984 on a
+            // 1 M-tet slab) are launched on the HALO stream, right behind the transfer they depend on: after the interior
+            // kernel on the main stream they cost a whole extra kernel latency (10-16 us: load -> 9 rotation iterations ->
+            // store, however few tiles); beside it their workgroups slot in as interior ones retire (the halo stream has high
+            // priority).  It also saves host work, which matters at ~2-4 us per HIP call against ~42 us of GPU work per
+            // substep: no event between the transfer and its consumer.
+            // Ordering: the halo stream is behind packed[p-1], recorded after the previous particle pass, so the boundary
+            // kernel is behind everything it reads; the first substep of a call forks explicitly.
+            if (h->fork_needed || !h->halo_pending) {
+                HP("fork");
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_fork, 0));
+                h->fork_needed = false;
+            }
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior); }
+            int rc = halo_wait(h, h->comm_stream);
+            if (rc) return rc;
+            { HP("launch tet boundary"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
+            { HP("record bnd_tet"); HIPCHK(h, hipEventRecord(h->ev_bnd_tet, h->comm_stream)); }
+            { HP("main wait bnd_tet"); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_bnd_tet, 0)); }
+        } else {
+            pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
+            int rc = halo_wait(h, h->stream);
+            if (rc) return rc;
+            pjb_launch_tet(h->stream, h->blk, h->blk.nb_interior, nbnd);
+        }
     } else {
-        int rc = halo_wait(h);
+        int rc = halo_wait(h, h->stream);
         if (rc) return rc;
         pj_tet(h);
     }
-    pj_vertex(h, 0, h->pj.nv_owned);
-    if (!h->comm) HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream));  // group transport only
+    { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned); }
+    if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream)); }  // group transport only
     return 0;
 }
 int enqueue_phase_b(tetsim_body* h) {  // halo start
@@ -868,6 +922,7 @@ void tetsim_destroy(tetsim_handle h) {
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {h->ev_fork, h->ev_bnd_tet}) if (ev) (void)hipEventDestroy(ev);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1320,7 +1375,7 @@ int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t n
     if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail(h, r, "ncclCommInitRank"); }
     h->comm_rank = rank;
     h->comm_size = nranks;
-    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    { int rc = create_halo_stream(h); if (rc) return rc; }
     return 0;
 }
 
@@ -1348,6 +1403,79 @@ int tetsim_comm_selftest(tetsim_handle h) {
                 hipMemcpy(back.data(), dst, kN * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
         rc = fail(h, TETSIM_EHIP, "selftest download failed");
     if (!rc && back != host) rc = fail(h, TETSIM_ECOMM, "selftest: received bytes differ from the bytes sent");
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}
+
+// Measurement helper (multi-GPU design input): cost of ONE grouped ncclSend+ncclRecv of `bytes` to this rank itself,
+// issued `reps` times back to back -- eagerly (use_graph = 0) or captured `per_graph` at a time into a HIP graph and
+// replayed (use_graph = 1).  host_us = host time spent issuing, per group; total_us = wall time to completion, per group.
+int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph, double* host_us, double* total_us) {
+    if (!h || !host_us || !total_us || reps == 0 || bytes < 4) return fail(h, TETSIM_EINVAL, "bad argument");
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const size_t n = bytes / sizeof(float);
+    float *src = nullptr, *dst = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), n * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), n * sizeof(float)));
+    std::vector<float> host(n), back(n, 0.0f);
+    for (size_t i = 0; i < n; i++) host[i] = static_cast<float>(i % 977) + 0.25f;
+    int rc = TETSIM_OK;
+    if (hipMemcpy(src, host.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, n * sizeof(float)) != hipSuccess)
+        rc = fail(h, TETSIM_EHIP, "probe upload failed");
+    auto group = [&]() -> ncclResult_t {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(src, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.GroupEnd();
+        return r;
+    };
+    using clk = std::chrono::steady_clock;
+    if (!rc) {  // warm-up (connection setup happens on first use)
+        ncclResult_t r = group();
+        if (r != ncclSuccess) rc = rccl_fail(h, r, "probe warm-up");
+        else if (hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe warm-up sync failed");
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (!rc && use_graph) {
+        if (per_graph == 0) per_graph = 1;
+        if (hipStreamBeginCapture(h->comm_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: begin capture failed");
+        for (uint32_t i = 0; !rc && i < per_graph; i++) {
+            ncclResult_t r = group();
+            if (r != ncclSuccess) rc = rccl_fail(h, r, "probe: send/recv under stream capture");
+        }
+        hipError_t e = hipStreamEndCapture(h->comm_stream, &graph);
+        if (!rc && e != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("probe: end capture: ") + hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph instantiate failed");
+    }
+    if (!rc) {
+        (void)hipMemset(dst, 0, n * sizeof(float));
+        (void)hipDeviceSynchronize();
+        const auto t0 = clk::now();
+        uint32_t done = 0;
+        if (use_graph) {
+            for (; done < reps && !rc; done += per_graph)
+                if (hipGraphLaunch(exec, h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph launch failed");
+        } else {
+            for (; done < reps && !rc; done++) {
+                ncclResult_t r = group();
+                if (r != ncclSuccess) rc = rccl_fail(h, r, "probe send/recv");
+            }
+        }
+        const auto t1 = clk::now();
+        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe sync failed");
+        const auto t2 = clk::now();
+        if (!rc) {
+            *host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / done;
+            *total_us = std::chrono::duration<double, std::micro>(t2 - t0).count() / done;
+            if (hipMemcpy(back.data(), dst, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe download failed");
+            else if (back != host) rc = fail(h, TETSIM_ECOMM, "probe: received bytes differ from the bytes sent");
+        }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
     (void)hipFree(src);
     (void)hipFree(dst);
     return rc;
@@ -1396,7 +1524,7 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
         if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
         if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream
             h->group.assign(hs, hs + count);
-            if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+            { int rc = create_halo_stream(h); if (rc) return rc; }
         }
     }
     for (uint32_t i = 0; i < count; i++) {
