@@ -75,7 +75,18 @@ def cpu_baseline(verts, tets):
             if r > best:
                 best, cores, nb = r, th, n
     set_threads(1)
+    # the reference's own CPU solver is the sequential Neo-Hookean Gauss-Seidel of Softbody.js (BASELINE config 1); its
+    # restatement (oracle section A, bit-exact with Softbody.js) on ONE core of this host, same lattice, for orientation
+    from oracle import OracleNH
+    nh = OracleNH(verts, tets, PP)
+    nh.simulate(DT, PP)
+    t0 = time.perf_counter()
+    nh.simulate(DT, PP)
+    nh.simulate(DT, PP)
+    nh_rate = 2 * len(tets) / (time.perf_counter() - t0) / 1e6
     res = {"value": round(best, 3), "unit": "M tet-solves/s", "cores": cores, "kind": "port",
+           "softbody_js_algorithm_1core": {"value": round(nh_rate, 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
+                                           "sample": "2 substeps of the same lattice, sequential Neo-Hookean Gauss-Seidel (oracle section A)"},
            "sample": "%d substeps of the same %d-tet lattice (oracle/tetsim_oracle.c section G, gcc -O2 + OpenMP over "
                      "tets/particles); best of 1/16/64 threads" % (nb, len(tets)),
            "value_1core": round(r1, 3), "host_cpus_available": avail}
