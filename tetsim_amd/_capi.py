@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtetsim_hip.so")
+LIB_PATH = os.environ.get("TETSIM_HIP_LIB") or os.path.join(_HERE, "libtetsim_hip.so")   # same override as the N-API shim
 
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
