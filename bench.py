@@ -134,6 +134,7 @@ def run():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--constant-rest-shape", action="store_true",
                     help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
+    ap.add_argument("--cells", type=int, default=CELLS, help="lattice cells per side (default 55 = the 1 M-tet headline; 110 = 8 M tets)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     args = ap.parse_args()
 
@@ -156,13 +157,14 @@ def run():
     from tetsim_amd import SoftBodyHIP, make_lattice, measure_copy_bandwidth
 
     # ---- workload ------------------------------------------------------------------------------------
-    nz = CELLS * world
-    verts, tets = make_lattice(CELLS, nz=nz)
+    cells = args.cells
+    nz = cells * world
+    verts, tets = make_lattice(cells, nz=nz)
     nt_global = len(tets)
     kw = {}
     if use_dist:
-        plane = (CELLS + 1) * (CELLS + 1)
-        owner = np.minimum((np.arange(len(verts)) // plane) // CELLS, world - 1).astype(np.int32)
+        plane = (cells + 1) * (cells + 1)
+        owner = np.minimum((np.arange(len(verts)) // plane) // cells, world - 1).astype(np.int32)
         # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
         # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
         PP["worldBounds"] = [-2.5, -1.0, -(0.5 * world + 2.0), 2.5, 10.0, 0.5 * world + 2.0]
@@ -216,7 +218,7 @@ def run():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
-                                   "%d substeps/frame, dt=1/1200 s" % (CELLS, CELLS, nz, nt_global, nv_global, SUBSTEPS),
+                                   "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
                        "solver": "polar_jacobi", "arithmetic": args.precision,
                        "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (carried world-space rest shape)", "substeps_per_step": SUBSTEPS,
                        "tets": nt_global, "particles": nv_global,
