@@ -300,6 +300,16 @@ def test_rccl_transport_selftest():
     comm_selftest(body)
     body.simulateSubsteps(5, DT20, PP)
     assert np.isfinite(body.pos).all()
+    # tetsim_comm_probe: the same grouped send/recv issued eagerly and replayed from a captured HIP graph; both verify
+    # the received bytes (the graph leg is the evidence that RCCL point-to-point can be captured on this stack)
+    import ctypes as C
+    from tetsim_amd import _capi
+    L = _capi.lib()
+    for use_graph, per in ((0, 1), (1, 4)):
+        host, total = C.c_double(), C.c_double()
+        rc = L.tetsim_comm_probe(body._h, 197 * 1024, 16, use_graph, per, C.byref(host), C.byref(total))
+        assert rc == 0, L.tetsim_last_error(body._h).decode()
+        assert 0.0 < host.value <= total.value < 1e4
 
 
 def test_lattice_1m_properties():
