@@ -21,6 +21,7 @@ TOL = {
     "dragon": {1: 0.0, 20: 1e-5, 200: 1e-4},
     "dragon_grab": {10: 5e-6, 60: 5e-5},
     "lat4_drag": {60: 5e-5, 200: 2e-4},
+    "hub": {1: 0.0, 20: 1e-5, 150: 2e-4},     # Delaunay ball around a hub particle of valence >> 36 (slots silently dropped)
 }
 
 
@@ -66,7 +67,7 @@ def test_generated_by_the_reference(glsl_golden):
     assert g["three"] == "160" and "softpipe" in g["gl"]["renderer"]
 
 
-@pytest.mark.parametrize("mesh", ["lat4", "dragon"])
+@pytest.mark.parametrize("mesh", ["lat4", "dragon", "hub"])
 def test_host_tables_bit_exact(mesh, glsl_golden):
     """Scatter table (incl. the `<= 0.0` quirk, SoftbodyGPU.js:563-577) and 1/V (:579-589) as the reference built them."""
     g, _ = glsl_golden
@@ -78,9 +79,12 @@ def test_host_tables_bit_exact(mesh, glsl_golden):
     import hashlib
     assert hashlib.sha256(slots.tobytes()).hexdigest()[:16] == gc["slots"]
     assert sha16(o.invRestVolume) == gc["invRestVolume"]
-    if mesh == "lat4":
-        assert np.array_equal(slots.ravel(), np.fromfile(os.path.join(GOLDEN, "lat4_gpu_slots.i32"), dtype="<i4"))
-        assert np.array_equal(o.invRestVolume.view(np.uint32), load_f32("lat4_gpu_invRestVolume.f32").view(np.uint32))
+    if mesh in ("lat4", "hub"):
+        assert np.array_equal(slots.ravel(), np.fromfile(os.path.join(GOLDEN, mesh + "_gpu_slots.i32"), dtype="<i4"))
+        assert np.array_equal(o.invRestVolume.view(np.uint32), load_f32(mesh + "_gpu_invRestVolume.f32").view(np.uint32))
+    if mesh == "hub":   # the point of this mesh: a particle with far more incident tets than the 36 slots
+        valence = np.bincount(t.ravel(), minlength=len(v))
+        assert valence.max() > 36 and (slots >= 0).sum(axis=1).max() == 36
     # the library's own host prep builds the same table
     from tetsim_amd import _capi
     import ctypes as C
@@ -92,7 +96,7 @@ def test_host_tables_bit_exact(mesh, glsl_golden):
     assert np.array_equal(out, slots.ravel())
 
 
-@pytest.mark.parametrize("name", ["lat4", "dragon", "dragon_grab", "lat4_drag"])
+@pytest.mark.parametrize("name", ["lat4", "dragon", "dragon_grab", "lat4_drag", "hub"])
 def test_trajectory_tracks_the_reference_glsl(name, glsl_golden):
     g, cases = glsl_golden
     c, gc = cases[name], g["cases"][name]
