@@ -243,6 +243,36 @@ def test_group_stepping_irregular_partition():
         assert np.array_equal(b.pos.view(np.uint32), ref[b.ownedIds].view(np.uint32))
 
 
+def test_caller_provided_transport_export_import():
+    """tetsim_get_halo_plan / tetsim_halo_export / tetsim_halo_import: a host that moves the halos itself (here: numpy)
+    reproduces the monolithic body bit for bit, and the plan is symmetric."""
+    v, t = make_lattice(6, y0=0.3)
+    owner = (np.arange(len(v)) * 3 // len(v)).astype(np.int32)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+    parts = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", part_count=3, part_index=i, vert_owner=owner) for i in range(3)]
+    plans = [p.haloPlan() for p in parts]
+    for i, plan in enumerate(plans):
+        assert len(plan) == parts[i].info.num_neighbours
+        for rank, sent, recv in plan:
+            back = [x for x in plans[rank] if x[0] == i]
+            assert len(back) == 1 and np.array_equal(back[0][2], sent) and np.array_equal(back[0][1], recv)   # what i sends, rank receives
+            assert (owner[sent] == i).all() and (owner[recv] == rank).all()
+    for step in range(40):
+        mono.simulate(DT20, PP)
+        for p in parts:
+            p.simulate(DT20, PP)
+        outbox = {(i, rank): parts[i].haloExport(slot, len(sent)) for i, plan in enumerate(plans) for slot, (rank, sent, _) in enumerate(plan)}
+        for i, plan in enumerate(plans):
+            for slot, (rank, _, recv) in enumerate(plan):
+                msg = outbox[(rank, i)]
+                assert len(msg) == len(recv)
+                parts[i].haloImport(slot, msg)
+    pos = np.empty_like(mono.pos)
+    for p in parts:
+        pos[p.ownedIds] = p.pos
+    assert np.array_equal(pos.view(np.uint32), mono.pos.view(np.uint32))
+
+
 def test_quats_follow_local_tet_order():
     """tetsim_read_quats is indexed like tetsim_get_local_tets (the blocked path stores tets in tile order)."""
     v, t = load_mesh("dragon")

@@ -238,6 +238,30 @@ class SoftBodyHIP:
         capi.check(self._L.tetsim_read_visual_mesh(self._h, _fp(out), _fp(nrm) if with_normals else None), self._h)
         return (out.reshape(-1, 3), nrm.reshape(-1, 3)) if with_normals else out.reshape(-1, 3)
 
+    # -- caller-provided transports (include/tetsim.h: tetsim_get_halo_plan / tetsim_halo_export / tetsim_halo_import) --
+    def haloPlan(self):
+        """[(neighbour rank, global ids sent, global ids received)] in neighbour-slot order."""
+        n = self.info.num_neighbours
+        if n == 0:
+            return []
+        neigh, sc, rc = (np.empty(n, dtype=np.int32) for _ in range(3))
+        capi.check(self._L.tetsim_get_halo_plan(self._h, _ip(neigh), _ip(sc), _ip(rc), None, None), self._h)
+        sid, rid = np.empty(int(sc.sum()), dtype=np.int32), np.empty(int(rc.sum()), dtype=np.int32)
+        capi.check(self._L.tetsim_get_halo_plan(self._h, _ip(neigh), _ip(sc), _ip(rc), _ip(sid), _ip(rid)), self._h)
+        so, ro = np.concatenate([[0], np.cumsum(sc)]), np.concatenate([[0], np.cumsum(rc)])
+        return [(int(neigh[i]), sid[so[i]:so[i + 1]].copy(), rid[ro[i]:ro[i + 1]].copy()) for i in range(n)]
+
+    def haloExport(self, slot, count):
+        """Predicted positions (x, y, z, w) this handle owes neighbour slot `slot`, as a host array [count, 4]."""
+        out = np.empty(4 * count, dtype=np.float32)
+        capi.check(self._L.tetsim_halo_export(self._h, int(slot), _fp(out)), self._h)
+        return out.reshape(-1, 4)
+
+    def haloImport(self, slot, xyzw):
+        """Install the ghost predictions received from neighbour slot `slot`."""
+        a = _f32(xyzw).reshape(-1)
+        capi.check(self._L.tetsim_halo_import(self._h, int(slot), _fp(a)), self._h)
+
     # -- grab (Softbody.js:279-298) -------------------------------------------------------------------
     def startGrab(self, pos):
         p = _f32([pos["x"], pos["y"], pos["z"]] if isinstance(pos, dict) else pos)
