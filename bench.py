@@ -114,6 +114,9 @@ class stdout_to_stderr:
 
 
 def main():
+    # a rank that is stuck in a collective would otherwise hang the whole launch until someone's outer limit fires
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "900")), exit=True)
     with stdout_to_stderr():
         out, rank, dist, body = run()
     if rank == 0:
@@ -123,6 +126,7 @@ def main():
             dist.barrier()
             body.close()
             dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def run():
