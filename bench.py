@@ -84,7 +84,28 @@ def cpu_baseline(verts, tets):
     nh.simulate(DT, PP)
     nh.simulate(DT, PP)
     nh_rate = 2 * len(tets) / (time.perf_counter() - t0) / 1e6
+    # ... and the same algorithm in JavaScript under node (oracle/nh_port.js, bit-exact with Softbody.js on the golden
+    # vectors): the reference's design point -- one JS thread -- on this host
+    js = None
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    if node:
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                np.ascontiguousarray(verts, dtype="<f4").tofile(os.path.join(tmp, "v.f32"))
+                np.ascontiguousarray(tets, dtype="<i4").tofile(os.path.join(tmp, "t.i32"))
+                r = subprocess.run([node, os.path.join(ROOT, "oracle", "nh_port.js"), "--verts", os.path.join(tmp, "v.f32"), "--tets",
+                                    os.path.join(tmp, "t.i32"), "--substeps", "3", "--warmup", "1", "--per-frame", str(SUBSTEPS)],
+                                   capture_output=True, text=True, timeout=300)
+            jr = json.loads(r.stdout)
+            js = {"value": round(jr["m_tet_solves_per_s"], 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
+                  "sample": "3 substeps of the same lattice after 1 warm-up, oracle/nh_port.js under node " + jr["node"]}
+        except Exception as e:  # the JS leg is optional: node may be absent or too old
+            js = {"error": str(e)[:200]}
     res = {"value": round(best, 3), "unit": "M tet-solves/s", "cores": cores, "kind": "port",
+           "softbody_js_algorithm_node_1thread": js,
            "softbody_js_algorithm_1core": {"value": round(nh_rate, 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
                                            "sample": "2 substeps of the same lattice, sequential Neo-Hookean Gauss-Seidel (oracle section A)"},
            "sample": "%d substeps of the same %d-tet lattice (oracle/tetsim_oracle.c section G, gcc -O2 + OpenMP over "

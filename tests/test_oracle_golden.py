@@ -69,3 +69,33 @@ def test_dragon_long(golden):
         o.simulate(dt, c["params"])
     assert sha16(o.pos) == g["steps"]["1200"]["pos"] == "9f52c76cdd7223f0"
     assert float(np.sum(o.pos.ravel().astype(np.float64))) == pytest.approx(g["steps"]["1200"]["sumPos"], rel=1e-12)
+
+
+@pytest.mark.parametrize("name,step", [("dragon", 100), ("dragon_sub5", 60), ("dragon_soft", 80), ("lat4", 300), ("lat4c", 300),
+                                       ("lat2degen", 40), ("notets", 200)])
+def test_js_port_bit_exact(name, step, golden):
+    """oracle/nh_port.js (the JavaScript restatement timed as the single-thread "JS CPU path" on the GPU box) reproduces the
+    golden vectors recorded from the reference's Softbody.js bit for bit -- same cases as the C oracle, minus the grab script."""
+    import json
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed on this host")
+    gold, cases = golden
+    c, g = cases[name], gold[name]
+    assert not c["grab"] and str(step) in g["steps"]
+    import os
+    pp = dict(c["params"], timeScale=c["timeScale"], timeStep=c["timeStep"])
+    out = subprocess.run([node, os.path.join(ROOT, "oracle", "nh_port.js"), "--verts", os.path.join(GOLDEN, c["mesh"] + "_verts.f32"),
+                          "--tets", os.path.join(GOLDEN, c["mesh"] + "_tets.i32"), "--substeps", str(step),
+                          "--per-frame", str(c["numSubsteps"]), "--params", json.dumps(pp)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    assert r["pos_sha16"] == g["steps"][str(step)]["pos"], (name, step)
+    want = g["steps"][str(step)]["volError"]
+    if want is None:
+        assert r["vol_error"] is None          # NaN serialises as null
+    else:
+        assert r["vol_error"] == want
