@@ -29,6 +29,7 @@
 // Result differs from the gather formulation only by summation order (tile partials) -- tolerance-level, FAST
 // mode only; PRECISE keeps the reference's slot order.
 #define TETSIM_FAST 1
+#include <cstdio>
 #include <cstdlib>
 
 #include "dev_common.h"
@@ -229,6 +230,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
         const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
         const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
         dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0) | ((np && np[0] == '1') ? 64 : 0);
+        if ((dbg & 15) != 9 || (dbg & 16))  // these two change the physics: never silently
+            fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_ITERS / TETSIM_DEBUG_SKIP_REST_STORE are set: timing ablation, the results are NOT the solver's\n");
     }
     const uint32_t mode = static_cast<uint32_t>(dbg) | (d.lean ? 128u : 0u);
     if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, mode);
