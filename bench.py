@@ -160,6 +160,9 @@ def run():
     ap.add_argument("--constant-rest-shape", action="store_true",
                     help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
     ap.add_argument("--cells", type=int, default=CELLS, help="lattice cells per side (default 55 = the 1 M-tet headline; 110 = 8 M tets)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver measures): cells^2 x (cells*N) lattice, one slab per GPU; strong: the cells^3 "
+                         "lattice split into N slabs (BASELINE config 5 is --scaling strong --cells 110)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     args = ap.parse_args()
 
@@ -183,16 +186,18 @@ def run():
 
     # ---- workload ------------------------------------------------------------------------------------
     cells = args.cells
-    nz = cells * world
+    nz = cells * world if args.scaling == "weak" else cells
     verts, tets = make_lattice(cells, nz=nz)
     nt_global = len(tets)
     kw = {}
     if use_dist:
         plane = (cells + 1) * (cells + 1)
-        owner = np.minimum((np.arange(len(verts)) // plane) // cells, world - 1).astype(np.int32)
+        layers = cells if args.scaling == "weak" else -(-cells // world)   # cell layers per slab
+        owner = np.minimum((np.arange(len(verts)) // plane) // layers, world - 1).astype(np.int32)
         # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
         # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
-        PP["worldBounds"] = [-2.5, -1.0, -(0.5 * world + 2.0), 2.5, 10.0, 0.5 * world + 2.0]
+        zext = 0.5 * (nz / cells) + 2.0
+        PP["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
         kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
     if args.constant_rest_shape:
         kw["constant_rest_shape"] = True
@@ -240,7 +245,7 @@ def run():
         out = {
             "metric": "tet_solves_per_sec", "value": round(value, 1), "unit": "M tet-solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
                                    "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
