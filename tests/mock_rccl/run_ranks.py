@@ -1,0 +1,65 @@
+"""Drives the RCCL-mode halo path of libtetsim_hip with N ranks living in one process (one host thread per rank, all on
+device 0) against the strict test double of tests/mock_rccl/mock_rccl.cpp.  Run with TETSIM_RCCL_LIB pointing at the double.
+
+    python tests/mock_rccl/run_ranks.py <nranks> <precise|fast> <cells> <substep calls> <substeps per call>
+Prints "OK max|dx| = ..." and exits 0 when the stitched result equals the monolithic body (bit for bit in PRECISE)."""
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tetsim_amd import SoftBodyHIP, comm_init, comm_unique_id, make_lattice  # noqa: E402
+
+nranks, precision, cells, calls, per_call = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+assert "mock_rccl" in os.environ.get("TETSIM_RCCL_LIB", ""), "this driver is for the test double only"
+PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0, worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+DT = (1.0 / 60.0) / 20
+v, t = make_lattice(cells, nz=cells * nranks, y0=0.02)          # close to the floor: contact within the run
+plane = (cells + 1) * (cells + 1)
+owner = np.minimum((np.arange(len(v)) // plane) // cells, nranks - 1).astype(np.int32)
+kw = dict(solver="polar", precision=precision, ref_fixed_bounds=False)
+
+mono = SoftBodyHIP(v, t, None, dict(PP), **kw)
+for _ in range(calls):
+    mono.simulateSubsteps(per_call, DT, PP)
+want = mono.pos
+
+uid = comm_unique_id()
+results, errors = [None] * nranks, []
+
+
+def rank_main(r):
+    try:
+        body = SoftBodyHIP(v, t, None, dict(PP), part_count=nranks, part_index=r, vert_owner=owner, **kw)
+        comm_init(body, uid, r, nranks)                       # blocks until every rank joined (like ncclCommInitRank)
+        for c in range(calls):
+            if c % 2:
+                for _ in range(per_call):
+                    body.simulate(DT, PP)                        # tetsim_step, one substep per call
+            else:
+                body.simulateSubsteps(per_call, DT, PP)          # tetsim_step_n
+        results[r] = (body.ownedIds, body.pos)
+        body.close()
+    except Exception as e:  # noqa: BLE001
+        errors.append("rank %d: %r" % (r, e))
+
+
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+for th in threads:
+    th.start()
+for th in threads:
+    th.join(timeout=240)
+if errors or any(th.is_alive() for th in threads):
+    print("FAILED", errors, [th.is_alive() for th in threads])
+    os._exit(1)
+got = np.full_like(want, np.nan)
+for ids, pos in results:
+    got[ids] = pos
+err = float(np.abs(got - want).max())
+exact = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+ok = exact if precision == "precise" else err <= 1e-4   # FAST: tile composition differs between decompositions (summation order)
+print("%s max|dx| = %.3g (bit-exact: %s), ymin %.4f" % ("OK" if ok else "MISMATCH", err, exact, float(want[:, 1].min())))
+sys.exit(0 if ok else 2)

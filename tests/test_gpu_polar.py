@@ -342,6 +342,25 @@ def test_rccl_transport_selftest():
         assert 0.0 < host.value <= total.value < 1e4
 
 
+@pytest.mark.parametrize("nranks,precision,cells", [(2, "precise", 6), (3, "precise", 5), (2, "fast", 12), (4, "fast", 8)])
+def test_rccl_code_path_against_a_strict_test_double(nranks, precision, cells):
+    """The RCCL-mode halo path (tetsim_comm_init + grouped ncclSend/ncclRecv per substep, boundary tiles on the halo
+    stream) with N ranks = N host threads on this one GPU, librccl replaced by tests/mock_rccl (which rejects unmatched or
+    mis-sized messages and enforces NCCL's stream ordering).  PRECISE must equal the monolithic body bit for bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock_rccl")
+    lib = os.path.join(here, "libmock_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(here, "mock_rccl.cpp")):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-std=c++17", os.path.join(here, "mock_rccl.cpp"), "-o", lib],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(here, "run_ranks.py"), str(nranks), precision, str(cells), "6", "7"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, TETSIM_RCCL_LIB=lib))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_lattice_1m_properties():
     """BASELINE config 3 at full size: size-independent properties instead of a CPU run."""
     v, t = make_lattice(55)

@@ -43,9 +43,14 @@ struct Rccl {
     std::string err;
     bool load() {
         if (lib) return true;
+        // TETSIM_RCCL_LIB: explicit library path (deployments with several RCCL builds; the test double of tests/mock_rccl)
+        if (const char* over = getenv("TETSIM_RCCL_LIB")) {
+            lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { err = std::string("cannot load TETSIM_RCCL_LIB=") + over + ": " + dlerror(); return false; }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
         auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
