@@ -109,7 +109,11 @@ class SoftBodyHIP {
     }
     endFrame() {                                        // Softbody.js:244-247
         this.readToCPU();
-        if (this.edgeMesh) this.updateEdgeMesh();
+        if (this.edgeMesh) {
+            this.updateEdgeMesh();
+            // the GUI's 'ShowTetMesh' switch (main.js:34,42) is honoured by SoftBodyGPU.endFrame only (SoftbodyGPU.js:646)
+            if (this._solver === 'polar' && this.physicsParams.ShowTetMesh !== undefined) this.edgeMesh.visible = !!this.physicsParams.ShowTetMesh;
+        }
         if (this.visMesh) this.updateVisMesh();
     }
     readToCPU() {                                       // SoftbodyGPU.js:649-653
