@@ -136,7 +136,8 @@ class SoftBodyHIP {
     updateVisMesh() {                                   // Softbody.js:259-277: barycentric skinning of the embedded mesh,
         const positions = this.visMesh.geometry.attributes.position.array;   // done by the device kernel
         this.readVisualPositions(positions);
-        if (this.physicsParams.computeNormals !== false) this.visMesh.geometry.computeVertexNormals();
+        // Softbody.js:273 always recomputes the normals; SoftbodyGPU.js:687 only when physicsParams.computeNormals is set
+        if (this._solver !== 'polar' || this.physicsParams.computeNormals) this.visMesh.geometry.computeVertexNormals();
         this.visMesh.geometry.attributes.position.needsUpdate = true;
         this.visMesh.geometry.computeBoundingSphere();
     }
