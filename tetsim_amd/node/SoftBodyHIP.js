@@ -11,7 +11,8 @@
 //
 // Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
 //     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured', device: 0,
-//       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false }   (include/tetsim.h flags)
+//       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false,   (include/tetsim.h flags)
+//       partCount: 1, partIndex: 0, vertOwner: Int32Array }   (one Node process per GPU: see commUniqueId / commInit below)
 // default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
 const path = require('path');
 
@@ -50,8 +51,10 @@ class SoftBodyHIP {
                    (opt.gather ? FLAG_GATHER_FORMULATION : 0) | (opt.constantRestShape ? FLAG_CONSTANT_REST_SHAPE : 0) |
                    (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0),
             device: opt.device || 0,
+            partCount: opt.partCount || 1, partIndex: opt.partIndex || 0,
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
         };
+        if (opt.vertOwner) createOptions.vertOwner = opt.vertOwner instanceof Int32Array ? opt.vertOwner : Int32Array.from(opt.vertOwner);
         // fromFile: the library maps the .tetsim container itself (and picks up a stored colouring / visual mesh)
         this._h = _meshFile ? api.createFromFile(_meshFile, createOptions) : api.create(verts32, tets32, createOptions);
         this._dirty = false;
@@ -95,6 +98,14 @@ class SoftBodyHIP {
         return new SoftBodyHIP(m.vertices, m.tetIds, m.tetEdgeIds || [], physicsParams, m.visVerts || new Float32Array(0),
                                m.visTriIds || [], visMaterial, world, path);
     }
+
+    // ---- multi-GPU: one Node process per GPU, this body = partition partIndex of partCount (INTEGRATION.md §4) -------------
+    // rank 0: id = SoftBodyHIP.commUniqueId(); ship the 128 bytes to every process (any channel); all: body.commInit(id, rank, n).
+    // Afterwards simulate()/simulateSubsteps() exchange ghost positions with the neighbouring partitions over RCCL; `pos`
+    // then holds the OWNED particles only, whose global ids are body.ownedIds().
+    static commUniqueId() { return loadTetSim().commUniqueId(); }
+    commInit(id, rank, nranks) { this._api.commInit(this._h, id, rank, nranks); }
+    ownedIds() { return this._api.ownedIds(this._h); }
 
     // ---- the hot path ------------------------------------------------------------------------------------------
     simulate(dt, physicsParams) {                       // ONE substep, asynchronous (Softbody.js:195 / SoftbodyGPU.js:610)

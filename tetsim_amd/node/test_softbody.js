@@ -100,4 +100,24 @@ if (process.env.TETSIM_TEST_MESH) {
     b.dispose();
     console.log('fromFile: .tetsim container -> bit-exact vs Softbody.js goldens (positions + 29,800 skinned vertices)');
 }
+// 5. partitioned bodies and the RCCL communicator from Node (one rank here: the entry points and the bookkeeping)
+{
+    const nv = verts.length / 3;
+    const owner = new Int32Array(nv); for (let i = 0; i < nv; i++) owner[i] = i < nv / 2 ? 0 : 1;
+    const p5 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'precise', partCount: 2, partIndex: 1, vertOwner: owner } });
+    const part = new SoftBodyHIP(verts.slice(0), tets, [], p5, new Float32Array(0), [], null, {});
+    const inf = part.info(), ids = part.ownedIds();
+    assert.strictEqual(inf.ownedParticles, nv - Math.ceil(nv / 2)); assert.strictEqual(ids.length, inf.ownedParticles);
+    assert.ok(inf.localParticles > inf.ownedParticles && inf.numNeighbours === 1);
+    for (let i = 0; i < ids.length; i++) assert.strictEqual(owner[ids[i]], 1);
+    part.dispose();
+    const id = SoftBodyHIP.commUniqueId();
+    assert.ok(id instanceof Uint8Array && id.length === 128);
+    const solo = new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', precision: 'fast' } }), new Float32Array(0), [], null, {});
+    solo.commInit(id, 0, 1);
+    solo.simulateSubsteps(20, dt20, pp); solo.endFrame();
+    for (let i = 0; i < solo.pos.length; i++) assert.ok(Number.isFinite(solo.pos[i]));
+    solo.dispose();
+    console.log('partition options, ownedIds, commUniqueId/commInit ok');
+}
 console.log('node boundary ok');

@@ -39,6 +39,9 @@ struct Api {
     decltype(&tetsim_set_grab) set_grab = nullptr;
     decltype(&tetsim_start_grab) start_grab = nullptr;
     decltype(&tetsim_abi_version) abi_version = nullptr;
+    decltype(&tetsim_comm_unique_id) comm_unique_id = nullptr;
+    decltype(&tetsim_comm_init) comm_init = nullptr;
+    decltype(&tetsim_get_owned_ids) get_owned_ids = nullptr;
     decltype(&tetsim_mesh_open) mesh_open = nullptr;
     decltype(&tetsim_mesh_arrays) mesh_arrays = nullptr;
     decltype(&tetsim_mesh_close) mesh_close = nullptr;
@@ -60,6 +63,7 @@ bool load_lib(const std::string& hint) {
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(abi_version, "tetsim_abi_version")
+    SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
 #undef SYM
     if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
@@ -173,6 +177,14 @@ void options_of(napi_env env, napi_value obj, TetSimOptions* o) {
     if (get_double(env, obj, "flags", &d)) o->flags = static_cast<uint32_t>(d);
     if (get_double(env, obj, "device", &d)) o->device = static_cast<int32_t>(d);
     if (get_double(env, obj, "density", &d)) o->density = d;
+    // domain decomposition (one Node process per GPU): partCount / partIndex / vertOwner: Int32Array [numParticles]
+    if (get_double(env, obj, "partCount", &d)) o->part_count = static_cast<int32_t>(d);
+    if (get_double(env, obj, "partIndex", &d)) o->part_index = static_cast<int32_t>(d);
+    napi_value ov; bool has = false;
+    if (napi_has_named_property(env, obj, "vertOwner", &has) == napi_ok && has && napi_get_named_property(env, obj, "vertOwner", &ov) == napi_ok) {
+        int32_t* own; size_t n;
+        if (typed_array(env, ov, napi_int32_array, &own, &n)) o->vert_owner = own;   // read during create only
+    }
 }
 // createFromFile(path, options) -> handle      (tetsim_create_from_file: the library maps the .tetsim container itself)
 napi_value CreateFromFile(napi_env env, napi_callback_info info) {
@@ -360,6 +372,43 @@ napi_value StartGrab(napi_env env, napi_callback_info info) {
     if (rc) return check(env, rc, h);
     napi_value r; napi_create_int32(env, id, &r); return r;
 }
+// commUniqueId() -> Uint8Array(128): rank 0 makes it, the host distributes it (any channel), every rank calls commInit
+napi_value CommUniqueId(napi_env env, napi_callback_info) {
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    void* data = nullptr; napi_value ab, out;
+    napi_create_arraybuffer(env, 128, &data, &ab);
+    const int rc = g.comm_unique_id(data);
+    if (rc != TETSIM_OK) return check(env, rc, nullptr);
+    napi_create_typedarray(env, napi_uint8_array, 128, ab, 0, &out);
+    return out;
+}
+// commInit(handle, Uint8Array(128) id, rank, nranks): RCCL communicator for this partition's ghost halo
+napi_value CommInit(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    uint8_t* id; size_t n;
+    if (!typed_array(env, a[1], napi_uint8_array, &id, &n) || n < 128) return throw_err(env, "id must be the Uint8Array(128) of commUniqueId()");
+    double rank, nranks;
+    napi_get_value_double(env, a[2], &rank); napi_get_value_double(env, a[3], &nranks);
+    return check(env, g.comm_init(h, id, static_cast<int32_t>(rank), static_cast<int32_t>(nranks)), h);
+}
+// ownedIds(handle) -> Int32Array: global particle id of every row readPositions returns (partitioned bodies)
+napi_value OwnedIds(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    void* data = nullptr; napi_value ab, out;
+    napi_create_arraybuffer(env, 4ull * inf.owned_particles, &data, &ab);
+    const int rc = g.get_owned_ids(h, static_cast<int32_t*>(data));
+    if (rc != TETSIM_OK) return check(env, rc, h);
+    napi_create_typedarray(env, napi_int32_array, inf.owned_particles, ab, 0, &out);
+    return out;
+}
 napi_value Info(napi_env env, napi_callback_info info) {
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return nullptr;
@@ -373,7 +422,8 @@ napi_value Info(napi_env env, napi_callback_info info) {
     set("numParticles", inf.num_particles); set("numElems", inf.num_elems); set("ownedParticles", inf.owned_particles);
     set("localElems", inf.local_elems); set("numLevels", inf.num_levels); set("maxValence", inf.max_valence);
     set("droppedSlots", inf.dropped_slots); set("deviceBytes", static_cast<double>(inf.device_bytes));
-    set("solver", inf.solver); set("precision", inf.precision);
+    set("solver", inf.solver); set("precision", inf.precision); set("localParticles", inf.local_particles);
+    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours);
     return o;
 }
 
@@ -383,6 +433,9 @@ napi_value Init(napi_env env, napi_value exports) {
         {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"createFromFile", nullptr, CreateFromFile, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readMesh", nullptr, ReadMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"ownedIds", nullptr, OwnedIds, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"stepN", nullptr, StepN, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
