@@ -163,6 +163,9 @@ def run():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, what the driver measures): cells^2 x (cells*N) lattice, one slab per GPU; strong: the cells^3 "
                          "lattice split into N slabs (BASELINE config 5 is --scaling strong --cells 110)")
+    ap.add_argument("--profile-ranks", action="store_true",
+                    help="N > 1: after the timed region every rank runs 60 more substeps with per-kernel events and rank 0 reports "
+                         "its interior tet kernel in `roofline` (default at N > 1: whole-substep figures only)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     args = ap.parse_args()
 
@@ -254,33 +257,49 @@ def run():
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
         }
-    if world == 1:
-        # dominant kernel: its OWN begin/end HIP events (hipExtLaunchKernelGGL) on the handle's stream, inside the real
-        # tet -> particle -> tet ... sequence, 60 substeps right after the timed region (same kernels as the graph)
+    # dominant kernel: its OWN begin/end HIP events (hipExtLaunchKernelGGL) on the handle's stream, inside the real
+    # tet -> particle -> tet ... sequence, 60 substeps right after the timed region (same kernels as the graph).  N > 1: every
+    # rank takes part (the substeps exchange halos as usual); rank 0 reports ITS interior tet kernel -- the boundary tiles run
+    # beside it on the halo stream.
+    pr = None
+    if world == 1 or (args.profile_ranks and args.precision == "fast"):
         pr = body.profile(SUBSTEPS * 3, DT, PP)
+        barrier()
+    if rank == 0 and pr is not None:
         tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3
         # constant-rest-shape option: the 48 B/tet shape is read only (never written back): 148 - 48 = 100 B/tet
         tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)
-        achieved = tet_bytes * len(tets) / (tet_us * 1e-6) / 1e9
+        units = pr["tets_per_tet_launch"]
+        achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
         b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
         traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = None if args.constant_rest_shape else json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": kname,
+        if world == 1:
+            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    traffic = None if args.constant_rest_shape else json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
-                           "alg_bytes_per_launch": tet_bytes * len(tets),
+                           "alg_bytes_per_launch": tet_bytes * units,
                            "substep_alg_bytes_per_tet": round(b_alg, 1),
                            "substep_achieved": round(b_alg * value * 1e6 / 1e9, 1),
-                           "substep_frac": round(b_alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
-                           "measured_copy_peak": {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0),
-                                                  "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}}
+                           "substep_frac": round(b_alg * value * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+        if world == 1:
+            out["roofline"]["measured_copy_peak"] = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0),
+                                                     "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
+    if rank == 0 and pr is None:
+        # N > 1 without --profile-ranks: the whole-job figure only (no extra GPU work after the timed region)
+        b_alg = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0) + VERTEX_BYTES * len(verts) / len(tets)
+        agg = b_alg * value * 1e6 / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "whole substep, all ranks (tet + particle kernels)", "achieved": round(agg, 1),
+                           "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                           "substep_alg_bytes_per_tet": round(b_alg, 1)}
+    if world == 1:
         if not args.no_cpu_baseline:
             body.close()
             out["cpu_baseline"] = cpu_baseline(verts, tets)

@@ -141,6 +141,8 @@ typedef struct TetSimProfile {
     double kernel_ms[TETSIM_K_COUNT]; /* summed duration per kernel class */
     uint32_t launches[TETSIM_K_COUNT];
     uint32_t substeps;
+    uint32_t tets_per_tet_launch;    /* tets one timed TETSIM_K_TET launch processes: all of them, or on a partitioned body with a
+                                        halo transport the INTERIOR tiles' (the boundary tiles run beside them on the halo stream) */
 } TetSimProfile;
 
 /* --- lifecycle ------------------------------------------------------------------------------- */

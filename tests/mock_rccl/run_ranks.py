@@ -42,6 +42,10 @@ def rank_main(r):
             else:
                 body.simulateSubsteps(per_call, DT, PP)          # tetsim_step_n
         results[r] = (body.ownedIds, body.pos)
+        if precision == "fast":   # tetsim_profile on a body with an RCCL halo: every rank together, interior tet kernel timed
+            pr = body.profile(6, DT, PP)
+            assert pr["substeps"] == 6 and pr["tet_launches"] == 6 and 0 < pr["tets_per_tet_launch"] <= body.info.local_elems, pr
+            assert 0.0 < pr["tet_ms"] and 0.0 < pr["vertex_ms"], pr
         body.close()
     except Exception as e:  # noqa: BLE001
         errors.append("rank %d: %r" % (r, e))

@@ -46,7 +46,7 @@ class TetSimInfo(C.Structure):
 
 class TetSimProfile(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("kernel_ms", C.c_double * K_COUNT), ("launches", C.c_uint32 * K_COUNT),
-                ("substeps", C.c_uint32)]
+                ("substeps", C.c_uint32), ("tets_per_tet_launch", C.c_uint32)]
 
 
 class TetSimPlanSizes(C.Structure):

@@ -85,6 +85,7 @@ struct tetsim_body {
     TetSimInfo info{};
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
+    uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
     bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
     // halo choreography events, double buffered by substep parity: an event is never re-recorded while a wait that
@@ -362,7 +363,7 @@ bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm 
 //
 // In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
-int enqueue_phase_a(tetsim_body* h) {  // tet kernels + particles
+int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
@@ -381,7 +382,7 @@ int enqueue_phase_a(tetsim_body* h) {  // tet kernels + particles
                 HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_fork, 0));
                 h->fork_needed = false;
             }
-            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior); }
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
             int rc = halo_wait(h, h->comm_stream);
             if (rc) return rc;
             { HP("launch tet boundary"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
@@ -398,7 +399,7 @@ int enqueue_phase_a(tetsim_body* h) {  // tet kernels + particles
         if (rc) return rc;
         pj_tet(h);
     }
-    { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned); }
+    { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
     if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream)); }  // group transport only
     return 0;
 }
@@ -564,6 +565,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
         h->tet_perm = B.tet_perm;
         PJBlk& k = h->blk;
+        h->interior_tets = B.blk_tet_off[B.num_interior_blocks];
         k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
@@ -1212,12 +1214,17 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
 
 int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params, TetSimProfile* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
-    if (has_transport(h)) return fail(h, TETSIM_ESTATE, "profile a partitioned body through rocprofv3 instead");
+    // a body with an RCCL halo: every rank calls this together (the substeps exchange halos as usual); what is timed is the
+    // interior tet kernel and the particle kernel of the two-stream choreography
+    const bool halo = has_transport(h);
+    if (halo && (!h->comm || !h->blocked || h->blk.nb == h->blk.nb_interior || getenv("TETSIM_DEBUG_ONE_STREAM")))
+        return fail(h, TETSIM_ESTATE, "profiling a partitioned body needs the RCCL transport and the blocked formulation (in-process groups: use rocprofv3)");
     HIPCHK(h, hipSetDevice(h->opt.device));
     std::memset(out, 0, sizeof(*out));
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
+    out->tets_per_tet_launch = halo ? h->interior_tets : h->info.local_elems;
     // POLAR_JACOBI: every kernel carries its own begin/end events (hipExtLaunchKernelGGL), so kernel_ms is the sum of
     // the kernels' OWN durations inside the real tet -> particle -> tet ... sequence (what rocprofv3 reports), not the
     // spacing of event markers.  NEOHOOKEAN_GS: one span per kernel class (hundreds of tiny level launches).
@@ -1227,7 +1234,9 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     hipEvent_t first_ev = ev[4ull * n], last_ev = ev[4ull * n + 1];
     HIPCHK(h, hipEventRecord(first_ev, h->stream));
     for (uint32_t i = 0; i < n; i++) {
-        if (pjs) {
+        if (pjs && halo) {
+            if ((rc = enqueue_phase_a(h, &ev[4 * i])) || (rc = enqueue_phase_b(h))) break;
+        } else if (pjs) {
             pj_tet(h, ev[4 * i], ev[4 * i + 1]);
             pj_vertex(h, 0, h->pj.nv_owned, ev[4 * i + 2], ev[4 * i + 3]);
         } else {
@@ -1245,6 +1254,8 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     }
     HIPCHK(h, hipEventRecord(last_ev, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (rc) { for (auto& e : ev) (void)hipEventDestroy(e); return rc; }
     float ms = 0.0f;
     for (uint32_t i = 0; i < n; i++) {
         float a = 0, b = 0, c = 0;

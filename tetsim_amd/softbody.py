@@ -291,7 +291,8 @@ class SoftBodyHIP:
         pr = capi.TetSimProfile()
         capi.check(self._L.tetsim_profile(self._h, int(n), float(dt), C.byref(make_params(pp)), C.byref(pr)), self._h)
         return dict(total_ms=pr.total_ms, tet_ms=pr.kernel_ms[capi.K_TET], vertex_ms=pr.kernel_ms[capi.K_VERTEX],
-                    tet_launches=pr.launches[capi.K_TET], vertex_launches=pr.launches[capi.K_VERTEX], substeps=pr.substeps)
+                    tet_launches=pr.launches[capi.K_TET], vertex_launches=pr.launches[capi.K_VERTEX], substeps=pr.substeps,
+                    tets_per_tet_launch=pr.tets_per_tet_launch)
 
     def timeKernels(self, reps, dt, physicsParams=None):
         """Kernel-only timing (back-to-back launches, one event pair per kernel class).  Scratch bodies only."""
