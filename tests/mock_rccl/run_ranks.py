@@ -22,9 +22,10 @@ plane = (cells + 1) * (cells + 1)
 owner = np.minimum((np.arange(len(v)) // plane) // cells, nranks - 1).astype(np.int32)
 kw = dict(solver="polar", precision=precision, ref_fixed_bounds=False)
 
+dts = [DT * (2.0 if c == 2 else 0.5 if c == 4 else 1.0) for c in range(calls)]   # the time step changes twice mid-run
 mono = SoftBodyHIP(v, t, None, dict(PP), **kw)
-for _ in range(calls):
-    mono.simulateSubsteps(per_call, DT, PP)
+for c in range(calls):
+    mono.simulateSubsteps(per_call, dts[c], PP)
 want = mono.pos
 
 uid = comm_unique_id()
@@ -38,9 +39,9 @@ def rank_main(r):
         for c in range(calls):
             if c % 2:
                 for _ in range(per_call):
-                    body.simulate(DT, PP)                        # tetsim_step, one substep per call
+                    body.simulate(dts[c], PP)                    # tetsim_step, one substep per call
             else:
-                body.simulateSubsteps(per_call, DT, PP)          # tetsim_step_n
+                body.simulateSubsteps(per_call, dts[c], PP)      # tetsim_step_n
         results[r] = (body.ownedIds, body.pos)
         if precision == "fast":   # tetsim_profile on a body with an RCCL halo: every rank together, interior tet kernel timed
             pr = body.profile(6, DT, PP)

@@ -230,6 +230,26 @@ def test_group_stepping_uses_the_rccl_choreography(precision, parts):
         bodies[0].simulate(DT20, PP)  # grouped bodies are stepped through the group only
 
 
+def test_dt_change_on_partitioned_bodies_refreshes_the_halo():
+    """A new dt invalidates the fused x* = x + v*dt predictions, ghosts included: partitioned bodies with a transport redo
+    the prediction and re-exchange it (in-process group here, RCCL in the mock-rank test); without a transport it is an error."""
+    v, t = make_lattice(5, y0=0.02)
+    owner = (np.arange(len(v)) * 2 // len(v)).astype(np.int32)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+    parts = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", part_count=2, part_index=i, vert_owner=owner) for i in range(2)]
+    for dt, n in ((DT20, 7), (DT20 * 2, 5), (DT20 * 0.5, 9), (DT20, 4)):
+        mono.simulateSubsteps(n, dt, PP)
+        group_step_n(parts, n, dt, PP)
+    pos = np.empty_like(mono.pos)
+    for p in parts:
+        pos[p.ownedIds] = p.pos
+    assert np.array_equal(pos.view(np.uint32), mono.pos.view(np.uint32))
+    lone = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", part_count=2, part_index=0, vert_owner=owner)
+    lone.simulate(DT20, PP)
+    with pytest.raises(Exception, match="without a transport"):
+        lone.simulate(DT20 * 2, PP)
+
+
 def test_group_stepping_irregular_partition():
     v, t = load_mesh("dragon")
     parts = 3

@@ -86,6 +86,7 @@ struct tetsim_body {
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
     uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
+    bool needs_halo_refresh = false;    // in-process group: predictions were redone for a new dt
     bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
     // halo choreography events, double buffered by substep parity: an event is never re-recorded while a wait that
@@ -435,13 +436,24 @@ int enqueue_substep(tetsim_body* h) {
 }
 
 // POLAR_JACOBI keeps x* = x + v*dt precomputed by the previous vertex kernel; redo it if dt changed.
+int enqueue_phase_b(tetsim_body* h);
 int ensure_prediction(tetsim_body* h, double dt) {
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return 0;
     const float fdt = static_cast<float>(dt);
     if (!h->pred_any_dt && fdt != h->dt_pred) {
-        if (h->partitioned && !h->neigh.empty())
-            return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body (ghost predictions would be stale)");
+        if (h->partitioned && !h->neigh.empty() && !has_transport(h))
+            return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body without a transport (ghost predictions would be stale): "
+                                          "exchange halos through tetsim_comm_init / tetsim_group_step_n, or keep dt fixed");
         pj_repredict(h);
+        // the neighbours' ghost copies of our interface predictions are stale now: one extra halo exchange (every rank sees the
+        // same dt change, so every rank does this).  RCCL bodies do it here; an in-process group does it for all its members
+        // in tetsim_group_step_n (a copy waits for the RECEIVER's event, so all records must precede all copies).
+        if (has_transport(h)) {
+            if (h->comm) {
+                int rc = enqueue_phase_b(h);
+                if (rc) return rc;
+            } else h->needs_halo_refresh = true;
+        }
     }
     h->pred_any_dt = false;
     h->dt_pred = fdt;
@@ -1547,6 +1559,15 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
         int rc = push_params(hs[i], dt, params);
         if (!rc) rc = ensure_prediction(hs[i], dt);
         if (rc) return rc;
+    }
+    bool refresh = false;
+    for (uint32_t i = 0; i < count; i++) refresh = refresh || hs[i]->needs_halo_refresh;
+    if (refresh) {  // dt changed: every member redid its predictions; re-send them (all "ghosts are free" records, then all copies)
+        for (uint32_t i = 0; i < count; i++) {
+            hs[i]->needs_halo_refresh = false;
+            HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->stream));
+        }
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
     }
     static const bool dbg_sync = getenv("TETSIM_DEBUG_GROUP_SYNC") != nullptr;  // development: serialise every phase
     for (uint32_t s = 0; s < n; s++) {
