@@ -228,6 +228,10 @@ int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]);
  * Softbody.js:284-288 does, first minimum wins), only one candidate per 256 particles travels to the host; sets and
  * returns the particle (no full read-back, unlike GPUGrabber.start, SoftbodyGPU.js:790-795). */
 int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t *id_out);
+/* The owned particle nearest to xyz (same f64 distance and first-minimum rule) WITHOUT grabbing it: global id and squared
+ * distance.  Partitioned bodies: take the minimum over the partitions on the host (ties: lowest id), then call
+ * tetsim_set_grab(id, xyz) on every partition -- only the owner pins it. */
+int tetsim_nearest_particle(tetsim_handle h, const float xyz[3], int32_t *global_id, double *dist2);
 
 /* --- measurement ----------------------------------------------------------------------------- */
 

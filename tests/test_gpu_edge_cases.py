@@ -120,6 +120,36 @@ def test_device_grab_query_matches_reference_argmin():
     assert b.startGrab(np.float32([0.1, 0.3, 0.1])) == orc2.startGrab(float(np.float32(0.1)), float(np.float32(0.3)), float(np.float32(0.1)))
 
 
+def test_nearest_particle_over_partitions_equals_start_grab():
+    """tetsim_nearest_particle on each partition + a host-side min reproduces startGrab of the monolithic body (the device
+    argmin of Softbody.js:279-291), also after the body has moved; then the grab pins the particle on its owner only."""
+    from conftest import load_mesh
+    from tetsim_amd import group_step_n
+    v, t = load_mesh("dragon")
+    pp = dict(gravity=-9.81, friction=1000.0, density=1000.0)
+    owner = (np.arange(len(v)) * 3 // len(v)).astype(np.int32)
+    for solver_kw in (dict(solver="polar", precision="fast"), dict(solver="polar", precision="precise")):
+        mono = SoftBodyHIP(v, t, None, dict(pp), **solver_kw)
+        parts = [SoftBodyHIP(v, t, None, dict(pp), part_count=3, part_index=i, vert_owner=owner, **solver_kw) for i in range(3)]
+        mono.simulateSubsteps(15, 1 / 1200, pp)
+        group_step_n(parts, 15, 1 / 1200, pp)
+        rng = np.random.RandomState(3)
+        for q in np.vstack([rng.uniform(-1, 2, (20, 3)), v[[0, 500, 1233]] + 1e-4]):
+            want = mono.startGrab(q)
+            cands = [p.nearestParticle(q) for p in parts]
+            gid = min(cands, key=lambda c: (c[1], c[0]))[0]
+            assert gid == want, (q, cands, want)
+        target = np.float32([0.3, 1.5, 0.2])
+        for p in parts:
+            p.setGrab(gid, target)
+        group_step_n(parts, 1, 1 / 1200, pp)
+        for p in parts:
+            ids = p.ownedIds
+            hit = np.nonzero(ids == gid)[0]
+            if len(hit):
+                assert np.allclose(p.pos[hit[0]], target, atol=1e-6)
+
+
 @pytest.mark.parametrize("solver,precision", [("polar", "fast"), ("polar", "precise"), ("neohookean", "precise")])
 def test_pinned_zero_copy_readback_equals_copying_readback(solver, precision):
     v, t = load_mesh("dragon")

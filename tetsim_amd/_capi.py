@@ -68,7 +68,7 @@ SYMBOLS = [
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
     "tetsim_read_visual_mesh", "tetsim_set_grab",
-    "tetsim_start_grab", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
+    "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
     "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
@@ -100,6 +100,7 @@ def lib():
     L.tetsim_destroy.argtypes = [H]
     L.tetsim_destroy.restype = None
     L.tetsim_comm_probe.argtypes = [H, C.c_uint64, u32, i32, u32, dp, dp]
+    L.tetsim_nearest_particle.argtypes = [H, fp, ip, dp]
     L.tetsim_mesh_write.argtypes = [C.c_char_p, C.POINTER(TetSimMeshArrays)]
     L.tetsim_mesh_open.argtypes = [C.c_char_p, C.POINTER(H)]
     L.tetsim_mesh_arrays.argtypes = [H, C.POINTER(TetSimMeshArrays)]

@@ -1192,18 +1192,19 @@ int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {
     if (xyz) std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
     return 0;
 }
-int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
-    if (!h || !xyz) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->partitioned) return fail(h, TETSIM_ESTATE, "start_grab on a partitioned body: pick the particle on the host and use tetsim_set_grab");
-    // argmin of Softbody.js:279-291 on the device: one (d2, index) candidate per 256 particles comes back
+namespace {
+// argmin of Softbody.js:279-291 over this handle's OWNED particles, on the device: one (d2, index) candidate per 256
+// particles comes back.  *local receives the API-local index (first minimum), *best its squared distance (f64).
+int nearest_owned(tetsim_body* h, const float xyz[3], int32_t* local, double* best_out) {
     HIPCHK(h, hipSetDevice(h->opt.device));
-    const uint32_t n = h->info.num_particles, nblk = (n + 255u) / 256u;
+    const uint32_t n = h->info.owned_particles, nblk = (n + 255u) / 256u;
     int rc;
     if (!h->d_best) {
         if ((rc = dev_alloc(h, &h->d_best, nblk))) return rc;
         if ((rc = dev_alloc(h, &h->d_best_id, nblk))) return rc;
         if ((rc = ensure_index_map(h))) return rc;
     }
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     util_launch_nearest(h->stream, current_positions(h), h->d_api2dev, n, static_cast<double>(xyz[0]), static_cast<double>(xyz[1]),
                         static_cast<double>(xyz[2]), h->d_best, h->d_best_id);
     std::vector<double> bd(nblk);
@@ -1217,10 +1218,32 @@ int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
     int32_t id = -1;
     for (uint32_t b = 0; b < nblk; b++)  // blocks are in ascending particle order: `<` keeps the first minimum
         if (bd[b] < best) { best = bd[b]; id = static_cast<int32_t>(bi[b]); }
+    *local = id;
+    *best_out = best;
+    return 0;
+}
+}  // namespace
+
+int tetsim_start_grab(tetsim_handle h, const float xyz[3], int32_t* id_out) {
+    if (!h || !xyz) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->partitioned) return fail(h, TETSIM_ESTATE, "start_grab on a partitioned body: combine tetsim_nearest_particle over the partitions on the host, then tetsim_set_grab on each");
+    int32_t id = -1;
+    double best = 0.0;
+    int rc = nearest_owned(h, xyz, &id, &best);
+    if (rc) return rc;
     h->grab_global = id;
     ref_grab_texels(h->grab_global, h->info.num_elems, h->info.num_particles, h->grab_ref);
     std::memcpy(h->grab_pos, xyz, 3 * sizeof(float));
     if (id_out) *id_out = id;
+    return 0;
+}
+
+int tetsim_nearest_particle(tetsim_handle h, const float xyz[3], int32_t* global_id, double* dist2) {
+    if (!h || !xyz || !global_id || !dist2) return fail(h, TETSIM_EINVAL, "null argument");
+    int32_t local = -1;
+    int rc = nearest_owned(h, xyz, &local, dist2);
+    if (rc) return rc;
+    *global_id = local < 0 ? -1 : (h->partitioned ? h->part.local_to_global_vert[local] : local);
     return 0;
 }
 

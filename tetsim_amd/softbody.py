@@ -271,6 +271,14 @@ class SoftBodyHIP:
         self.grabPos[:] = p
         return self.grabId
 
+    def nearestParticle(self, pos):
+        """(global id, squared distance) of the owned particle nearest to pos -- the building block of startGrab for partitioned
+        bodies: min over the partitions (ties: lowest id), then setGrab(id, pos) on each."""
+        p = _f32([pos["x"], pos["y"], pos["z"]] if isinstance(pos, dict) else pos)
+        gid, d2 = C.c_int32(), C.c_double()
+        capi.check(self._L.tetsim_nearest_particle(self._h, _fp(p), C.byref(gid), C.byref(d2)), self._h)
+        return int(gid.value), float(d2.value)
+
     def setGrab(self, gid, pos):
         p = _f32(pos)
         capi.check(self._L.tetsim_set_grab(self._h, int(gid), _fp(p)), self._h)
