@@ -153,7 +153,7 @@ def main():
 def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)   # 200 frames = 4000 substeps = 0.17 s timed: past the clock ramp of a short run
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="fast", choices=["fast", "precise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
