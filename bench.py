@@ -263,7 +263,10 @@ def run():
     # beside it on the halo stream.
     pr = None
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
-        pr = body.profile(SUBSTEPS * 3, DT, PP)
+        # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
+        # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
+        batches = sorted((body.profile(SUBSTEPS * 3, DT, PP) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])
+        pr = batches[1]
         barrier()
     if rank == 0 and pr is not None:
         tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
