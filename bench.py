@@ -134,23 +134,68 @@ class stdout_to_stderr:
         os.close(self._saved)
 
 
-def main():
-    # a rank that is stuck in a collective would otherwise hang the whole launch until someone's outer limit fires
-    import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "900")), exit=True)
-    with stdout_to_stderr():
-        out, rank, dist, body = run()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        with stdout_to_stderr():
-            dist.barrier()
-            body.close()
-            dist.destroy_process_group()
-    faulthandler.cancel_dump_traceback_later()
+class TorchRanks:
+    """One process per GPU (the driver's launch): torch.distributed over RCCL for rendezvous, barrier and the max over ranks.
+    The halo traffic itself does not go through torch: libtetsim_hip owns its RCCL communicator."""
+
+    def __init__(self, local_rank):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def broadcast_bytes(self, data, n):           # rank 0's `data` (n bytes) to everyone
+        t = self.torch.zeros(n, dtype=self.torch.uint8, device="cuda")
+        if data is not None:
+            t.copy_(self.torch.tensor(list(data), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().tolist())
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        self.dist.barrier()
+
+    def max_float(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
 
 
-def run():
+class ThreadRanks:
+    """--fake-ranks N (development / tests on a ONE-GPU box): the N ranks are host threads of this process, all on device 0,
+    and librccl is the strict test double of tests/mock_rccl (TETSIM_RCCL_LIB).  Same code path as the real launch from
+    `run()` down; only this adapter differs."""
+
+    def __init__(self, shared, rank):
+        self.s, self.rank = shared, rank
+
+    def broadcast_bytes(self, data, n):
+        if data is not None:
+            self.s["bytes"] = bytes(data)
+        self.s["barrier"].wait()
+        out = self.s["bytes"]
+        self.s["barrier"].wait()
+        return out
+
+    def barrier(self):
+        self.s["barrier"].wait()
+
+    def max_float(self, x):
+        self.s["vals"][self.rank] = x
+        self.s["barrier"].wait()
+        out = max(self.s["vals"])
+        self.s["barrier"].wait()
+        return out
+
+    def close(self):
+        pass
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # 200 frames = 4000 substeps = 0.17 s timed: past the clock ramp of a short run
@@ -167,7 +212,45 @@ def run():
                     help="N > 1: after the timed region every rank runs 60 more substeps with per-kernel events and rank 0 reports "
                          "its interior tet kernel in `roofline` (default at N > 1: whole-substep figures only)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
-    args = ap.parse_args()
+    ap.add_argument("--fake-ranks", type=int, default=0,
+                    help="development: run N ranks as threads on ONE GPU against the RCCL test double (needs TETSIM_RCCL_LIB=tests/mock_rccl/...)")
+    return ap.parse_args()
+
+
+def main():
+    # a rank that is stuck in a collective would otherwise hang the whole launch until someone's outer limit fires
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "900")), exit=True)
+    args = parse_args()
+    if args.fake_ranks > 1:
+        import threading
+        if "mock_rccl" not in os.environ.get("TETSIM_RCCL_LIB", ""):
+            raise SystemExit("--fake-ranks needs TETSIM_RCCL_LIB to point at the test double (tests/mock_rccl/libmock_rccl.so)")
+        n = args.fake_ranks
+        shared = {"barrier": threading.Barrier(n), "vals": [0.0] * n, "bytes": None}
+        results, errors = [None] * n, []
+
+        def rank_main(r):
+            try:
+                out, body = run(args, r, n, 0, ThreadRanks(shared, r))
+                shared["barrier"].wait()
+                body.close()
+                results[r] = out
+            except BaseException as e:  # noqa: BLE001
+                errors.append("rank %d: %r" % (r, e))
+                shared["barrier"].abort()
+
+        with stdout_to_stderr():
+            threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(n)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+        if errors:
+            raise SystemExit("; ".join(errors))
+        print(json.dumps(results[0]), flush=True)
+        faulthandler.cancel_dump_traceback_later()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,15 +259,23 @@ def run():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
+    with stdout_to_stderr():
+        ranks = TorchRanks(local_rank) if (world > 1 or args.force_dist) else None
+        out, body = run(args, rank, world, local_rank, ranks)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if ranks is not None:
+        with stdout_to_stderr():
+            ranks.barrier()
+            body.close()
+            ranks.close()
+    faulthandler.cancel_dump_traceback_later()
 
-    dist = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+def run(args, rank, world, local_rank, ranks):
+    """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
+    barrier / max_float."""
+    use_dist = ranks is not None
     from tetsim_amd import SoftBodyHIP, make_lattice, measure_copy_bandwidth
 
     # ---- workload ------------------------------------------------------------------------------------
@@ -207,20 +298,14 @@ def run():
     body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
                        device=local_rank, **kw)
     if use_dist:
-        import torch
         from tetsim_amd import comm_init, comm_unique_id
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.tensor(list(comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=0)
-        comm_init(body, bytes(uid.cpu().tolist()), rank, world)
+        uid = ranks.broadcast_bytes(comm_unique_id() if rank == 0 else None, 128)
+        comm_init(body, uid, rank, world)
 
     def barrier():
         body.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        if use_dist:
+            ranks.barrier()
 
     # ---- timed region --------------------------------------------------------------------------------
     for _ in range(args.warmup):
@@ -231,11 +316,8 @@ def run():
         body.simulateSubsteps(SUBSTEPS, DT, PP)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if use_dist:
+        elapsed = ranks.max_float(elapsed)
     pos = body.pos
     if not np.isfinite(pos).all():
         raise SystemExit("non-finite positions after the timed region")
@@ -306,7 +388,7 @@ def run():
         if not args.no_cpu_baseline:
             body.close()
             out["cpu_baseline"] = cpu_baseline(verts, tets)
-    return out, rank, dist, body
+    return out, body
 
 
 if __name__ == "__main__":
