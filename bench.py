@@ -220,7 +220,7 @@ def parse_args():
 def main():
     # a rank that is stuck in a collective would otherwise hang the whole launch until someone's outer limit fires
     import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "900")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "600")), exit=True)
     args = parse_args()
     if args.fake_ranks > 1:
         import threading
