@@ -226,6 +226,7 @@ def main():
         import threading
         if "mock_rccl" not in os.environ.get("TETSIM_RCCL_LIB", ""):
             raise SystemExit("--fake-ranks needs TETSIM_RCCL_LIB to point at the test double (tests/mock_rccl/libmock_rccl.so)")
+        os.environ["TETSIM_HALO_GRAPH"] = "0"   # the test double rendezvouses on the host: not capturable
         n = args.fake_ranks
         shared = {"barrier": threading.Barrier(n), "vals": [0.0] * n, "bytes": None}
         results, errors = [None] * n, []

@@ -9,6 +9,8 @@ import threading
 
 import numpy as np
 
+os.environ["TETSIM_HALO_GRAPH"] = "0"   # the test double rendezvouses on the host: not capturable (the real RCCL is: tools/loopback_rank.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tetsim_amd import SoftBodyHIP, comm_init, comm_unique_id, make_lattice  # noqa: E402

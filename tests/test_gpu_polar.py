@@ -381,6 +381,26 @@ def test_rccl_code_path_against_a_strict_test_double(nranks, precision, cells):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("precision,cells", [("fast", 12), ("precise", 6)])
+def test_halo_graph_equals_eager_with_the_real_rccl_in_loopback(precision, cells):
+    """RCCL bodies step through ONE captured HIP graph per call (both streams, the grouped ncclSend/ncclRecv included).
+    With the real RCCL kernels in the loop -- a middle slab whose halo partner is itself -- the graph route must be live,
+    replayable, and give bit for bit what eager stepping gives."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_loopback_check.py")
+    out = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, script, str(cells), precision], capture_output=True, text=True, timeout=180,
+                           env=dict(os.environ, TETSIM_HALO_GRAPH=mode))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert r.returncode == 0 and len(lines) == 1, r.stdout[-800:] + r.stderr[-1500:]
+        assert "halo graph capture failed" not in r.stderr, r.stderr[-1500:]
+        out[mode] = lines[0]
+    assert out["0"] == out["1"], out
+
+
 def test_lattice_1m_properties():
     """BASELINE config 3 at full size: size-independent properties instead of a CPU run."""
     v, t = make_lattice(55)

@@ -86,6 +86,9 @@ struct tetsim_body {
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
     uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
+    bool halo_graph_broken = false;
+    bool halo_warm = false;             // RCCL bodies: one eager call has run (connections are set up before any capture)
+    bool loopback = false;              // measurement only (TETSIM_DEBUG_LOOPBACK_HALO): every neighbour is this rank itself
     bool needs_halo_refresh = false;    // in-process group: predictions were redone for a new dt
     bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
@@ -315,13 +318,13 @@ int halo_start(tetsim_body* h) {
         for (auto& nb : h->neigh) {
             if (nb.send_count) {
                 const float4* src = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
-                r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+                r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
                 if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
             }
             if (nb.recv_count) {
                 // posted on OUR halo stream, i.e. after our boundary pass of this substep: the ghosts are overwritten only
                 // once this partition's tet kernels (which read them) are done
-                r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, nb.rank, h->comm, h->comm_stream);
+                r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
                 if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
             }
         }
@@ -464,7 +467,17 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
+    const bool halo = has_transport(h);
+    if (halo) {  // the graph is self-contained: it forks the halo stream from the main stream and joins it before it ends
+        h->halo_pending = false;
+        h->fork_needed = true;
+    }
     for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+    if (halo && !rc) {
+        hipError_t je = hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0);  // join: the last transfer
+        if (je != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("join: ") + hipGetErrorString(je));
+        h->halo_pending = false;
+    }
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -933,8 +946,10 @@ void tetsim_destroy(tetsim_handle h) {
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
     }
-    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->pinned_pos) (void)hipHostFree(h->pinned_pos);
@@ -971,14 +986,35 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
-    if (has_transport(h)) {  // halo transfers are issued eagerly (two streams, no capture)
-        for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
-        return rc;
+    if (has_transport(h)) {
+        // RCCL bodies: the first call runs eagerly (RCCL sets its connections up on first use, which must not happen inside a
+        // capture); afterwards the n substeps -- both streams, the grouped send/recv included -- are one captured graph:
+        // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
+        // critical path.  TETSIM_HALO_GRAPH=0 keeps everything eager.
+        static const bool use_graph = [] { const char* e = getenv("TETSIM_HALO_GRAPH"); return !(e && e[0] == '0'); }();
+        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken) {
+            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            h->halo_warm = true;
+            return rc;
+        }
+        if (h->halo_pending) {  // leftovers of eager calls: join them first
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0));
+            h->halo_pending = false;
+        }
     }
     auto it = h->graphs.find(n);
     if (it == h->graphs.end()) {
         hipGraphExec_t exec = nullptr;
-        if ((rc = build_graph(h, n, &exec))) return rc;
+        if ((rc = build_graph(h, n, &exec))) {
+            if (!has_transport(h)) return rc;
+            // a halo graph that cannot be built (an RCCL build that refuses capture): stay eager for good, loudly
+            fprintf(stderr, "[tetsim] halo graph capture failed (%s); falling back to eager halo stepping\n", h->err.c_str());
+            h->halo_graph_broken = true;
+            (void)hipGetLastError();
+            rc = 0;
+            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            return rc;
+        }
         it = h->graphs.emplace(n, exec).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
@@ -1417,7 +1453,16 @@ int tetsim_comm_unique_id(void* id128) {
 int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t nranks) {
     if (!h || !id128) return fail(h, TETSIM_EINVAL, "null argument");
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "halo exchange exists only for POLAR_JACOBI");
-    if (nranks != h->opt.part_count || rank != h->opt.part_index) return fail(h, TETSIM_EINVAL, "rank/nranks must equal part_index/part_count");
+    // Measurement aid: TETSIM_DEBUG_LOOPBACK_HALO=1 + nranks == 1 on a PARTITIONED body makes every neighbour this rank itself:
+    // the real RCCL send/recv kernels then run in the real choreography on one GPU (ghosts receive this rank's own interface
+    // values, so the physics is meaningless -- timing and liveness only).
+    const char* lb = getenv("TETSIM_DEBUG_LOOPBACK_HALO");
+    if (lb && lb[0] == '1' && nranks == 1 && rank == 0 && h->opt.part_count > 1) {
+        for (auto& nb : h->neigh)
+            if (nb.send_count != nb.recv_count) return fail(h, TETSIM_ESTATE, "loopback halo needs equal send and receive counts per neighbour (use equal slabs)");
+        h->loopback = true;
+        fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_LOOPBACK_HALO: partition %d exchanges halos with ITSELF; results are not physics\n", h->opt.part_index);
+    } else if (nranks != h->opt.part_count || rank != h->opt.part_index) return fail(h, TETSIM_EINVAL, "rank/nranks must equal part_index/part_count");
     if (!g_rccl.load()) return fail(h, TETSIM_ECOMM, g_rccl.err);
     HIPCHK(h, hipSetDevice(h->opt.device));
     ncclUniqueId id;

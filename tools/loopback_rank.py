@@ -1,0 +1,30 @@
+"""What ONE interior rank of the slab decomposition costs per substep with the REAL RCCL kernels in the loop, on one GPU:
+the middle slab of a 3-slab lattice (1 M tets + two ghost layers, two neighbours) whose halo partner is itself
+(TETSIM_DEBUG_LOOPBACK_HALO=1: measurement only, the physics is meaningless).  Compared with the monolithic 1 M-tet body."""
+import os, sys, time
+os.environ["TETSIM_DEBUG_LOOPBACK_HALO"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tetsim_amd import SoftBodyHIP, comm_init, comm_unique_id, make_lattice
+PP = dict(gravity=0.0, friction=1000.0, density=1000.0, worldBounds=[-2.5, -1.0, -10.0, 2.5, 10.0, 10.0])   # g = 0: the self-halo keeps the lattice at rest
+DT = (1 / 60) / 20
+cells = 55
+mv, mt = make_lattice(cells)
+mono = SoftBodyHIP(mv, mt, None, dict(PP), solver="polar", precision="fast")
+v, t = make_lattice(cells, nz=cells * 3)
+plane = (cells + 1) ** 2
+owner = np.minimum((np.arange(len(v)) // plane) // cells, 2).astype(np.int32)
+owner[(np.arange(len(v)) // plane) >= 2 * cells] = 2
+mid = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=3, part_index=1, vert_owner=owner, ref_fixed_bounds=False)
+comm_init(mid, comm_unique_id(), 0, 1)
+print("middle slab: %d owned particles, %d local tets (%d owned), %d neighbours" % (mid.info.owned_particles, mid.info.local_elems, mid.info.owned_elems, mid.info.num_neighbours))
+for name, body in (("monolithic", mono), ("middle rank, RCCL loopback halo", mid)):
+    for _ in range(10): body.simulateSubsteps(20, DT, PP)
+    body.sync()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for _ in range(50): body.simulateSubsteps(20, DT, PP)
+        th = time.perf_counter() - t0
+        body.sync(); tt = time.perf_counter() - t0
+        print("%-34s host enqueue %.1f us, wall %.1f us per substep" % (name, th / 1000 * 1e6, tt / 1000 * 1e6), flush=True)
+    assert np.isfinite(body.pos).all()

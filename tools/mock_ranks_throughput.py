@@ -5,6 +5,8 @@ work of all ranks.  Compare tets/s with the monolithic body: the difference is w
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+
+os.environ["TETSIM_HALO_GRAPH"] = "0"   # the test double rendezvouses on the host: not capturable (the real RCCL is: tools/loopback_rank.py)
 from tetsim_amd import SoftBodyHIP, comm_init, comm_unique_id, make_lattice
 nranks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 cells = 55
