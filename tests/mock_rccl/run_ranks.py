@@ -45,10 +45,16 @@ def rank_main(r):
             else:
                 body.simulateSubsteps(per_call, dts[c], PP)      # tetsim_step_n
         results[r] = (body.ownedIds, body.pos)
-        if precision == "fast":   # tetsim_profile on a body with an RCCL halo: every rank together, interior tet kernel timed
-            pr = body.profile(6, DT, PP)
-            assert pr["substeps"] == 6 and pr["tet_launches"] == 6 and 0 < pr["tets_per_tet_launch"] <= body.info.local_elems, pr
-            assert 0.0 < pr["tet_ms"] and 0.0 < pr["vertex_ms"], pr
+        if precision == "fast" and cells >= 20:   # (thinner slabs: some ranks have no interior tiles and refuse, others would wait)
+            # tetsim_profile on a body with an RCCL halo: every rank together, interior tet kernel timed
+            try:
+                pr = body.profile(6, DT, PP)
+            except Exception as e:  # noqa: BLE001 -- a slab this thin has no interior tiles: a clean refusal, on every rank alike
+                assert "no interior tiles" in str(e), e
+                pr = None
+            if pr is not None:
+                assert pr["substeps"] == 6 and pr["tet_launches"] == 6 and 0 < pr["tets_per_tet_launch"] <= body.info.local_elems, pr
+                assert 0.0 < pr["tet_ms"] and 0.0 < pr["vertex_ms"], pr
         body.close()
     except Exception as e:  # noqa: BLE001
         errors.append("rank %d: %r" % (r, e))
@@ -60,7 +66,7 @@ for th in threads:
 for th in threads:
     th.join(timeout=240)
 if errors or any(th.is_alive() for th in threads):
-    print("FAILED", errors, [th.is_alive() for th in threads])
+    print("FAILED", errors, [th.is_alive() for th in threads], flush=True)
     os._exit(1)
 got = np.full_like(want, np.nan)
 for ids, pos in results:

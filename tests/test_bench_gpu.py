@@ -43,10 +43,11 @@ def test_multi_rank_code_path_with_thread_ranks(extra):
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-std=c++17", os.path.join(here, "mock_rccl.cpp"), "-o", lib],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-    d = _run(["--fake-ranks", "3", "--cells", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra, env={"TETSIM_RCCL_LIB": lib})
+    cells = 24 if "--profile-ranks" in extra else 12      # per-kernel profiling needs interior tiles on every rank
+    d = _run(["--fake-ranks", "3", "--cells", str(cells), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra, env={"TETSIM_RCCL_LIB": lib})
     assert REQUIRED <= set(d) and d["n_gpus"] == 3 and d["value"] > 0
-    cells_z = 12 if "strong" in extra else 36
-    assert d["config"]["tets"] == 12 * 12 * cells_z * 6 and d["scaling"] == ("strong" if "strong" in extra else "weak")
+    cells_z = cells if "strong" in extra else 3 * cells
+    assert d["config"]["tets"] == cells * cells * cells_z * 6 and d["scaling"] == ("strong" if "strong" in extra else "weak")
     assert "x3" in d["config"]["parallelism"]
     if "--profile-ranks" in extra:
         assert "interior tiles" in d["roofline"]["kernel"] and d["roofline"]["kernel_us"] > 0

@@ -46,7 +46,9 @@ struct PJDev {
 // particle (fixed order: deterministic), and the per-particle pass adds the few partial sums of the tiles
 // that touch it.
 struct PJBlk {
-    uint32_t nb = 0, nb_interior = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0;  // tiles >= nb_interior touch ghosts
+    // tile order I | N | G: [0, nb_interior) I, the next nb_near N (no ghost, but a particle shared with a G tile), the rest G
+    // (touch ghosts); owned particle order [interface | near | deep]: the first nv_near are the ones G tiles touch
+    uint32_t nb = 0, nb_interior = 0, nb_near = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0, nv_near = 0;
     const uint32_t* blk_tet_off = nullptr;   // [nb+1]
     const uint32_t* blk_vert_off = nullptr;  // [nb+1]
     const int32_t* blk_verts = nullptr;      // particle id of every tile slot
