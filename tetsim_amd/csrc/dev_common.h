@@ -46,9 +46,7 @@ struct PJDev {
 // particle (fixed order: deterministic), and the per-particle pass adds the few partial sums of the tiles
 // that touch it.
 struct PJBlk {
-    // tile order I | N | G: [0, nb_interior) I, the next nb_near N (no ghost, but a particle shared with a G tile), the rest G
-    // (touch ghosts); owned particle order [interface | near | deep]: the first nv_near are the ones G tiles touch
-    uint32_t nb = 0, nb_interior = 0, nb_near = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0, nv_near = 0;
+    uint32_t nb = 0, nb_interior = 0, nt = 0, nv_local = 0, nv_owned = 0, nv_boundary = 0;  // tiles >= nb_interior touch ghosts
     const uint32_t* blk_tet_off = nullptr;   // [nb+1]
     const uint32_t* blk_vert_off = nullptr;  // [nb+1]
     const int32_t* blk_verts = nullptr;      // particle id of every tile slot
@@ -100,6 +98,16 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
                     hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
+// Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `wait` / `signal` are device words holding the sequence number of
+// the last finished producer launch, `seq` = this substep.
+struct PJSync {
+    const uint32_t* wait = nullptr;
+    uint32_t* signal = nullptr;
+    uint32_t* error = nullptr;
+    uint32_t seq = 0;
+};
+void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await
+void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: publish seq
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_predict_fast(hipStream_t s, const NHDev& d);
@@ -126,5 +134,6 @@ void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, 
                          double* best_d2, uint32_t* best_id);
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n);
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
+
 
 }  // namespace tetsim

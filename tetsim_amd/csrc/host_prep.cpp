@@ -221,17 +221,12 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
     return order;
 }
 
-namespace {
-// A tile = a run [begin, end) of the Morton-sorted tets.  cls: 0 = I (touches neither a ghost particle nor a particle of a
-// ghost-touching tile), 1 = N (no ghost, but shares a particle with a G tile), 2 = G (touches a ghost particle).
-struct TileRun { uint32_t begin, end; uint8_t cls; };
-
-// Steps 1 and 2 of the tiling: Morton order of the rest centroids, greedy cut into tiles of <= 256 tets / <= 256 distinct
-// particles, classification.  Depends on the particle NUMBERING only through identities, so it gives the same tiles
-// before and after the device renumbering.  in_c[v] = 1 for every particle of a G tile.
-void form_tiles(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum, std::vector<int32_t>* tet_perm,
-                std::vector<TileRun>* runs_out, std::vector<uint8_t>* in_c) {
+void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
+                  const Incidence& inc, BlockPlan* out) {
+    BlockPlan& B = *out;
+    B = BlockPlan();
     constexpr uint32_t kMaxTets = 256, kMaxVerts = 256;
+    // 1. Morton order of rest centroids (quantised to 10 bits per axis over the bounding box)
     const Quantiser Q(verts, nv);
     std::vector<uint64_t> key(nt);
     for (uint32_t e = 0; e < nt; e++) {
@@ -241,73 +236,47 @@ void form_tiles(const float* verts, const int32_t* tets, uint32_t nt, uint32_t n
         key[e] = (static_cast<uint64_t>(Q.code(0.25f * m[0], 0.25f * m[1], 0.25f * m[2])) << 32) | e;  // ties keep the caller's order
     }
     std::sort(key.begin(), key.end());
-    tet_perm->resize(nt);
-    for (uint32_t i = 0; i < nt; i++) (*tet_perm)[i] = static_cast<int32_t>(key[i] & 0xffffffffu);
-
-    std::vector<int32_t> slot_of(nv, -1);
-    std::vector<int32_t> touched;
-    std::vector<TileRun>& runs = *runs_out;
-    runs.clear();
-    in_c->assign(nv, 0);
-    uint32_t i = 0;
-    while (i < nt) {
-        const uint32_t t0 = i;
-        touched.clear();
-        bool ghost = false;
-        while (i < nt && i - t0 < kMaxTets) {
-            const int32_t* t = &tets[4 * (*tet_perm)[i]];
-            uint32_t fresh = 0;
-            for (int k = 0; k < 4; k++) {
-                bool seen = slot_of[t[k]] >= 0;
-                for (int j = 0; j < k && !seen; j++) seen = t[j] == t[k];
-                if (!seen) fresh++;
-            }
-            if (touched.size() + fresh > kMaxVerts) break;
-            for (int k = 0; k < 4; k++)
-                if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); ghost |= static_cast<uint32_t>(t[k]) >= nv_sum; }
-            i++;
-        }
-        for (int32_t v : touched) { slot_of[v] = -1; if (ghost) (*in_c)[v] = 1; }
-        runs.push_back({t0, i, static_cast<uint8_t>(ghost ? 2 : 0)});
-    }
-    for (TileRun& r : runs) {
-        if (r.cls == 2) continue;
-        for (uint32_t j = r.begin; j < r.end && r.cls == 0; j++)
-            for (int k = 0; k < 4; k++)
-                if ((*in_c)[tets[4 * (*tet_perm)[j] + k]]) { r.cls = 1; break; }
-    }
-}
-}  // namespace
-
-std::vector<uint8_t> near_halo_particles(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum) {
-    std::vector<int32_t> perm;
-    std::vector<TileRun> runs;
-    std::vector<uint8_t> in_c;
-    form_tiles(verts, tets, nt, nv, nv_sum, &perm, &runs, &in_c);
-    return in_c;
-}
-
-void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
-                  const Incidence& inc, BlockPlan* out) {
-    BlockPlan& B = *out;
-    B = BlockPlan();
-    // 1 + 2. Morton order, greedy tiling, classification
-    std::vector<TileRun> runs;
-    std::vector<uint8_t> in_c;
-    form_tiles(verts, tets, nt, nv, nv_sum, &B.tet_perm, &runs, &in_c);
+    B.tet_perm.resize(nt);
+    for (uint32_t i = 0; i < nt; i++) B.tet_perm[i] = static_cast<int32_t>(key[i] & 0xffffffffu);
 
     // which (tet,corner) contributions are live (the incidence table may drop some: reference quirk / cap)
     std::vector<uint8_t> live(4ull * nt, 0);
     for (int32_t enc : inc.slot) live[enc] = 1;
 
-    // Order I | N | G.  A partitioned body runs the G tiles (and the particles they touch) on its halo stream behind the
-    // transfer they need, the N tiles first on the main stream (both sides' particle passes wait for them), and the I tiles
-    // -- the bulk -- need nothing from the halo side within a substep.  Unpartitioned: everything is I, order unchanged.
-    std::stable_sort(runs.begin(), runs.end(), [](const TileRun& a, const TileRun& b) { return a.cls < b.cls; });
+    // 2. greedy tiling along the curve: tile = a run [begin, end) of the sorted tets
+    std::vector<int32_t> slot_of(nv, -1);
+    std::vector<int32_t> touched;
+    struct Run { uint32_t begin, end; bool ghost; };
+    std::vector<Run> runs;
+    {
+        uint32_t i = 0;
+        while (i < nt) {
+            const uint32_t t0 = i;
+            touched.clear();
+            bool ghost = false;
+            while (i < nt && i - t0 < kMaxTets) {
+                const int32_t* t = &tets[4 * B.tet_perm[i]];
+                uint32_t fresh = 0;
+                for (int k = 0; k < 4; k++) {
+                    bool seen = slot_of[t[k]] >= 0;
+                    for (int j = 0; j < k && !seen; j++) seen = t[j] == t[k];
+                    if (!seen) fresh++;
+                }
+                if (touched.size() + fresh > kMaxVerts) break;
+                for (int k = 0; k < 4; k++)
+                    if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); ghost |= static_cast<uint32_t>(t[k]) >= nv_sum; }
+                i++;
+            }
+            for (int32_t v : touched) slot_of[v] = -1;
+            runs.push_back({t0, i, ghost});
+        }
+    }
+    // tiles that touch a ghost particle go last: a partitioned body solves the others while the halo is in flight
+    std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.ghost < b.ghost; });
     {
         std::vector<int32_t> perm2(nt);
         uint32_t o = 0;
-        for (TileRun& r : runs) {
+        for (Run& r : runs) {
             std::copy(B.tet_perm.begin() + r.begin, B.tet_perm.begin() + r.end, perm2.begin() + o);
             const uint32_t len = r.end - r.begin;
             r.begin = o; r.end = o + len;
@@ -315,8 +284,6 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
         }
         B.tet_perm.swap(perm2);
     }
-    std::vector<int32_t> slot_of(nv, -1);
-    std::vector<int32_t> touched;
 
     // 3. emit per-tile tables
     B.tet_lidx.resize(4ull * nt);
@@ -324,10 +291,9 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     B.blk_tet_off.push_back(0);
     B.blk_vert_off.push_back(0);
     std::vector<std::vector<uint32_t>> vert_partials(nv_sum);
-    for (const TileRun& r : runs) {
+    for (const Run& r : runs) {
         const uint32_t t0 = r.begin, i = r.end;
-        if (r.cls == 0) B.num_interior_blocks++;
-        if (r.cls == 1) B.num_near_blocks++;
+        if (!r.ghost) B.num_interior_blocks++;
         touched.clear();
         for (uint32_t j = t0; j < i; j++)
             for (int k = 0; k < 4; k++) {

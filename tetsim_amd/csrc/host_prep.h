@@ -76,17 +76,12 @@ struct BlockPlan {
     std::vector<uint32_t> vp_ell;        // the same lists as ELL [max_partials][nv_pad], 0xffffffff = none
     uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
-    // tile order I | N | G: [0, num_interior_blocks) touch neither a ghost particle (>= nv_sum) nor a particle of a tile that
-    // does; the next num_near_blocks touch no ghost but share a particle with a ghost-touching tile; the rest touch ghosts
-    uint32_t num_interior_blocks = 0, num_near_blocks = 0;
+    uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no particle >= nv_sum (no ghost)
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
 // it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out);
-// in_c[v] = 1 for every particle that shares a tile with a ghost particle (the same tiling build_blocks produces; it does
-// not depend on the particle numbering).  The device numbering puts these particles first: [interface | near | deep | ghosts].
-std::vector<uint8_t> near_halo_particles(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum);
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 

@@ -30,6 +30,7 @@
 // mode only; PRECISE keeps the reference's slot order.
 #define TETSIM_FAST 1
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 
 #include "dev_common.h"
@@ -60,8 +61,7 @@ constexpr uint32_t kTile = 256;
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // `dbg` is a development knob for timing ablations (bits 0-3: rotation iterations, bit 4: skip the rest-shape
 // write-back); the product always passes 9 / 0 -- anything else produces wrong physics.
-__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                        uint32_t tiles_per_xcd, uint32_t dbg) {
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t dbg) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -164,9 +164,40 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_
 #undef TETSIM_STAMP
 }
 
+__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                        uint32_t tiles_per_xcd, uint32_t dbg) {
+    pjb_tet_body(d, tile_first, tile_count, tiles_per_xcd, dbg);
+}
+
+// ---- cross-queue hand-over of partitioned bodies ----------------------------------------------------------
+// A partitioned substep runs on two queues (ghost-touching tiles + transfer on the halo stream, everything else on the main
+// stream).  A dependency between the queues costs ~15 us as an event (eager) and ~6 us as a fork/join edge of a captured graph
+// on this stack (tools/micro/xq_latency.hip), and the cycle  particles(s) -> transfer(s) -> G tiles(s+1) -> particles(s+1)
+// has two of them.  Here the producer queue runs a ONE-WAVE signal kernel behind its kernel (in-order queue: the kernel and
+// its agent-scope release are complete) and the consumer queue a one-wave wait kernel in front of the dependent kernel (whose
+// own start then performs the agent-scope acquire): ~5 us each under load, nothing else in either queue is delayed.
+// `seq` = the substep's sequence number, so a word is never reset.  The wait is bounded (~2 s, then *error is raised and it
+// carries on): a wedged peer must not wedge this GPU.  The host submits every signal before the matching wait, so even a
+// single shared hardware queue stays live.
+// Tried and dropped: the hand-over inside the compute kernels (last-workgroup detection / every workgroup polling on entry).
+// Any per-workgroup device-scope atomic -- read-modify-write or load, one word or 64 words a cache line apart -- costs
+// ~20 ns and serialises: the 2,744-workgroup particle pass went from 7 us to 60-400 us.
+__device__ __forceinline__ void await_done(const PJSync& y) {
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (static_cast<int32_t>(__hip_atomic_load(y.wait, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - y.seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000ll) {   // 100 MHz ticks: 2 s
+                __hip_atomic_store(y.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+}
+
 // 64-thread workgroups: 175,616 particles are only 2,744 waves (2.7 per SIMD); one-wave workgroups spread over the
 // 256 CUs evenly (10.7 per CU) where 256-thread ones leave some CUs with 3 and others with 2.
-__global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) {
+__device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, uint32_t count) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = first + i;
@@ -211,6 +242,10 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first,
     store_wt(&d.pos_pred[v], make_float4(pred.x, pred.y, pred.z, 0.0f));
 }
 
+__global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
+__global__ void pjb_wait_kernel(PJSync y) { await_done(y); }
+__global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.signal, y.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
     if (v >= d.nv_owned) return;
@@ -220,9 +255,7 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 
 }  // namespace
 
-void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
-    if (tile_count == 0) return;
-    const uint32_t per_xcd = (tile_count + 7u) / 8u;
+static uint32_t tet_mode(const PJBlk& d) {
     static int dbg = -1;
     if (dbg < 0) {  // timing ablations only (see kernel comment); unset => 9 iterations, all stores
         const char* it = getenv("TETSIM_DEBUG_ITERS");
@@ -233,10 +266,17 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
         if ((dbg & 15) != 9 || (dbg & 16))  // these two change the physics: never silently
             fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_ITERS / TETSIM_DEBUG_SKIP_REST_STORE are set: timing ablation, the results are NOT the solver's\n");
     }
-    const uint32_t mode = static_cast<uint32_t>(dbg) | (d.lean ? 128u : 0u);
+    return static_cast<uint32_t>(dbg) | (d.lean ? 128u : 0u);
+}
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
+    if (tile_count == 0) return;
+    const uint32_t per_xcd = (tile_count + 7u) / 8u;
+    const uint32_t mode = tet_mode(d);
     if (e0) hipExtLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, mode);
     else hipLaunchKernelGGL(pjb_tet_kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, mode);
 }
+void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
+void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
     if (count == 0) return;
     if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count);

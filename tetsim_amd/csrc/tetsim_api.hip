@@ -28,6 +28,8 @@ namespace {
 
 thread_local std::string g_create_error;
 constexpr int kRing = 64;  // pinned parameter slots in flight
+// device words of the flag-synchronised halo path: [0] G flag, [2] V flag, [4] error
+constexpr uint32_t kSyncWords = 8;
 
 // ---- RCCL, resolved at run time so single-GPU hosts (and the N-API addon) do not need librccl ----------
 struct Rccl {
@@ -84,9 +86,11 @@ struct tetsim_body {
     TetSimOptions opt{};
     TetSimInfo info{};
     hipStream_t stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr, ev_near = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
     uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
-    bool two_stream = false;            // blocked + transport: interface particles are produced on the halo stream itself
+    uint32_t halo_seq = 0;              // substep sequence number of the flag-synchronised path
+    uint32_t* d_sync = nullptr;         // device counters of the flag-synchronised halo path: G done/taken, V done/taken, error
+    bool flag_sync = false;             // this body steps through the flag-synchronised path (blocked + transport)
     bool halo_graph_broken = false;
     bool halo_warm = false;             // RCCL bodies: one eager call has run (connections are set up before any capture)
     bool loopback = false;              // measurement only (TETSIM_DEBUG_LOOPBACK_HALO): every neighbour is this rank itself
@@ -246,8 +250,6 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
     fill_params(h, dt, *params, &h->h_ring[slot]);
-    // two-stream bodies: the previous substep's near-particle pass (halo stream) still reads the device copy
-    if (h->two_stream && h->halo_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_near, 0));
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
@@ -277,9 +279,6 @@ void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = n
     if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
     else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count, e0, e1) : pj_launch_vertex_precise(h->stream, h->pj, first, count, e0, e1);
 }
-void pj_vertex_on(tetsim_body* h, hipStream_t st, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-    pjb_launch_vertex(st, h->blk, first, count, e0, e1);  // blocked bodies only
-}
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
     else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
@@ -294,7 +293,6 @@ int create_halo_stream(tetsim_body* h) {
     HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_bnd_tet, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_near, hipEventDisableTiming));
     return 0;
 }
 
@@ -315,7 +313,7 @@ int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
 //   our next boundary pass overwrites the very buffer our transfer reads
 int halo_start(tetsim_body* h) {
     const uint32_t p = h->halo_parity;
-    if (h->two_stream) {  // the interface particles were just written on the halo stream: everything stays in stream order
+    if (h->flag_sync) {  // the halo stream already waited for this substep's particle pass (wait V): stay in stream order
         for (auto& nb : h->neigh)
             if (!nb.contiguous && nb.send_count) util_launch_gather4(h->comm_stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
     } else {
@@ -324,7 +322,11 @@ int halo_start(tetsim_body* h) {
         { HP("record packed"); HIPCHK(h, hipEventRecord(h->ev_packed2[p], h->stream)); }
         { HP("comm wait packed"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_packed2[p], 0)); }
     }
-    if (h->comm) {
+    static const bool lb_copy = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_COPY"); return e && e[0] == '1'; }();
+    if (h->comm && h->loopback && lb_copy) {  // measurement only: the loopback transfer as a plain copy kernel instead of RCCL
+        for (auto& nb : h->neigh)
+            if (nb.send_count) util_launch_copy(h->comm_stream, nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf, h->pj.pos_pred + nb.recv_start, nb.send_count);
+    } else if (h->comm) {
         ncclResult_t r = g_rccl.GroupStart();
         if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
         for (auto& nb : h->neigh) {
@@ -354,7 +356,7 @@ int halo_start(tetsim_body* h) {
             { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
         }
     }
-    { HP("record sent"); HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream)); }
+    if (!(h->flag_sync && h->comm)) { HP("record sent"); HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream)); }  // (RCCL + flags: stream order is all there is)
     h->halo_pending = true;
     return 0;
 }
@@ -371,6 +373,12 @@ int halo_wait(tetsim_body* h, hipStream_t on) {
     return 0;
 }
 bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
+// blocked bodies with a transport and ghost-touching tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
+bool uses_flag_sync(const tetsim_body* h) {
+    static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();
+    static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
+    return use_flags && !one_stream && has_transport(h) && h->blocked && h->blk.nb > h->blk.nb_interior;
+}
 
 // Host cost matters here: a substep is ~42 us of GPU work and every launch / event call costs 1.5-4 us, so the eager
 // halo path issues as few operations as possible -- 3 kernel launches (interior tiles, boundary tiles, ONE particle pass),
@@ -383,41 +391,59 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr) {  // tet kernels 
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
+        static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();  // "events" = the older path
+        if (nbnd && !one_stream && use_flags) {
+            // Two queues, synchronised through device counters instead of events (util_kernels.hip: a cross-stream event costs
+            // ~15 us eagerly and ~6 us as a graph edge here, and a substep has two on its critical path):
+            //   main stream:  interior tiles(s) -> wait G(s) -> particles(s) -> signal V(s)
+            //   halo stream:  ghost tiles G(s) -> signal G(s) -> wait V(s) -> transfer(s)              [transfer(s-1) precedes G(s)]
+            // signal / wait are one-wave kernels (pj_blocked.hip).  Host submission order follows the dependencies (G, signal G,
+            // interior, wait G, particles, signal V, wait V, transfer): every wait is submitted after its signal, so the path
+            // stays live even if the runtime maps both streams onto one hardware queue (it then merely serialises).
+            if (!h->d_sync) {
+                int rc = dev_alloc(h, &h->d_sync, kSyncWords);
+                if (rc) return rc;
+                HIPCHK(h, hipMemset(h->d_sync, 0, kSyncWords * sizeof(uint32_t)));
+                HIPCHK(h, hipDeviceSynchronize());   // once: the halo stream must also see everything create() uploaded
+            }
+            h->flag_sync = true;
+            const uint32_t seq = ++h->halo_seq;
+            PJSync yg, yv;   // word 0: "G tiles of substep seq are done"; word 2: "particles of substep seq are done"
+            yg.wait = yg.signal = h->d_sync + 0; yg.error = h->d_sync + 4; yg.seq = seq;
+            yv.wait = yv.signal = h->d_sync + 2; yv.error = h->d_sync + 4; yv.seq = seq;
+            int rc = halo_wait(h, h->comm_stream);   // in-process groups: the neighbours' transfers of the previous substep (events)
+            if (rc) return rc;
+            { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
+            { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+            if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
+            { HP("wait G"); pjb_launch_wait(h->stream, yg); }
+            { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+            { HP("signal V"); pjb_launch_signal(h->stream, yv); }
+            { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            return 0;
+        }
         if (nbnd && !one_stream) {
-            // Two sub-domains, two streams, no cross-stream dependency on either critical chain (a cross-queue dependency
-            // costs ~6-10 us on this stack, eagerly and inside a captured graph alike; measured with the real RCCL kernels
-            // in loopback, tools/loopback_rank.py):
-            //   halo stream (high priority):  transfer(s-1) -> G tiles(s) -> near particles(s) -> transfer(s)
-            //   main stream:                  N tiles(s) -> I tiles(s) -> deep particles(s)
-            // G tiles touch ghosts; "near" particles are the owned particles of G tiles (the interface ones that are sent
-            // included); N tiles are the other tiles that touch a near particle; I tiles and deep particles are the bulk.
-            // The two dependencies between the chains -- near particles(s) need N tiles(s), N tiles(s+1) need near
-            // particles(s) -- have most of a substep of slack each.  Tets of I tiles read deep particles only and deep
-            // particles are summed from N and I tiles only, so the bulk never waits for the halo.
-            const uint32_t nI = h->blk.nb_interior, nN = h->blk.nb_near, nG = nbnd - nN, nvc = h->blk.nv_near;
-            h->two_stream = true;
+            // (TETSIM_HALO_SYNC=events) Interior tiles read no ghost and start at once on the main stream.  The few boundary tiles (272 of 3984 on a
+            // 1 M-tet slab) are launched on the HALO stream, right behind the transfer they depend on: after the interior
+            // kernel on the main stream they cost a whole extra kernel latency (10-16 us: load -> 9 rotation iterations ->
+            // store, however few tiles); beside it their workgroups slot in as interior ones retire (the halo stream has high
+            // priority).  It also saves host work, which matters at ~2-4 us per HIP call against ~42 us of GPU work per
+            // substep: no event between the transfer and its consumer.
+            // Ordering: the halo stream is behind packed[p-1], recorded after the previous particle pass, so the boundary
+            // kernel is behind everything it reads; the first substep of a call forks explicitly.
             if (h->fork_needed || !h->halo_pending) {
                 HP("fork");
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_fork, 0));
                 h->fork_needed = false;
             }
-            if (h->halo_pending) {
-                HP("main wait near");  // N tiles read the near particles of the previous substep (halo stream)
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_near, 0));
-            }
-            { HP("launch tet near"); pjb_launch_tet(h->stream, h->blk, nI, nN); }
-            { HP("record near tets"); HIPCHK(h, hipEventRecord(h->ev_bnd_tet, h->stream)); }
-            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, nI, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
             int rc = halo_wait(h, h->comm_stream);
             if (rc) return rc;
-            { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, nI + nN, nG); }
-            if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // ghosts are free again
-            { HP("halo wait near tets"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_bnd_tet, 0)); }
-            { HP("launch vertex near"); pj_vertex_on(h, h->comm_stream, 0, nvc); }
-            { HP("record near"); HIPCHK(h, hipEventRecord(h->ev_near, h->comm_stream)); }
-            { HP("launch vertex deep"); pj_vertex_on(h, h->stream, nvc, h->pj.nv_owned - nvc, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
-            return 0;
+            { HP("launch tet boundary"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
+            { HP("record bnd_tet"); HIPCHK(h, hipEventRecord(h->ev_bnd_tet, h->comm_stream)); }
+            { HP("main wait bnd_tet"); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_bnd_tet, 0)); }
         } else {
             pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
             int rc = halo_wait(h, h->stream);
@@ -473,16 +499,16 @@ int ensure_prediction(tetsim_body* h, double dt) {
         if (h->partitioned && !h->neigh.empty() && !has_transport(h))
             return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body without a transport (ghost predictions would be stale): "
                                           "exchange halos through tetsim_comm_init / tetsim_group_step_n, or keep dt fixed");
-        // two-stream bodies: the near particles' state was written on the halo stream by the previous substep
-        if (h->two_stream && h->halo_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_near, 0));
         pj_repredict(h);
         // the neighbours' ghost copies of our interface predictions are stale now: one extra halo exchange (every rank sees the
         // same dt change, so every rank does this).  RCCL bodies do it here; an in-process group does it for all its members
         // in tetsim_group_step_n (a copy waits for the RECEIVER's event, so all records must precede all copies).
         if (has_transport(h)) {
-            if (h->comm_stream) {  // the halo stream must see the new predictions (two-stream bodies have no other main -> halo edge here)
-                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-                HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_fork, 0));
+            if (h->flag_sync) {  // the halo stream continues only after the new predictions exist: publish / await one more sequence number
+                PJSync y;
+                y.wait = h->d_sync + 2; y.signal = h->d_sync + 2; y.error = h->d_sync + 4; y.seq = ++h->halo_seq;
+                pjb_launch_signal(h->stream, y);
+                pjb_launch_wait(h->comm_stream, y);
             }
             if (h->comm) {
                 int rc = enqueue_phase_b(h);
@@ -559,7 +585,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         ltets.assign(tets, tets + 4ull * nt);
         h->info.owned_elems = nt;
     }
-    uint32_t nv_near = 0;
     // device numbering: Morton order inside the interior segment [nvb, nvo); boundary (halo sends stay contiguous
     // runs) and ghosts (receive ranges) keep the plan's order
     {
@@ -569,15 +594,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             lv[3 * i] = verts[3 * g]; lv[3 * i + 1] = verts[3 * g + 1]; lv[3 * i + 2] = verts[3 * g + 2];
         }
         h->dev2api = morton_vertex_order(lv.data(), nvl, nvb, nvo - nvb);
-        // blocked bodies with ghosts: the particles that share a tile with a ghost ("near": their update needs the G tiles,
-        // which run on the halo stream) come first -- [interface | near | deep | ghosts], each segment still in Morton order
-        nv_near = nvb;
-        const bool will_block = h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION);
-        if (will_block && nvl > nvo) {
-            const std::vector<uint8_t> in_c = near_halo_particles(lv.data(), ltets.data(), ntl, nvl, nvo);
-            auto mid = std::stable_partition(h->dev2api.begin() + nvb, h->dev2api.begin() + nvo, [&](uint32_t api) { return in_c[api] != 0; });
-            nv_near = static_cast<uint32_t>(mid - h->dev2api.begin());
-        }
         h->api2dev.resize(nvl);
         for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
         for (auto& id : ltets) id = static_cast<int32_t>(h->api2dev[id]);
@@ -633,7 +649,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         h->tet_perm = B.tet_perm;
         PJBlk& k = h->blk;
         h->interior_tets = B.blk_tet_off[B.num_interior_blocks];
-        k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nb_near = B.num_near_blocks; k.nv_near = nv_near; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
+        k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
         uint32_t *bto, *bvo, *lcr, *vpe;
@@ -998,7 +1014,7 @@ void tetsim_destroy(tetsim_handle h) {
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {h->ev_fork, h->ev_bnd_tet, h->ev_near}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {h->ev_fork, h->ev_bnd_tet}) if (ev) (void)hipEventDestroy(ev);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1034,7 +1050,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
         // critical path.  TETSIM_HALO_GRAPH=0 keeps everything eager.
         static const bool use_graph = [] { const char* e = getenv("TETSIM_HALO_GRAPH"); return !(e && e[0] == '0'); }();
-        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken) {
+        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {  // (the flag path is eager by design)
             for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
             h->halo_warm = true;
             return rc;
@@ -1067,6 +1083,11 @@ int tetsim_sync(tetsim_handle h) {
     if (!h) return TETSIM_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted
+        uint32_t err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->d_sync + 4, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(h, TETSIM_ECOMM, "a halo dependency was not signalled within 2 s (device-side wait timed out): a rank or a queue is stuck");
+    }
     return 0;
 }
 
@@ -1332,7 +1353,7 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     const bool halo = has_transport(h);
     if (halo && (!h->comm || !h->blocked || h->blk.nb == h->blk.nb_interior || getenv("TETSIM_DEBUG_ONE_STREAM")))
         return fail(h, TETSIM_ESTATE, "profiling a partitioned body needs the RCCL transport and the blocked formulation (in-process groups: use rocprofv3)");
-    if (halo && (h->blk.nb_interior == 0 || h->blk.nv_near >= h->pj.nv_owned))
+    if (halo && h->blk.nb_interior == 0)
         return fail(h, TETSIM_ESTATE, "nothing to time: this partition has no interior tiles (every tile is next to the halo)");
     HIPCHK(h, hipSetDevice(h->opt.device));
     std::memset(out, 0, sizeof(*out));
@@ -1677,8 +1698,8 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
     if (refresh) {  // dt changed: every member redid its predictions; re-send them (all "ghosts are free" records, then all copies)
         for (uint32_t i = 0; i < count; i++) {
             hs[i]->needs_halo_refresh = false;
-            // "my ghosts may be overwritten": behind the fork edge recorded by ensure_prediction, i.e. behind everything so far
-            HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->comm_stream ? hs[i]->comm_stream : hs[i]->stream));
+            // "my ghosts may be overwritten": flag bodies record it on the halo stream, which ensure_prediction put behind the re-prediction
+            HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->flag_sync ? hs[i]->comm_stream : hs[i]->stream));
         }
         for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
     }
