@@ -5,6 +5,12 @@ import os, sys, time
 os.environ["TETSIM_DEBUG_LOOPBACK_HALO"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("LOOPBACK_WITH_TORCH"):   # the bench's environment: torch's own streams and its RCCL communicator in the same process
+    import torch, torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    t = torch.ones(4, device="cuda"); dist.all_reduce(t); dist.barrier()
 from tetsim_amd import SoftBodyHIP, comm_init, comm_unique_id, make_lattice
 PP = dict(gravity=0.0, friction=1000.0, density=1000.0, worldBounds=[-2.5, -1.0, -10.0, 2.5, 10.0, 10.0])   # g = 0: the self-halo keeps the lattice at rest
 DT = (1 / 60) / 20
