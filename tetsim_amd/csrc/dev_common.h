@@ -105,6 +105,7 @@ struct PJSync {
     uint32_t* signal = nullptr;
     uint32_t* error = nullptr;
     uint32_t seq = 0;
+    uint32_t timeout_ms = 0;   // 0 = unbounded
 };
 void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await
 void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: publish seq

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_
 // has two of them.  Here the producer queue runs a ONE-WAVE signal kernel behind its kernel (in-order queue: the kernel and
 // its agent-scope release are complete) and the consumer queue a one-wave wait kernel in front of the dependent kernel (whose
 // own start then performs the agent-scope acquire): ~5 us each under load, nothing else in either queue is delayed.
-// `seq` = the substep's sequence number, so a word is never reset.  The wait is bounded (~2 s, then *error is raised and it
+// `seq` = the substep's sequence number, so a word is never reset.  The wait is bounded (timeout_ms, 30 s by default; then *error is raised and it
 // carries on): a wedged peer must not wedge this GPU.  The host submits every signal before the matching wait, so even a
 // single shared hardware queue stays live.
 // Tried and dropped: the hand-over inside the compute kernels (last-workgroup detection / every workgroup polling on entry).
@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_
 // ~20 ns and serialises: the 2,744-workgroup particle pass went from 7 us to 60-400 us.
 __device__ __forceinline__ void await_done(const PJSync& y) {
     if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
+        const long long t0 = wall_clock64(), limit = 100000ll * y.timeout_ms;   // 100 MHz ticks
         while (static_cast<int32_t>(__hip_atomic_load(y.wait, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - y.seq) < 0) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 200000000ll) {   // 100 MHz ticks: 2 s
+            if (limit && wall_clock64() - t0 > limit) {
                 __hip_atomic_store(y.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

@@ -372,6 +372,12 @@ int halo_wait(tetsim_body* h, hipStream_t on) {
     h->halo_pending = false;
     return 0;
 }
+// Bound of the device-side waits of the flag path.  `wait G` sits behind a transfer, i.e. behind the PEER's progress: a rank
+// that steps this much later than its neighbour is reported as TETSIM_ECOMM at the next synchronisation.  0 = wait for ever.
+uint32_t halo_timeout_ms() {
+    static const uint32_t ms = [] { const char* e = getenv("TETSIM_HALO_TIMEOUT_MS"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 30000u; }();
+    return ms;
+}
 bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
 // blocked bodies with a transport and ghost-touching tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
 bool uses_flag_sync(const tetsim_body* h) {
@@ -409,8 +415,8 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr) {  // tet kernels 
             h->flag_sync = true;
             const uint32_t seq = ++h->halo_seq;
             PJSync yg, yv;   // word 0: "G tiles of substep seq are done"; word 2: "particles of substep seq are done"
-            yg.wait = yg.signal = h->d_sync + 0; yg.error = h->d_sync + 4; yg.seq = seq;
-            yv.wait = yv.signal = h->d_sync + 2; yv.error = h->d_sync + 4; yv.seq = seq;
+            yg.wait = yg.signal = h->d_sync + 0; yg.error = h->d_sync + 4; yg.seq = seq; yg.timeout_ms = halo_timeout_ms();
+            yv.wait = yv.signal = h->d_sync + 2; yv.error = h->d_sync + 4; yv.seq = seq; yv.timeout_ms = yg.timeout_ms;
             int rc = halo_wait(h, h->comm_stream);   // in-process groups: the neighbours' transfers of the previous substep (events)
             if (rc) return rc;
             { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
@@ -506,7 +512,7 @@ int ensure_prediction(tetsim_body* h, double dt) {
         if (has_transport(h)) {
             if (h->flag_sync) {  // the halo stream continues only after the new predictions exist: publish / await one more sequence number
                 PJSync y;
-                y.wait = h->d_sync + 2; y.signal = h->d_sync + 2; y.error = h->d_sync + 4; y.seq = ++h->halo_seq;
+                y.wait = h->d_sync + 2; y.signal = h->d_sync + 2; y.error = h->d_sync + 4; y.seq = ++h->halo_seq; y.timeout_ms = halo_timeout_ms();
                 pjb_launch_signal(h->stream, y);
                 pjb_launch_wait(h->comm_stream, y);
             }
@@ -1537,6 +1543,32 @@ int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t n
     h->comm_rank = rank;
     h->comm_size = nranks;
     { int rc = create_halo_stream(h); if (rc) return rc; }
+    // Connection set-up happens on the first transfer between two ranks and can take seconds; do it here, with the real
+    // message sizes on scratch buffers and a host-side wait, so that the stepping path (whose device-side waits are
+    // bounded, TETSIM_HALO_TIMEOUT_MS) never sees it.  Collective: every rank of the communicator is inside this call.
+    size_t most = 0;
+    for (auto& nb : h->neigh) most = std::max<size_t>(most, std::max(nb.send_count, nb.recv_count));
+    if (most) {
+        float4 *src = nullptr, *dst = nullptr;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), most * sizeof(float4)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), most * h->neigh.size() * sizeof(float4)));
+        int rc = TETSIM_OK;
+        if (hipMemsetAsync(src, 0, most * sizeof(float4), h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up memset failed");
+        r = rc ? ncclSuccess : g_rccl.GroupStart();
+        size_t k = 0;
+        for (auto& nb : h->neigh) {
+            const int peer = h->loopback ? h->comm_rank : nb.rank;
+            if (!rc && r == ncclSuccess && nb.send_count) r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, peer, h->comm, h->comm_stream);
+            if (!rc && r == ncclSuccess && nb.recv_count) r = g_rccl.Recv(dst + most * k, 4ull * nb.recv_count, ncclFloat, peer, h->comm, h->comm_stream);
+            k++;
+        }
+        if (!rc && r == ncclSuccess) r = g_rccl.GroupEnd();
+        if (!rc && r != ncclSuccess) rc = rccl_fail(h, r, "halo warm-up send/recv");
+        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up did not complete");
+        (void)hipFree(src);
+        (void)hipFree(dst);
+        if (rc) return rc;
+    }
     return 0;
 }
 
