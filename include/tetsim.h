@@ -63,7 +63,12 @@ enum {
     TETSIM_ORDER_ORIGINAL = 0,
     /* greedy graph colouring, tets stably sorted by colour (BASELINE config 4).  The result equals the
      * reference CPU solver run on tetIds permuted by tetsim_get_tet_order(). */
-    TETSIM_ORDER_COLOURED = 1
+    TETSIM_ORDER_COLOURED = 1,
+    /* clusters of <= 8 tets over <= 8 vertices (the 6 tets of a cell on a cell-major lattice), clusters coloured; a GPU lane
+     * sweeps its cluster sequentially out of LDS, one launch per cluster colour (8 on the lattice instead of 31 tet colours).
+     * Same contract as COLOURED: the result equals the reference CPU solver run on tetIds permuted by
+     * tetsim_get_tet_order().  TetSimInfo.num_levels = launches per substep; tet_colour is ignored. */
+    TETSIM_ORDER_CLUSTERED = 2
 };
 
 /* flags */
@@ -291,6 +296,12 @@ int tetsim_halo_import(tetsim_handle h, uint32_t n, const float *in_xyzw);
 int tetsim_prep_levels(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *level, uint32_t *num_levels);
 /* Greedy colouring in tet order (smallest colour not used by any tet sharing a vertex). */
 int tetsim_prep_colours(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *colour, uint32_t *num_colours);
+/* The TETSIM_ORDER_CLUSTERED schedule of a mesh.  order[i] = caller's tet id at sequential position i (what
+ * tetsim_get_tet_order returns for such a body); launch[i] / lane[i] / step[i] = the kernel launch (cluster colour), the lane
+ * (cluster) and the lane's step that solve position i.  Correct iff any two positions a < b whose tets share a vertex have
+ * launch[a] < launch[b], or the same launch AND lane with step[a] < step[b]. */
+int tetsim_prep_clusters(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *order, int32_t *launch, int32_t *lane,
+                         int32_t *step, uint32_t *num_launches, uint32_t *num_clusters);
 /* Scatter table of SoftbodyGPU.js:563-577: slots[v*36 + s] = 4*tet + corner, -1 = empty.
  * ref_quirk != 0 reproduces the `<= 0.0` test.  Returns the number of dropped contributions. */
 int tetsim_prep_slot_table(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t ref_quirk,

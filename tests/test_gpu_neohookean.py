@@ -74,7 +74,7 @@ def test_dragon_1200_substeps_hash(golden):
     assert sha16(body.pos) == g["steps"]["1200"]["pos"] == "9f52c76cdd7223f0"
 
 
-@pytest.mark.parametrize("order", ["original", "coloured"])
+@pytest.mark.parametrize("order", ["original", "coloured", "clustered"])
 def test_precise_bit_exact_vs_oracle_lattice(order):
     """Config 4's claim: the coloured schedule equals the sequential solver fed the permuted tetIds."""
     v, t = make_lattice(6, y0=0.02)
@@ -98,6 +98,37 @@ def test_precise_bit_exact_vs_oracle_lattice(order):
             assert body.volError == orc.volError
     if order == "coloured":
         assert body.info.num_levels <= 64  # a colouring, not a wavefront
+    if order == "clustered":
+        assert body.info.num_levels == 8   # cells as clusters, 2x2x2 cell parities as cluster colours
+
+
+@pytest.mark.parametrize("precision", ["precise", "fast"])
+def test_clustered_dragon_vs_oracle(precision):
+    """The clustered schedule on the reference's own mesh: bit-exact (PRECISE) with the sequential solver fed the
+    permuted tetIds, FAST within the Neo-Hookean FAST tolerance of the same horizon; grab + floor included."""
+    from conftest import load_mesh
+    v, t = load_mesh("dragon")
+    pp = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
+              worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+    body = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision=precision, order="clustered")
+    assert body.info.num_levels < 32        # fewer launches than tet colours
+    orc = OracleNH(v, t[body.tetOrder], pp)
+    dt = (1.0 / 60.0) / 10
+    for frame in range(10):
+        if frame == 3:
+            body.setGrab(100, [0.3, 1.5, 0.1])
+            orc.setGrab(100, [0.3, 1.5, 0.1])
+        if frame == 6:
+            body.endGrab()
+            orc.endGrab()
+        body.simulateSubsteps(10, dt, pp)
+        for _ in range(10):
+            orc.simulate(dt, pp)
+        if precision == "precise":
+            assert np.array_equal(body.pos.view(np.uint32), orc.pos.view(np.uint32)), frame
+            assert body.volError == orc.volError
+        else:
+            assert np.abs(body.pos - orc.pos).max() < 2e-3, frame
 
 
 def test_fast_tolerance_vs_reference_goldens(golden):
@@ -117,11 +148,12 @@ def test_fast_tolerance_vs_reference_goldens(golden):
             assert err <= tol[step], (step, err)
 
 
-def test_graph_equals_eager():
+@pytest.mark.parametrize("order", ["coloured", "clustered"])
+def test_graph_equals_eager(order):
     v, t = make_lattice(5, y0=0.1)
     pp = dict(density=1000.0)
-    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", order="coloured")
-    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", order="coloured")
+    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order)
+    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order)
     dt = 1.0 / 600
     for _ in range(3):
         a.simulateSubsteps(7, dt, pp)
@@ -139,20 +171,21 @@ def test_repeated_vertex_is_rejected():
         SoftBodyHIP(v, t, None, {}, solver="neohookean")
 
 
-def test_lattice_1m_coloured_properties():
+@pytest.mark.parametrize("order", ["coloured", "clustered"])
+def test_lattice_1m_coloured_properties(order):
     """BASELINE config 4 at full size (998,250 tets), through size-independent properties: determinism, PRECISE vs FAST
     agreement, rigid free fall of the centroid (XPBD constraints are internal forces), bounded volume error."""
     v, t = make_lattice(55)
     pp = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
               worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
     dt, n = (1.0 / 60.0) / 20, 20
-    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="precise", order="coloured")
-    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="precise", order="coloured")
-    f = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="fast", order="coloured")
+    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="precise", order=order)
+    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="precise", order=order)
+    f = SoftBodyHIP(v, t, None, pp, solver="neohookean", precision="fast", order=order)
     for body in (a, b, f):
         body.simulateSubsteps(n, dt, pp)
     pa, pb, pf = a.pos, b.pos, f.pos
-    assert a.info.num_levels <= 40                                  # a colouring (max valence 24), not a wavefront
+    assert a.info.num_levels <= (40 if order == "coloured" else 8)  # a colouring (max valence 24), not a wavefront
     assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))   # deterministic
     assert np.isfinite(pa).all() and np.abs(pa - pf).max() < 2e-4   # f32+FMA tracks the f64-exact path
     # the masses are lumped per vertex, so the MASS-weighted centroid falls rigidly: sum_k (k dt) dt g = g dt^2 n(n+1)/2

@@ -31,7 +31,7 @@ def random_mesh(seed, npts, min_vol=2e-6):
 @pytest.mark.parametrize("seed,npts", [(1, 60), (2, 400), (3, 2500)])
 def test_neohookean_precise_bit_exact_on_random_meshes(seed, npts):
     v, t = random_mesh(seed, npts)
-    for order in ("original", "coloured"):
+    for order in ("original", "coloured", "clustered"):
         body = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="precise", order=order)
         orc = OracleNH(v, t[body.tetOrder], PP)
         for _ in range(25):

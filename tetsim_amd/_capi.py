@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("TETSIM_HIP_LIB") or os.path.join(_HERE, "libtetsim_hi
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
 PRECISE, FAST = 0, 1
-ORDER_ORIGINAL, ORDER_COLOURED = 0, 1
+ORDER_ORIGINAL, ORDER_COLOURED, ORDER_CLUSTERED = 0, 1, 2
 FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE, FLAG_REF_GRAB_TEXEL = 1, 2, 4, 8, 16
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
@@ -70,7 +70,7 @@ SYMBOLS = [
     "tetsim_read_visual_mesh", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
-    "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours",
+    "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
     "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
     "tetsim_mesh_write", "tetsim_mesh_open", "tetsim_mesh_arrays", "tetsim_mesh_close", "tetsim_create_from_file",
@@ -137,6 +137,7 @@ def lib():
     L.tetsim_halo_import.argtypes = [H, u32, fp]
     L.tetsim_prep_levels.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_colours.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
+    L.tetsim_prep_clusters.argtypes = [ip, u32, u32, ip, ip, ip, ip, C.POINTER(u32), C.POINTER(u32)]
     L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
     L.tetsim_prep_ref_grab_texels.argtypes = [i32, u32, u32, ip]
     L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]

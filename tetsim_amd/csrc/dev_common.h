@@ -81,7 +81,16 @@ struct NHDev {
     float4* irp_c = nullptr;   // m8, invRestVolume, 0, 0
     double* vol_err = nullptr; // [nt] det F - 1 per tet, indexed by the CALLER's tet id
     int32_t* order = nullptr;  // [nt] solve position -> caller's tet id
+    uint32_t* corner_slots = nullptr;  // [nt] TETSIM_ORDER_CLUSTERED: the corners' cluster-local vertex slots, a byte each
     const DevParams* params = nullptr;
+};
+// One launch of the clustered Gauss-Seidel schedule (host_prep.h ClusterPlan): lane = cluster, step j = tets first[j] + lane
+// for lanes < count[j] (count non-increasing), slot_vid = [kNHClusterVerts][clusters] vertex ids (-1 = unused).
+constexpr uint32_t kNHClusterVerts = 8, kNHClusterTets = 8;
+struct NHClusterLaunch {
+    uint32_t nsteps = 0, clusters = 0;
+    uint32_t first[kNHClusterTets] = {}, count[kNHClusterTets] = {};
+    const int32_t* slot_vid = nullptr;
 };
 
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
@@ -94,6 +103,8 @@ void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32
 void pj_launch_repredict_precise(hipStream_t s, const PJDev& d);
 void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
 
+void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
+void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

@@ -116,6 +116,148 @@ uint32_t prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* co
     return ncol;
 }
 
+ClusterPlan prep_clusters(const int32_t* tets, uint32_t nt, uint32_t nv) {
+    ClusterPlan P;
+    // vertex -> incident tets (CSR, ascending tet id)
+    std::vector<uint32_t> voff(nv + 1, 0);
+    for (uint64_t i = 0; i < 4ull * nt; i++) voff[tets[i] + 1]++;
+    for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
+    std::vector<uint32_t> vtet(4ull * nt), fill(voff.begin(), voff.end() - 1);
+    for (uint32_t e = 0; e < nt; e++)
+        for (int k = 0; k < 4; k++) vtet[fill[tets[4 * e + k]]++] = e;
+
+    // 1. greedy clusters: seed = lowest unassigned tet; grow by the unassigned neighbour that adds the fewest new vertices
+    //    (ties: closest tet id to the seed, which keeps the cells of a cell-major lattice together)
+    std::vector<int32_t> cluster_of(nt, -1);
+    struct Cluster { uint32_t n = 0, nvert = 0; uint32_t tet[kClusterTets]; int32_t vert[kClusterVerts]; };
+    std::vector<Cluster> clusters;
+    std::vector<uint32_t> cand;
+    std::vector<int32_t> stamp(nt, -1);    // cluster id for which `covered` is valid
+    std::vector<uint8_t> covered(nt, 0);   // corners of a candidate tet that are cluster vertices already
+    for (uint32_t seed = 0; seed < nt; seed++) {
+        if (cluster_of[seed] >= 0) continue;
+        Cluster c;
+        const int32_t id = static_cast<int32_t>(clusters.size());
+        cand.clear();
+        auto add = [&](uint32_t e) {
+            c.tet[c.n++] = e;
+            cluster_of[e] = id;
+            for (int k = 0; k < 4; k++) {
+                const int32_t v = tets[4 * e + k];
+                bool have = false;
+                for (uint32_t j = 0; j < c.nvert; j++) have |= c.vert[j] == v;
+                if (have) continue;
+                c.vert[c.nvert++] = v;
+                for (uint32_t q = voff[v]; q < voff[v + 1]; q++) {  // (a tet listing v twice is visited twice: two corners covered)
+                    const uint32_t t = vtet[q];
+                    if (cluster_of[t] >= 0) continue;
+                    if (stamp[t] != id) { stamp[t] = id; covered[t] = 0; cand.push_back(t); }
+                    covered[t]++;
+                }
+            }
+        };
+        add(seed);  // (at most 4 distinct vertices: always fits)
+        while (c.n < kClusterTets) {
+            uint32_t best = nt, best_new = 5;
+            uint64_t best_dist = ~0ull;
+            for (uint32_t e : cand) {
+                if (cluster_of[e] >= 0) continue;
+                const uint32_t fresh = 4u - covered[e];
+                if (c.nvert + fresh > kClusterVerts) continue;
+                const uint64_t dist = e > seed ? e - seed : seed - e;
+                if (fresh < best_new || (fresh == best_new && dist < best_dist)) { best = e; best_new = fresh; best_dist = dist; }
+            }
+            if (best == nt) break;
+            add(best);
+        }
+        std::sort(c.tet, c.tet + c.n);  // inside a cluster: the caller's order
+        clusters.push_back(c);
+    }
+    const uint32_t nc = static_cast<uint32_t>(clusters.size());
+    P.num_clusters = nc;
+
+    // 2. greedy colouring of the clusters (conflict = a shared vertex), per-vertex bitsets of used colours
+    std::vector<std::vector<uint64_t>> used(nv);
+    std::vector<uint32_t> colour(nc);
+    uint32_t ncol = 0;
+    for (uint32_t ci = 0; ci < nc; ci++) {
+        const Cluster& c = clusters[ci];
+        size_t words = 0;
+        for (uint32_t j = 0; j < c.nvert; j++) words = std::max(words, used[c.vert[j]].size());
+        int32_t col = -1;
+        for (size_t w = 0; w <= words && col < 0; w++) {
+            uint64_t m = 0;
+            for (uint32_t j = 0; j < c.nvert; j++)
+                if (w < used[c.vert[j]].size()) m |= used[c.vert[j]][w];
+            if (~m) col = static_cast<int32_t>(64 * w + __builtin_ctzll(~m));
+        }
+        colour[ci] = static_cast<uint32_t>(col);
+        for (uint32_t j = 0; j < c.nvert; j++) {
+            auto& u = used[c.vert[j]];
+            if (u.size() <= static_cast<size_t>(col / 64)) u.resize(col / 64 + 1, 0);
+            u[col / 64] |= 1ull << (col % 64);
+        }
+        ncol = std::max<uint32_t>(ncol, col + 1);
+    }
+
+    // 3. per colour: clusters by size, largest first (so step j is the lane range [0, count_j)); layout
+    std::vector<uint32_t> by(nc);
+    for (uint32_t i = 0; i < nc; i++) by[i] = i;
+    std::stable_sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) {
+        if (colour[a] != colour[b]) return colour[a] < colour[b];
+        return clusters[a].n > clusters[b].n;
+    });
+    P.pre.reserve(nt);
+    P.exec_pos.assign(nt, 0);
+    P.corner_slots.assign(nt, 0);
+    P.launch_off.assign(1, 0);
+    P.step_off.assign(1, 0);
+    P.vid_off.assign(1, 0);
+    uint32_t storage = 0;
+    for (uint32_t b0 = 0; b0 < nc;) {
+        uint32_t b1 = b0;
+        while (b1 < nc && colour[by[b1]] == colour[by[b0]]) b1++;
+        const uint32_t n0 = b1 - b0;
+        // sequential order: cluster after cluster
+        std::vector<uint32_t> seq_first(n0);
+        for (uint32_t i = 0; i < n0; i++) {
+            const Cluster& c = clusters[by[b0 + i]];
+            seq_first[i] = static_cast<uint32_t>(P.pre.size());
+            for (uint32_t j = 0; j < c.n; j++) P.pre.push_back(static_cast<int32_t>(c.tet[j]));
+        }
+        // storage order: step after step
+        for (uint32_t j = 0; j < clusters[by[b0]].n; j++) {
+            uint32_t count = 0;
+            while (count < n0 && clusters[by[b0 + count]].n > j) count++;
+            P.step_first.push_back(storage);
+            P.step_count.push_back(count);
+            for (uint32_t i = 0; i < count; i++) {
+                const Cluster& c = clusters[by[b0 + i]];
+                uint32_t packed = 0;
+                for (int k = 0; k < 4; k++) {
+                    uint32_t slot = 0;
+                    while (c.vert[slot] != tets[4 * c.tet[j] + k]) slot++;
+                    packed |= slot << (8 * k);
+                }
+                P.exec_pos[storage + i] = seq_first[i] + j;
+                P.corner_slots[storage + i] = packed;
+            }
+            storage += count;
+        }
+        const size_t base = P.slot_vid.size();
+        P.slot_vid.resize(base + static_cast<size_t>(kClusterVerts) * n0, -1);
+        for (uint32_t i = 0; i < n0; i++) {
+            const Cluster& c = clusters[by[b0 + i]];
+            for (uint32_t k = 0; k < c.nvert; k++) P.slot_vid[base + static_cast<size_t>(k) * n0 + i] = c.vert[k];
+        }
+        P.launch_off.push_back(storage);
+        P.step_off.push_back(static_cast<uint32_t>(P.step_first.size()));
+        P.vid_off.push_back(static_cast<uint32_t>(P.slot_vid.size()));
+        b0 = b1;
+    }
+    return P;
+}
+
 Incidence build_incidence(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, bool ref_cap) {
     Incidence inc;
     std::vector<uint32_t> count(nv, 0);

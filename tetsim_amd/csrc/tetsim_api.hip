@@ -143,6 +143,8 @@ struct tetsim_body {
 
     // NEOHOOKEAN_GS
     NHDev nh;
+    std::vector<NHClusterLaunch> cluster_launch;  // TETSIM_ORDER_CLUSTERED: one per cluster colour
+    int32_t* d_slot_vid = nullptr;
     std::vector<uint32_t> level_off;
     std::vector<int32_t> order;
     std::vector<float> h_inv_mass;
@@ -286,6 +288,18 @@ void pj_repredict(tetsim_body* h) {
 
 // The halo stream carries the transfers AND the boundary tiles that consume them; high priority so that its few
 // workgroups are dispatched ahead of the interior kernel's backlog.
+// NEOHOOKEAN_GS: the Gauss-Seidel sweep over all tets (A3-A5), as dependency levels or as cluster colours
+void nh_sweep(tetsim_body* h) {
+    if (!h->cluster_launch.empty()) {
+        for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L) : nh_launch_cluster_precise(h->stream, h->nh, L);
+        return;
+    }
+    for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
+        const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
+        h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+    }
+}
+
 int create_halo_stream(tetsim_body* h) {
     if (h->comm_stream) return 0;
     int lo = 0, hi = 0;
@@ -485,10 +499,7 @@ int enqueue_substep(tetsim_body* h) {
         }
     } else {
         h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
-        for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
-            const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-            h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
-        }
+        nh_sweep(h);
         h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
     }
     hipError_t e = hipGetLastError();
@@ -791,6 +802,12 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         else prep_colours(tets, nt, nv, colour.data());
         std::stable_sort(pre.begin(), pre.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
     }
+    ClusterPlan plan;
+    const bool clustered = o.order == TETSIM_ORDER_CLUSTERED;
+    if (clustered) {
+        plan = prep_clusters(tets, nt, nv);
+        pre = plan.pre;
+    }
     std::vector<int32_t> ptets(4ull * nt);
     for (uint32_t i = 0; i < nt; i++) std::memcpy(&ptets[4 * i], &tets[4 * pre[i]], 4 * sizeof(int32_t));
     // 2. rest data in the order the reference would see (mass accumulation is order dependent, Softbody.js:74-78)
@@ -798,14 +815,21 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     h->h_inv_mass.assign(nv, 0.0f);
     prep_rest(verts, nv, ptets.data(), nt, o.density, h->h_inv_mass.data(), irp.data(), irv.data());
     // 3. dependency levels of that order; solve order = stable sort by level
-    std::vector<int32_t> level(nt);
-    const uint32_t nl = prep_levels(ptets.data(), nt, nv, level.data());
     std::vector<int32_t> pos_in(nt);
-    for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(i);
-    std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
-    h->level_off.assign(nl + 1, 0);
-    for (uint32_t i = 0; i < nt; i++) h->level_off[level[i] + 1]++;
-    for (uint32_t l = 0; l < nl; l++) h->level_off[l + 1] += h->level_off[l];
+    uint32_t nl = 0;
+    if (clustered) {  // the plan IS the schedule: one launch per cluster colour, storage order = step after step
+        nl = static_cast<uint32_t>(plan.launch_off.size() - 1);
+        for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(plan.exec_pos[i]);
+        h->level_off = plan.launch_off;
+    } else {
+        std::vector<int32_t> level(nt);
+        nl = prep_levels(ptets.data(), nt, nv, level.data());
+        for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(i);
+        std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+        h->level_off.assign(nl + 1, 0);
+        for (uint32_t i = 0; i < nt; i++) h->level_off[level[i] + 1]++;
+        for (uint32_t l = 0; l < nl; l++) h->level_off[l + 1] += h->level_off[l];
+    }
     h->order.resize(nt);  // solve position -> caller's tet id, for the PERMUTED sequence the reference must be fed
     std::vector<int32_t> seq(nt);
     for (uint32_t i = 0; i < nt; i++) seq[i] = pre[i];
@@ -852,6 +876,23 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     if ((rc = upload(h, d.irp_b, b))) return rc;
     if ((rc = upload(h, d.irp_c, c))) return rc;
     if ((rc = upload(h, d.order, ord))) return rc;
+    if (clustered) {
+        if ((rc = dev_alloc(h, &d.corner_slots, nt))) return rc;
+        if ((rc = upload(h, d.corner_slots, plan.corner_slots))) return rc;
+        if ((rc = dev_alloc(h, &h->d_slot_vid, plan.slot_vid.size()))) return rc;
+        if ((rc = upload(h, h->d_slot_vid, plan.slot_vid))) return rc;
+        for (uint32_t l = 0; l < nl; l++) {
+            NHClusterLaunch L;
+            L.nsteps = plan.step_off[l + 1] - plan.step_off[l];
+            for (uint32_t j = 0; j < L.nsteps; j++) {
+                L.first[j] = plan.step_first[plan.step_off[l] + j];
+                L.count[j] = plan.step_count[plan.step_off[l] + j];
+            }
+            L.clusters = L.nsteps ? L.count[0] : 0;
+            L.slot_vid = h->d_slot_vid + plan.vid_off[l];
+            h->cluster_launch.push_back(L);
+        }
+    }
     return 0;
 }
 
@@ -950,6 +991,7 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     if (opts) o = *opts; else tetsim_default_options(&o);
     if (o.solver != TETSIM_SOLVER_POLAR_JACOBI && o.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(nullptr, TETSIM_EINVAL, "unknown solver");
     if (o.precision != TETSIM_PRECISE && o.precision != TETSIM_FAST) return fail(nullptr, TETSIM_EINVAL, "unknown precision");
+    if (o.solver == TETSIM_SOLVER_NEOHOOKEAN_GS && (o.order < TETSIM_ORDER_ORIGINAL || o.order > TETSIM_ORDER_CLUSTERED)) return fail(nullptr, TETSIM_EINVAL, "unknown order");
     if (o.part_count < 1) o.part_count = 1;
     std::string merr = validate_mesh(verts, nv, tets, nt, o.solver == TETSIM_SOLVER_NEOHOOKEAN_GS);
     if (!merr.empty()) return fail(nullptr, TETSIM_EINVAL, merr);
@@ -1385,10 +1427,7 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             HIPCHK(h, hipEventRecord(ev[4 * i], h->stream));
             h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
             HIPCHK(h, hipEventRecord(ev[4 * i + 1], h->stream));
-            for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
-                const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-                h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
-            }
+            nh_sweep(h);
             HIPCHK(h, hipEventRecord(ev[4 * i + 2], h->stream));
             h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
             HIPCHK(h, hipEventRecord(ev[4 * i + 3], h->stream));
@@ -1432,10 +1471,7 @@ int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimP
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     auto tet_once = [&]() {
         if (pjs) { pj_tet(h); return 1u; }
-        for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
-            const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-            h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
-        }
+        nh_sweep(h);
         return static_cast<uint32_t>(h->level_off.size() - 1);
     };
     auto vert_once = [&]() {
@@ -1783,6 +1819,26 @@ int tetsim_prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* 
     std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
     if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
     *num_colours = prep_colours(tets, nt, nv, colour);
+    return 0;
+}
+int tetsim_prep_clusters(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* order, int32_t* launch, int32_t* lane, int32_t* step,
+                         uint32_t* num_launches, uint32_t* num_clusters) {
+    if ((nt && (!tets || !order || !launch || !lane || !step)) || !num_launches) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    const ClusterPlan P = prep_clusters(tets, nt, nv);
+    for (uint32_t i = 0; i < nt; i++) order[i] = P.pre[i];
+    const uint32_t nl = static_cast<uint32_t>(P.launch_off.size() - 1);
+    for (uint32_t l = 0; l < nl; l++)
+        for (uint32_t j = P.step_off[l]; j < P.step_off[l + 1]; j++)
+            for (uint32_t i = 0; i < P.step_count[j]; i++) {
+                const uint32_t pos = P.exec_pos[P.step_first[j] + i];
+                launch[pos] = static_cast<int32_t>(l);
+                lane[pos] = static_cast<int32_t>(i);
+                step[pos] = static_cast<int32_t>(j - P.step_off[l]);
+            }
+    *num_launches = nl;
+    if (num_clusters) *num_clusters = P.num_clusters;
     return 0;
 }
 int tetsim_prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t ref_quirk, int32_t* slots, uint32_t* dropped) {

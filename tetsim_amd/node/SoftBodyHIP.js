@@ -10,7 +10,7 @@
 // the body is headless (physics only; edgeMesh / visMesh stay null).
 //
 // Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
-//     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured', device: 0,
+//     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured' | 'clustered', device: 0,
 //       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false,   (include/tetsim.h flags)
 //       partCount: 1, partIndex: 0, vertOwner: Int32Array }   (one Node process per GPU: see commUniqueId / commInit below)
 // default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
@@ -18,7 +18,7 @@ const path = require('path');
 
 const SOLVER = { polar: 0, neohookean: 1 };
 const PRECISION = { precise: 0, fast: 1 };
-const ORDER = { original: 0, coloured: 1 };
+const ORDER = { original: 0, coloured: 1, clustered: 2 };
 const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2, FLAG_GATHER_FORMULATION = 4, FLAG_CONSTANT_REST_SHAPE = 8, FLAG_REF_GRAB_TEXEL = 16;
 
 let addon = null;

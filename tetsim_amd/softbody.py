@@ -79,7 +79,7 @@ class SoftBodyHIP:
         L.tetsim_default_options(C.byref(o))
         o.solver = {"polar": capi.SOLVER_POLAR_JACOBI, "neohookean": capi.SOLVER_NEOHOOKEAN_GS}[solver]
         o.precision = {"precise": capi.PRECISE, "fast": capi.FAST}[precision]
-        o.order = {"original": capi.ORDER_ORIGINAL, "coloured": capi.ORDER_COLOURED}[order]
+        o.order = {"original": capi.ORDER_ORIGINAL, "coloured": capi.ORDER_COLOURED, "clustered": capi.ORDER_CLUSTERED}[order]
         o.flags = ((capi.FLAG_REF_SLOT_TABLE if ref_slot_table else 0) | (capi.FLAG_REF_FIXED_BOUNDS if ref_fixed_bounds else 0)
                    | (capi.FLAG_GATHER_FORMULATION if gather else 0)
                    | (capi.FLAG_CONSTANT_REST_SHAPE if constant_rest_shape else 0)

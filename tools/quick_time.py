@@ -23,12 +23,12 @@ for prec in (("fast",) if fastonly else ("precise", "fast")):
     print("polar %-7s create %.2fs  frame(20) %.3f ms  -> %.1f M tet-solves/s | tet %.1f us vertex %.1f us per substep"
           % (prec, t1 - t0, ms, len(t) * 20 / ms / 1e3, pr["tet_ms"] / 20 * 1e3, pr["vertex_ms"] / 20 * 1e3))
     b.close()
-for prec in (() if fastonly else ("precise", "fast")):
+for prec, order in (() if fastonly else [(p, o) for o in ("coloured", "clustered") for p in ("precise", "fast")]):
     t0 = time.time()
-    b = SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision=prec, order="coloured")
+    b = SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision=prec, order=order)
     t1 = time.time()
     b.simulateSubsteps(20, dt, pp); b.sync()
     ms = min(b.timeSubsteps(20, dt, pp) for _ in range(5))
-    print("neohk %-7s create %.2fs  levels %d  frame(20) %.3f ms -> %.1f M tet-solves/s"
-          % (prec, t1 - t0, b.info.num_levels, ms, len(t) * 20 / ms / 1e3))
+    print("neohk %-9s %-7s create %.2fs  launches/substep %d  frame(20) %.3f ms -> %.1f M tet-solves/s"
+          % (order, prec, t1 - t0, b.info.num_levels, ms, len(t) * 20 / ms / 1e3))
     b.close()
