@@ -103,6 +103,8 @@ void pj_launch_vertex_fast(hipStream_t s, const PJDev& d, uint32_t first, uint32
 void pj_launch_repredict_precise(hipStream_t s, const PJDev& d);
 void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
 
+void nh_launch_post_predict_precise(hipStream_t s, const NHDev& d);
+void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
 void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,

@@ -487,7 +487,9 @@ int enqueue_phase_b(tetsim_body* h) {  // halo start
 }
 
 // one substep's launches (parameters already on the device)
-int enqueue_substep(tetsim_body* h) {
+// first / last: position inside a run of substeps enqueued back to back with one dt (NEOHOOKEAN_GS fuses the particle pass
+// that ends a substep with the prediction that starts the next one)
+int enqueue_substep(tetsim_body* h, bool first = true, bool last = true) {
     if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
         if (has_transport(h)) {
             int rc = enqueue_phase_a(h);
@@ -498,9 +500,10 @@ int enqueue_substep(tetsim_body* h) {
             pj_vertex(h, 0, h->pj.nv_owned);
         }
     } else {
-        h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
+        if (first) h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
         nh_sweep(h);
-        h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+        if (last) h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+        else h->fast ? nh_launch_post_predict_fast(h->stream, h->nh) : nh_launch_post_predict_precise(h->stream, h->nh);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -547,7 +550,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         h->halo_pending = false;
         h->fork_needed = true;
     }
-    for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+    for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
     if (halo && !rc) {
         hipError_t je = hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0);  // join: the last transfer
         if (je != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("join: ") + hipGetErrorString(je));

@@ -31,6 +31,8 @@ bodies = {
     "polar Jacobi (FAST, blocked)": SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast"),
     "Neo-Hookean coloured GS (PRECISE)": SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision="precise", order="coloured"),
     "Neo-Hookean coloured GS (FAST)": SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision="fast", order="coloured"),
+    "Neo-Hookean clustered GS (PRECISE)": SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision="precise", order="clustered"),
+    "Neo-Hookean clustered GS (FAST)": SoftBodyHIP(v, t, None, dict(pp), solver="neohookean", precision="fast", order="clustered"),
 }
 print("lattice %d^3 cells: %d tets, %d particles; %d substeps/frame, dt = 1/%d s" % (n, len(t), len(v), sub, round(1 / dt)))
 print("%-36s %7s %12s %12s %12s %10s" % ("solver", "frames", "mean|detF-1|", "max|detF-1|", "mean dev res", "ms/frame"))
