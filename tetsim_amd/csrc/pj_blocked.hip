@@ -34,6 +34,7 @@
 #include <cstdlib>
 
 #include "dev_common.h"
+#include "dev_store.h"
 
 namespace tetsim {
 namespace {
@@ -41,17 +42,10 @@ namespace {
 #include "pj_math.inc"
 
 // Streamed outputs (carried rest shape, quaternion, partial sums, particle state) are written WRITE-THROUGH
-// (sc0 sc1): a plain store leaves the line dirty in the XCD's 4 MiB L2, and a kernel that streams ~70 MB of
+// (sc0 sc1, dev_store.h): a plain store leaves the line dirty in the XCD's 4 MiB L2, and a kernel that streams ~70 MB of
 // results then pays the write-back of whatever is still dirty at its end, outside the CUs' busy time (per-CU
 // s_memtime timelines: ~65k busy cycles inside a ~96k-cycle kernel).  With write-through the bytes leave while the
 // kernel is still computing.  The data is next read by OTHER CUs in the next kernel, so L2 residency is not needed.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_wt(float4* p, const float4& v) {
-    const v4f x = {v.x, v.y, v.z, v.w};
-    // hipcc's hazard recogniser cannot see inside an asm statement: a VMEM store of more than 8 bytes needs 2 wait
-    // states before a VALU instruction may overwrite its data VGPRs (gfx940+), so they are part of the string.
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
-}
 
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd) { return (b & 7u) * tiles_per_xcd + (b >> 3); }
 
@@ -98,6 +92,11 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         s_ent[tid] = d.lc_ent[e];
     }
     TETSIM_STAMP(1);  // loads issued (and landed, for this wave)
+    // Every load above has been consumed by now on the path that has tets; say so for ALL paths.  Without this, the
+    // wait-count model keeps "load into v[..] pending" alive through the path that skips the solve, and protects the reuse
+    // of those registers after the join with vmcnt(0) -- which on gfx9 (one in-order counter for loads and stores) makes
+    // every wave sit out its own write-through result stores' trip to HBM before the partial-sum reduction.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
     TETSIM_STAMP(2);  // tile staged
 
@@ -110,19 +109,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         float4 q_new;
         pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u), !(dbg & 64u), (dbg & 128u) != 0u);
         TETSIM_STAMP(3);  // solved
-        if (dbg & 32u) {  // A/B: plain stores (development)
-            d.quat[e] = q_new;
-            if (!(dbg & 128u)) d.rest_a[e] = make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x);
-            d.rest_b[e] = make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y);
-            d.rest_c[e] = make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z);
-        } else {
-            store_wt(&d.quat[e], q_new);
-            if (!(dbg & (16u | 128u))) {  // constant-rest-shape bodies never write the shape back
-                store_wt(&d.rest_a[e], make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
-                store_wt(&d.rest_b[e], make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
-                store_wt(&d.rest_c[e], make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
-            }
-        }
+        // LDS staging first, global results after it: nothing below may have to wait for the write-through stores
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             s_gx[k * kTile + tid] = goal[k].x * V;
@@ -130,6 +117,12 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             s_gz[k * kTile + tid] = goal[k].z * V;
         }
         s_v[tid] = V;
+        store_wt(d.quat, e, q_new);
+        if (!(dbg & (16u | 128u))) {  // constant-rest-shape bodies never write the shape back
+            store_wt(d.rest_a, e, make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
+            store_wt(d.rest_b, e, make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
+            store_wt(d.rest_c, e, make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
+        }
     }
     TETSIM_STAMP(4);  // stores issued
     __syncthreads();
@@ -157,8 +150,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             for (uint32_t j = 0; j < 4u; j++)
                 if (i + j < last) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; acc.w += gv[j]; }
         }
-        if (dbg & 32u) d.partial[v0 + tid] = acc;
-        else store_wt(&d.partial[v0 + tid], acc);
+        store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
 #undef TETSIM_STAMP
@@ -233,13 +225,15 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
         p.x += F.x * fr;
         p.z += F.z * fr;
     }
-    // P7, :364-372, then P1 + P2 of the next substep
-    const float rdt = __builtin_amdgcn_rcpf(P.dt);
-    const f3 vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * P.dt;
-    store_wt(&d.pos_final[v], make_float4(p.x, p.y, p.z, 0.0f));
-    store_wt(&d.vel[v], make_float4(vel.x, vel.y, vel.z, 0.0f));
-    const f3 pred = p + vel * P.dt;
-    store_wt(&d.pos_pred[v], make_float4(pred.x, pred.y, pred.z, 0.0f));
+    // P7, :364-372, then P1 + P2 of the next substep (everything computed before the first store: a parameter re-read
+    // behind a store would wait for that store's trip to HBM)
+    const float dt = P.dt;
+    const float rdt = __builtin_amdgcn_rcpf(dt);
+    const f3 vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * dt;
+    const f3 pred = p + vel * dt;
+    store_wt(d.pos_final, v, make_float4(p.x, p.y, p.z, 0.0f));
+    store_wt(d.vel, v, make_float4(vel.x, vel.y, vel.z, 0.0f));
+    store_wt(d.pos_pred, v, make_float4(pred.x, pred.y, pred.z, 0.0f));
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
