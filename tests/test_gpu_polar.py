@@ -340,6 +340,35 @@ def test_lattice_1m_two_partitions_match_monolithic():
         assert np.abs(b.pos - ref[b.ownedIds]).max() < 2e-5
 
 
+def test_lattice_8m_eight_slabs_match_monolithic():
+    """BASELINE config 5 at full size on ONE GPU: Lattice-8M (110^3 cells, 7,986,000 tets) cut into the 8 z-slabs of
+    SURVEY.md 8(e) (14,14,14,14,14,14,13,13 cell layers; 12,321-particle interface planes), stepped with the multi-GPU
+    path's two-queue choreography (device copies standing in for the RCCL transfers), against the monolithic body; plus
+    the size-independent properties of a rigid free fall."""
+    n = 110
+    v, t = make_lattice(n)
+    assert len(t) == 7986000 and len(v) == 111 ** 3
+    layers = [14] * 6 + [13] * 2
+    first_plane = np.concatenate([[0], np.cumsum(layers)])            # slab p owns vertex planes [first, next); the last one the top plane too
+    plane_owner = np.minimum(np.searchsorted(first_plane, np.arange(n + 1), side="right") - 1, 7)
+    owner = plane_owner[np.arange(len(v)) // (111 * 111)].astype(np.int32)
+    pp = dict(PP, worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+    mono = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast")
+    parts = [SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast", part_count=8, part_index=p, vert_owner=owner)
+             for p in range(8)]
+    assert [b.info.num_neighbours for b in parts] == [1, 2, 2, 2, 2, 2, 2, 1]
+    assert sum(b.info.owned_elems for b in parts) == len(t) and sum(b.info.owned_particles for b in parts) == len(v)
+    mono.simulateSubsteps(20, DT20, pp)
+    group_step_n(parts, 20, DT20, pp)
+    ref = mono.pos
+    for b in parts:
+        assert np.abs(b.pos - ref[b.ownedIds]).max() < 2e-5
+    assert np.isfinite(ref).all()
+    expect = -9.81 * DT20 * DT20 * 20 * 21 / 2
+    assert abs((ref[:, 1] - v[:, 1]).mean() - expect) < 2e-4 and abs(ref[:, 0].mean() - v[:, 0].mean()) < 1e-5
+    assert np.abs(np.linalg.norm(mono.quats, axis=1) - 1.0).max() < 1e-5
+
+
 def test_rccl_transport_selftest():
     """The RCCL entry points are resolved with dlopen at run time; a 1-rank communicator + a send/recv to self on
     the halo stream proves they work on this host (real multi-rank halos need >1 GPU: driver's scaling run)."""

@@ -19,6 +19,7 @@
 
 #include "../../include/tetsim.h"
 #include "dev_common.h"
+#include "dev_store.h"
 #include "host_prep.h"
 #include "mesh_file.h"
 
@@ -681,6 +682,8 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = dev_alloc(h, &bto, B.blk_tet_off.size()))) return rc;
         if ((rc = dev_alloc(h, &bvo, B.blk_vert_off.size()))) return rc;
         if ((rc = dev_alloc(h, &bv, nslots))) return rc;
+        if (ntl >= kStoreWtMaxIndex || nslots >= kStoreWtMaxIndex || nvl >= kStoreWtMaxIndex)
+            return fail(h, TETSIM_EINVAL, "body too large for one handle (2^27 tets / particles / partial sums: 32-bit store offsets, dev_store.h); partition it");
         if ((rc = dev_alloc(h, &lidx, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.rest_a, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.rest_b, ntl))) return rc;
@@ -841,6 +844,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     h->info.owned_particles = h->info.local_particles = nv;
     h->info.local_elems = h->info.owned_elems = nt;
 
+    if (nv >= kStoreWtMaxIndex) return fail(h, TETSIM_EINVAL, "more than 2^27 particles (32-bit store offsets, dev_store.h)");
     NHDev& d = h->nh;
     d.nv = nv; d.nt = nt;
     int rc;
