@@ -26,6 +26,9 @@ UNITS = {
     "host_prep.cpp": ["-ffp-contract=off", "-x", "hip"],
     "mesh_file.cpp": ["-ffp-contract=off", "-x", "hip"],
     "tetsim_api.hip": ["-ffp-contract=off"],
+    "tetsim_create.hip": ["-ffp-contract=off"],
+    "tetsim_halo.hip": ["-ffp-contract=off"],
+    "tetsim_host.cpp": ["-ffp-contract=off", "-x", "hip"],
     "pj_precise.hip": ["-ffp-contract=off"],
     "pj_fast.hip": ["-ffp-contract=fast"],
     "pj_blocked.hip": ["-ffp-contract=fast"],
@@ -34,7 +37,7 @@ UNITS = {
     "util_kernels.hip": ["-ffp-contract=off"],
     "skin_kernels.hip": ["-ffp-contract=off"],
 }
-HEADERS = ["dev_common.h", "dev_store.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
+HEADERS = ["body.h", "dev_common.h", "dev_store.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
 
 
 def _newest(paths):
@@ -58,7 +61,7 @@ def _compile(unit, flags, force):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=min(8, len(UNITS))) as ex:
+    with ThreadPoolExecutor(max_workers=min(12, len(UNITS))) as ex:
         results = list(ex.map(lambda kv: _compile(kv[0], kv[1], force), UNITS.items()))
     objs = [o for o, _ in results]
     if force or any(c for _, c in results) or not os.path.exists(LIB):

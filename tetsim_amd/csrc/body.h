@@ -1,0 +1,235 @@
+// body.h -- the handle behind tetsim_handle and the helpers the translation units of the C ABI share.
+//
+//   tetsim_api.hip     lifecycle, stepping (streams / graphs), state read-back, grab, visual mesh, measurement
+//   tetsim_create.hip  construction of the two solvers' device state (host preprocessing -> uploads)
+//   tetsim_halo.hip    multi-GPU: halo choreography (two queues, flag or event synchronised), RCCL / in-process transports
+//   tetsim_host.cpp    host-only entry points: preprocessing, partition plans, the .tetsim container
+//
+// There is NO CPU fallback: every compute entry point needs a working HIP device and fails with
+// TETSIM_ENODEVICE / TETSIM_EHIP otherwise.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tetsim.h"
+#include "dev_common.h"
+#include "dev_store.h"
+#include "host_prep.h"
+#include "mesh_file.h"
+
+namespace tetsim {
+
+constexpr int kRing = 64;  // pinned parameter slots in flight
+// device words of the flag-synchronised halo path: [0] G flag, [2] V flag, [4] error
+constexpr uint32_t kSyncWords = 8;
+
+// ---- RCCL, resolved at run time so single-GPU hosts (and the N-API addon) do not need librccl ----------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        // TETSIM_RCCL_LIB: explicit library path (deployments with several RCCL builds; the test double of tests/mock_rccl)
+        if (const char* over = getenv("TETSIM_RCCL_LIB")) {
+            lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { err = std::string("cannot load TETSIM_RCCL_LIB=") + over + ": " + dlerror(); return false; }
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+extern Rccl g_rccl;
+
+struct NeighDev {
+    int rank = -1;
+    uint32_t send_count = 0, recv_start = 0, recv_count = 0;
+    bool contiguous = false;
+    uint32_t send_first = 0;       // when contiguous: first local id
+    int32_t* send_idx = nullptr;   // device, when not contiguous
+    float4* send_buf = nullptr;    // device staging, when not contiguous
+    std::vector<int32_t> send_global, recv_global, send_local;
+};
+
+}  // namespace tetsim
+
+using namespace tetsim;  // (private header of the ABI's own translation units; the handle type lives in the global namespace)
+
+struct tetsim_body {
+    std::string err;
+    TetSimOptions opt{};
+    TetSimInfo info{};
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
+    uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
+    uint32_t halo_seq = 0;              // substep sequence number of the flag-synchronised path
+    uint32_t* d_sync = nullptr;         // device counters of the flag-synchronised halo path: G done/taken, V done/taken, error
+    bool flag_sync = false;             // this body steps through the flag-synchronised path (blocked + transport)
+    bool halo_graph_broken = false;
+    bool halo_warm = false;             // RCCL bodies: one eager call has run (connections are set up before any capture)
+    bool loopback = false;              // measurement only (TETSIM_DEBUG_LOOPBACK_HALO): every neighbour is this rank itself
+    bool needs_halo_refresh = false;    // in-process group: predictions were redone for a new dt
+    bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;
+    // halo choreography events, double buffered by substep parity: an event is never re-recorded while a wait that
+    // other streams enqueued on its previous record may still be pending
+    hipEvent_t ev_boundary2[2] = {nullptr, nullptr}, ev_packed2[2] = {nullptr, nullptr}, ev_sent2[2] = {nullptr, nullptr};
+    uint32_t halo_parity = 0;
+    DevParams* d_params = nullptr;
+    DevParams* h_ring = nullptr;  // pinned [kRing]
+    hipEvent_t ring_ev[kRing] = {};
+    bool ring_used[kRing] = {};
+    int ring_pos = 0;
+    std::vector<int32_t> tet_colour;  // copy of TetSimOptions.tet_colour (create only)
+    int32_t grab_global = -1;
+    int32_t grab_ref[2] = {-1, -1};  // particles the reference's indexFromUV pins for grab_global (TETSIM_FLAG_REF_GRAB_TEXEL)
+    float grab_pos[3] = {0, 0, 0};
+    std::map<uint32_t, hipGraphExec_t> graphs;
+    std::vector<void*> allocs;
+    std::vector<float> h_verts;
+    std::vector<int32_t> h_tets;
+    bool fast = false;
+
+    // POLAR_JACOBI
+    PJDev pj;
+    PJBlk blk;             // blocked formulation (FAST unless TETSIM_FLAG_GATHER_FORMULATION)
+    bool blocked = false;
+    std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
+    // Particles are renumbered on the device (Morton order inside the interior segment) for locality; the API keeps
+    // the caller's / the partition plan's numbering.  api2dev[a] = device index of API-local particle a.
+    std::vector<uint32_t> api2dev, dev2api;
+    Partition part;
+    bool partitioned = false;
+    std::vector<int32_t> g2l_owned;  // global vertex -> local id (owned) or -1
+    std::vector<NeighDev> neigh;
+    bool pred_any_dt = true;  // velocities are all zero: the prediction is valid for every dt
+    float dt_pred = 0.0f;
+    ncclComm_t comm = nullptr;
+    int comm_rank = -1, comm_size = 0;
+    bool halo_pending = false;            // a halo was started and nobody has waited for it yet
+    std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
+
+    SkinDev skin;  // embedded visual mesh
+    float* pinned_pos = nullptr;   // tetsim_read_positions_pinned: host-pinned xyz
+    float* d_packed = nullptr;     //   and its device-side staging
+    uint32_t* d_api2dev = nullptr; // device copy of api2dev (pack / nearest kernels), null = identity
+    double* d_best = nullptr; uint32_t* d_best_id = nullptr;  // tetsim_start_grab candidates
+
+    // NEOHOOKEAN_GS
+    NHDev nh;
+    std::vector<NHClusterLaunch> cluster_launch;  // TETSIM_ORDER_CLUSTERED: one per cluster colour
+    int32_t* d_slot_vid = nullptr;
+    std::vector<uint32_t> level_off;
+    std::vector<int32_t> order;
+    std::vector<float> h_inv_mass;
+};
+
+namespace tetsim {
+
+#define HIPCHK(h, call)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return TETSIM_EHIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+int fail(tetsim_body* h, int code, const std::string& msg);  // records the message on the handle (or for tetsim_last_error(NULL))
+const char* create_error();
+
+template <class Tp>
+inline int dev_alloc(tetsim_body* h, Tp** p, size_t count) {
+    *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
+    void* raw = nullptr;
+    hipError_t e = hipMalloc(&raw, bytes);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e); return TETSIM_ENOMEM; }
+    h->allocs.push_back(raw);
+    h->info.device_bytes += bytes;
+    *p = static_cast<Tp*>(raw);
+    return 0;
+}
+template <class Tp>
+inline int upload(tetsim_body* h, Tp* dst, const std::vector<Tp>& src) {
+    if (src.empty()) return 0;
+    HIPCHK(h, hipMemcpy(dst, src.data(), src.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// SoftbodyGPU.js:335-338,345: texel (px,py) of the R x R position texture is pinned when
+
+void ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]);
+int push_params(tetsim_body* h, double dt, const TetSimParams* params);
+
+// Development: TETSIM_DEBUG_HOSTPROF=1 accumulates the host time of every call in the eager halo path, printed at destroy.
+struct HostProf {
+    bool on = [] { const char* e = getenv("TETSIM_DEBUG_HOSTPROF"); return e && e[0] == '1'; }();
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+    ~HostProf() { for (auto& kv : acc) fprintf(stderr, "[hostprof] %-28s %8.2f us avg over %llu calls\n", kv.first.c_str(), kv.second.first / kv.second.second, (unsigned long long)kv.second.second); }
+};
+extern HostProf g_hostprof;
+struct HostProfScope {
+    const char* label; std::chrono::steady_clock::time_point t0;
+    explicit HostProfScope(const char* l) : label(l) { if (g_hostprof.on) t0 = std::chrono::steady_clock::now(); }
+    ~HostProfScope() { if (g_hostprof.on) { auto& a = g_hostprof.acc[label]; a.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); a.second++; } }
+};
+#define HP(label) HostProfScope hp_scope_##__LINE__(label)
+
+// ---- kernel sequencing (tetsim_api.hip)
+void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_repredict(tetsim_body* h);
+void nh_sweep(tetsim_body* h);
+// first / last: position inside a run of substeps enqueued back to back with one dt
+int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
+int ensure_prediction(tetsim_body* h, double dt);
+int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out);
+
+// ---- construction (tetsim_create.hip)
+int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt);
+int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt);
+
+// ---- halo (tetsim_halo.hip)
+int create_halo_stream(tetsim_body* h);
+int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what);
+int halo_start(tetsim_body* h);
+int halo_wait(tetsim_body* h, hipStream_t on);
+uint32_t halo_timeout_ms();
+bool has_transport(const tetsim_body* h);
+bool uses_flag_sync(const tetsim_body* h);
+int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr);  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
+int enqueue_phase_b(tetsim_body* h);                            // halo start
+
+}  // namespace tetsim

@@ -1,0 +1,329 @@
+// tetsim_create.hip -- construction: host preprocessing (host_prep.cpp) -> device state of the two solvers.
+#include "body.h"
+
+namespace tetsim {
+
+// ---- construction ----------------------------------------------------------------------------------------
+int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt) {
+    const TetSimOptions& o = h->opt;
+    const bool ref_table = (o.flags & TETSIM_FLAG_REF_SLOT_TABLE) != 0;
+    std::vector<int32_t> ltets;   // local connectivity
+    std::vector<int32_t> l2g_v, l2g_t;
+    uint32_t nvl = nv, nvo = nv, nvb = 0, ntl = nt;
+    h->partitioned = o.part_count > 1;
+    if (h->partitioned) {
+        std::string e = build_partition(tets, nt, nv, o.part_count, o.part_index, o.vert_owner, &h->part);
+        if (!e.empty()) return fail(h, TETSIM_EINVAL, e);
+        const Partition& P = h->part;
+        ltets = P.local_tets;
+        l2g_v = P.local_to_global_vert;
+        l2g_t = P.local_to_global_tet;
+        nvl = static_cast<uint32_t>(l2g_v.size());
+        nvo = P.n_owned;
+        nvb = P.n_boundary;
+        ntl = static_cast<uint32_t>(l2g_t.size());
+        h->g2l_owned.assign(nv, -1);
+        for (uint32_t i = 0; i < nvo; i++) h->g2l_owned[l2g_v[i]] = static_cast<int32_t>(i);
+        h->info.owned_elems = P.owned_tets;
+    } else {
+        ltets.assign(tets, tets + 4ull * nt);
+        h->info.owned_elems = nt;
+    }
+    // device numbering: Morton order inside the interior segment [nvb, nvo); boundary (halo sends stay contiguous
+    // runs) and ghosts (receive ranges) keep the plan's order
+    {
+        std::vector<float> lv(3ull * nvl);
+        for (uint32_t i = 0; i < nvl; i++) {
+            const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
+            lv[3 * i] = verts[3 * g]; lv[3 * i + 1] = verts[3 * g + 1]; lv[3 * i + 2] = verts[3 * g + 2];
+        }
+        h->dev2api = morton_vertex_order(lv.data(), nvl, nvb, nvo - nvb);
+        h->api2dev.resize(nvl);
+        for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
+        for (auto& id : ltets) id = static_cast<int32_t>(h->api2dev[id]);
+    }
+    const bool quirk_here = ref_table && ntl > 0 && (!h->partitioned || l2g_t[0] == 0);
+    Incidence inc = build_incidence(ltets.data(), ntl, nvl, quirk_here, ref_table);
+    // Only owned vertices are averaged here; the table rows of ghosts are never read.
+    uint32_t maxv = 0;
+    for (uint32_t v = 0; v < nvo; v++) maxv = std::max(maxv, inc.offset[v + 1] - inc.offset[v]);
+
+    PJDev& d = h->pj;
+    d.nv_local = nvl; d.nv_owned = nvo; d.nv_boundary = nvb; d.nt = ntl;
+    d.nt_pad = (ntl + 63u) & ~63u;
+    d.nv_pad = (nvo + 63u) & ~63u;
+    d.max_valence = maxv;
+    h->info.owned_particles = nvo;
+    h->info.local_particles = nvl;
+    h->info.local_elems = ntl;
+    h->info.max_valence = maxv;
+    h->info.dropped_slots = inc.dropped;
+
+    int rc;
+    if ((rc = dev_alloc(h, &d.pos_pred, nvl))) return rc;
+    if ((rc = dev_alloc(h, &d.pos_final, nvl))) return rc;
+    if ((rc = dev_alloc(h, &d.vel, nvl))) return rc;
+    d.params = h->d_params;
+
+    std::vector<float4> pos(nvl);
+    std::vector<float> lverts(3ull * nvl);
+    for (uint32_t i = 0; i < nvl; i++) {  // i = device index
+        const uint32_t a = h->dev2api[i];
+        const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[a]) : a;
+        pos[i] = make_float4(verts[3 * g], verts[3 * g + 1], verts[3 * g + 2], 0.0f);
+        lverts[3 * i] = verts[3 * g]; lverts[3 * i + 1] = verts[3 * g + 1]; lverts[3 * i + 2] = verts[3 * g + 2];
+    }
+    if ((rc = upload(h, d.pos_pred, pos))) return rc;
+    if ((rc = upload(h, d.pos_final, pos))) return rc;
+    HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nvl, 1) * sizeof(float4)));
+
+    // the weight the reference's P4 writes into elems.w: 1.0 / texture(invRestVolume).x, in f32
+    // (SoftbodyGPU.js:220,259-262 with invRestVolume = fround(1/V), :582-589)
+    auto rest_weight = [&](uint32_t local_tet) {
+        const uint32_t ge = h->partitioned ? static_cast<uint32_t>(l2g_t[local_tet]) : local_tet;
+        return 1.0f / pj_inv_rest_volume(verts, &tets[4 * ge]);
+    };
+
+    h->blocked = h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION);
+    if ((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && !h->blocked)
+        return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
+    if (h->blocked) {
+        BlockPlan B;
+        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
+        h->tet_perm = B.tet_perm;
+        PJBlk& k = h->blk;
+        h->interior_tets = B.blk_tet_off[B.num_interior_blocks];
+        k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
+        k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
+        k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
+        uint32_t *bto, *bvo, *lcr, *vpe;
+        int32_t* bv;
+        uchar4* lidx;
+        float* vol;
+        uint2* lce;
+        const size_t nslots = B.blk_verts.size();
+        if ((rc = dev_alloc(h, &bto, B.blk_tet_off.size()))) return rc;
+        if ((rc = dev_alloc(h, &bvo, B.blk_vert_off.size()))) return rc;
+        if ((rc = dev_alloc(h, &bv, nslots))) return rc;
+        if (ntl >= kStoreWtMaxIndex || nslots >= kStoreWtMaxIndex || nvl >= kStoreWtMaxIndex)
+            return fail(h, TETSIM_EINVAL, "body too large for one handle (2^27 tets / particles / partial sums: 32-bit store offsets, dev_store.h); partition it");
+        if ((rc = dev_alloc(h, &lidx, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_a, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_b, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.rest_c, ntl))) return rc;
+        if ((rc = dev_alloc(h, &vol, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.quat, ntl))) return rc;
+        if ((rc = dev_alloc(h, &lcr, nslots))) return rc;
+        if ((rc = dev_alloc(h, &lce, ntl))) return rc;
+        if ((rc = dev_alloc(h, &k.partial, nslots))) return rc;
+        if ((rc = dev_alloc(h, &vpe, B.vp_ell.size()))) return rc;
+        std::vector<float4> ra(ntl), rb(ntl), rcv(ntl), quat(ntl, make_float4(0, 0, 0, 1));
+        std::vector<float> volh(ntl);
+        std::vector<uchar4> lidxh(ntl);
+        std::vector<uint2> lceh(ntl);
+        for (uint32_t i = 0; i < ntl; i++) {
+            const uint32_t lt = static_cast<uint32_t>(B.tet_perm[i]);
+            const int32_t* c = &ltets[4 * lt];
+            const float4 p0 = pos[c[0]], p1 = pos[c[1]], p2 = pos[c[2]], p3 = pos[c[3]];
+            float4 r0 = p0, r1 = p1, r2 = p2, r3 = p3;
+            if (k.lean) {  // centred rest shape, with the arithmetic the kernel would use (f32, same association)
+                const float cx = (((p0.x + p1.x) + p2.x) + p3.x) * 0.25f, cy = (((p0.y + p1.y) + p2.y) + p3.y) * 0.25f,
+                            cz = (((p0.z + p1.z) + p2.z) + p3.z) * 0.25f;
+                r0 = make_float4(p0.x - cx, p0.y - cy, p0.z - cz, 0.0f); r1 = make_float4(p1.x - cx, p1.y - cy, p1.z - cz, 0.0f);
+                r2 = make_float4(p2.x - cx, p2.y - cy, p2.z - cz, 0.0f); r3 = make_float4(p3.x - cx, p3.y - cy, p3.z - cz, 0.0f);
+            }
+            ra[i] = make_float4(r0.x, r0.y, r0.z, r1.x);
+            rb[i] = make_float4(r1.y, r1.z, r2.x, r2.y);
+            rcv[i] = make_float4(r2.z, r3.x, r3.y, r3.z);
+            volh[i] = rest_weight(lt);
+            lidxh[i] = make_uchar4(B.tet_lidx[4ull * i], B.tet_lidx[4ull * i + 1], B.tet_lidx[4ull * i + 2], B.tet_lidx[4ull * i + 3]);
+            const uint16_t* en = &B.lc_ent[4ull * i];
+            lceh[i] = make_uint2(en[0] | (static_cast<uint32_t>(en[1]) << 16), en[2] | (static_cast<uint32_t>(en[3]) << 16));
+        }
+        if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
+        if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
+        if ((rc = upload(h, bv, B.blk_verts))) return rc;
+        if ((rc = upload(h, lidx, lidxh))) return rc;
+        if ((rc = upload(h, k.rest_a, ra))) return rc;
+        if ((rc = upload(h, k.rest_b, rb))) return rc;
+        if ((rc = upload(h, k.rest_c, rcv))) return rc;
+        if ((rc = upload(h, vol, volh))) return rc;
+        if ((rc = upload(h, k.quat, quat))) return rc;
+        if ((rc = upload(h, lcr, B.lc_range))) return rc;
+        if ((rc = upload(h, lce, lceh))) return rc;
+        if ((rc = upload(h, vpe, B.vp_ell))) return rc;
+        HIPCHK(h, hipMemset(k.partial, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
+        k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
+        k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
+        d.quat = k.quat;  // tetsim_read_quats
+        if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
+            if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
+            HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));
+        }
+    } else {
+        if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
+        if ((rc = dev_alloc(h, &d.elem, 4ull * d.nt_pad))) return rc;
+        if ((rc = dev_alloc(h, &d.quat, ntl))) return rc;
+        if ((rc = dev_alloc(h, &d.slot_tab, static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad))) return rc;
+        if ((rc = dev_alloc(h, &d.slot_cnt, d.nv_pad))) return rc;
+        std::vector<int4> idx(ntl);
+        std::vector<float4> elem(4ull * d.nt_pad, make_float4(0, 0, 0, 0)), quat(ntl, make_float4(0, 0, 0, 1));
+        for (uint32_t e = 0; e < ntl; e++) {
+            const int32_t* lt = &ltets[4 * e];
+            idx[e] = make_int4(lt[0], lt[1], lt[2], lt[3]);
+            const float w = rest_weight(e);
+            for (int k = 0; k < 4; k++) {
+                const float4 p = pos[lt[k]];
+                elem[static_cast<size_t>(k) * d.nt_pad + e] = make_float4(p.x, p.y, p.z, w);
+            }
+        }
+        if ((rc = upload(h, d.tet_idx, idx))) return rc;
+        if ((rc = upload(h, d.elem, elem))) return rc;
+        if ((rc = upload(h, d.quat, quat))) return rc;
+
+        std::vector<int32_t> tab(static_cast<size_t>(std::max(maxv, 1u)) * d.nv_pad, 0);
+        std::vector<uint32_t> cnt(d.nv_pad, 0);
+        for (uint32_t v = 0; v < nvo; v++) {
+            const uint32_t c = inc.offset[v + 1] - inc.offset[v];
+            cnt[v] = c;
+            for (uint32_t sl = 0; sl < c; sl++) {
+                const int32_t enc = inc.slot[inc.offset[v] + sl];
+                tab[static_cast<size_t>(sl) * d.nv_pad + v] = static_cast<int32_t>((enc & 3) * d.nt_pad + (enc >> 2));
+            }
+        }
+        if ((rc = upload(h, d.slot_tab, tab))) return rc;
+        if ((rc = upload(h, d.slot_cnt, cnt))) return rc;
+    }
+
+    if (h->partitioned) {
+        for (const auto& nb : h->part.neigh) {
+            NeighDev nd;
+            nd.rank = nb.rank;
+            nd.send_count = static_cast<uint32_t>(nb.send_local.size());
+            nd.recv_start = nb.recv_start;
+            nd.recv_count = nb.recv_count;
+            nd.contiguous = nb.send_contiguous;
+            nd.send_first = nd.send_count ? static_cast<uint32_t>(nb.send_local[0]) : 0;
+            nd.send_global = nb.send_global;
+            nd.recv_global = nb.recv_global;
+            nd.send_local = nb.send_local;
+            if (nd.send_count) {  // staging is always available (tetsim_halo_export, non-contiguous sends)
+                if ((rc = dev_alloc(h, &nd.send_idx, nd.send_count))) return rc;
+                if ((rc = dev_alloc(h, &nd.send_buf, nd.send_count))) return rc;
+                if ((rc = upload(h, nd.send_idx, nb.send_local))) return rc;
+            }
+            h->neigh.push_back(std::move(nd));
+        }
+        h->info.num_neighbours = static_cast<uint32_t>(h->neigh.size());
+    }
+    return 0;
+}
+
+int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt) {
+    const TetSimOptions& o = h->opt;
+    if (o.part_count > 1) return fail(h, TETSIM_EINVAL, "NEOHOOKEAN_GS does not partition (one halo per colour would be needed); use POLAR_JACOBI");
+    // 1. element order
+    std::vector<int32_t> pre(nt);
+    for (uint32_t e = 0; e < nt; e++) pre[e] = static_cast<int32_t>(e);
+    if (o.order == TETSIM_ORDER_COLOURED) {
+        std::vector<int32_t> colour(nt);
+        if (h->tet_colour.size() == nt) colour = h->tet_colour;  // caller-supplied (TetSimOptions.tet_colour)
+        else prep_colours(tets, nt, nv, colour.data());
+        std::stable_sort(pre.begin(), pre.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+    }
+    ClusterPlan plan;
+    const bool clustered = o.order == TETSIM_ORDER_CLUSTERED;
+    if (clustered) {
+        plan = prep_clusters(tets, nt, nv);
+        pre = plan.pre;
+    }
+    std::vector<int32_t> ptets(4ull * nt);
+    for (uint32_t i = 0; i < nt; i++) std::memcpy(&ptets[4 * i], &tets[4 * pre[i]], 4 * sizeof(int32_t));
+    // 2. rest data in the order the reference would see (mass accumulation is order dependent, Softbody.js:74-78)
+    std::vector<float> irp(9ull * nt), irv(nt);
+    h->h_inv_mass.assign(nv, 0.0f);
+    prep_rest(verts, nv, ptets.data(), nt, o.density, h->h_inv_mass.data(), irp.data(), irv.data());
+    // 3. dependency levels of that order; solve order = stable sort by level
+    std::vector<int32_t> pos_in(nt);
+    uint32_t nl = 0;
+    if (clustered) {  // the plan IS the schedule: one launch per cluster colour, storage order = step after step
+        nl = static_cast<uint32_t>(plan.launch_off.size() - 1);
+        for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(plan.exec_pos[i]);
+        h->level_off = plan.launch_off;
+    } else {
+        std::vector<int32_t> level(nt);
+        nl = prep_levels(ptets.data(), nt, nv, level.data());
+        for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(i);
+        std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+        h->level_off.assign(nl + 1, 0);
+        for (uint32_t i = 0; i < nt; i++) h->level_off[level[i] + 1]++;
+        for (uint32_t l = 0; l < nl; l++) h->level_off[l + 1] += h->level_off[l];
+    }
+    h->order.resize(nt);  // solve position -> caller's tet id, for the PERMUTED sequence the reference must be fed
+    std::vector<int32_t> seq(nt);
+    for (uint32_t i = 0; i < nt; i++) seq[i] = pre[i];
+    h->order = seq;  // tetsim_get_tet_order: the sequential order whose result we reproduce
+    h->info.num_levels = nl;
+    h->info.owned_particles = h->info.local_particles = nv;
+    h->info.local_elems = h->info.owned_elems = nt;
+
+    if (nv >= kStoreWtMaxIndex) return fail(h, TETSIM_EINVAL, "more than 2^27 particles (32-bit store offsets, dev_store.h)");
+    NHDev& d = h->nh;
+    d.nv = nv; d.nt = nt;
+    int rc;
+    if ((rc = dev_alloc(h, &d.pos, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.prev, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.vel, nv))) return rc;
+    if ((rc = dev_alloc(h, &d.tet_idx, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_a, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_b, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.irp_c, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.vol_err, nt))) return rc;
+    if ((rc = dev_alloc(h, &d.order, nt))) return rc;
+    d.params = h->d_params;
+
+    std::vector<float4> pos(nv);
+    for (uint32_t i = 0; i < nv; i++) pos[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], h->h_inv_mass[i]);
+    if ((rc = upload(h, d.pos, pos))) return rc;
+    if ((rc = upload(h, d.prev, pos))) return rc;
+    HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nv, 1) * sizeof(float4)));
+    HIPCHK(h, hipMemset(d.vol_err, 0, std::max<size_t>(nt, 1) * sizeof(double)));
+    std::vector<int4> idx(nt);
+    std::vector<float4> a(nt), b(nt), c(nt);
+    std::vector<int32_t> ord(nt);
+    for (uint32_t s = 0; s < nt; s++) {
+        const uint32_t i = static_cast<uint32_t>(pos_in[s]);  // position in the permuted sequential order
+        const int32_t* t = &ptets[4 * i];
+        idx[s] = make_int4(t[0], t[1], t[2], t[3]);
+        const float* m = &irp[9 * i];
+        a[s] = make_float4(m[0], m[1], m[2], m[3]);
+        b[s] = make_float4(m[4], m[5], m[6], m[7]);
+        c[s] = make_float4(m[8], irv[i], 0.0f, 0.0f);
+        ord[s] = static_cast<int32_t>(i);  // vol_err is indexed by sequential position
+    }
+    if ((rc = upload(h, d.tet_idx, idx))) return rc;
+    if ((rc = upload(h, d.irp_a, a))) return rc;
+    if ((rc = upload(h, d.irp_b, b))) return rc;
+    if ((rc = upload(h, d.irp_c, c))) return rc;
+    if ((rc = upload(h, d.order, ord))) return rc;
+    if (clustered) {
+        if ((rc = dev_alloc(h, &d.corner_slots, nt))) return rc;
+        if ((rc = upload(h, d.corner_slots, plan.corner_slots))) return rc;
+        if ((rc = dev_alloc(h, &h->d_slot_vid, plan.slot_vid.size()))) return rc;
+        if ((rc = upload(h, h->d_slot_vid, plan.slot_vid))) return rc;
+        for (uint32_t l = 0; l < nl; l++) {
+            NHClusterLaunch L;
+            L.nsteps = plan.step_off[l + 1] - plan.step_off[l];
+            for (uint32_t j = 0; j < L.nsteps; j++) {
+                L.first[j] = plan.step_first[plan.step_off[l] + j];
+                L.count[j] = plan.step_count[plan.step_off[l] + j];
+            }
+            L.clusters = L.nsteps ? L.count[0] : 0;
+            L.slot_vid = h->d_slot_vid + plan.vid_off[l];
+            h->cluster_launch.push_back(L);
+        }
+    }
+    return 0;
+}
+
+}  // namespace tetsim

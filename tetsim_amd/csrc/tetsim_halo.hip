@@ -1,0 +1,463 @@
+// tetsim_halo.hip -- multi-GPU: the per-substep halo of partitioned POLAR_JACOBI bodies and its C ABI.
+#include "body.h"
+
+using namespace tetsim;
+
+namespace tetsim {
+
+Rccl g_rccl;
+
+int create_halo_stream(tetsim_body* h) {
+    if (h->comm_stream) return 0;
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_bnd_tet, hipEventDisableTiming));
+    return 0;
+}
+
+int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
+    return fail(h, TETSIM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
+}
+
+// Start this substep's halo: owned interface predictions -> the neighbours' ghost ranges, on the halo stream.
+// Two transports share this choreography: RCCL (one process per GPU) and, for partitions living in ONE process
+// (tests, "multi-GPU without a cluster"), asynchronous device copies issued by the sender.
+//
+// Dependencies (p = substep parity; all partitions of a group advance in lock-step on the host, so parities agree):
+//   boundary[p]  recorded on the main stream after this substep's boundary-particle pass (hence after its tet kernels)
+//   packed[p]    = boundary[p] + the pack kernels of non-contiguous send lists
+//   a transfer into partition D's ghosts waits for D's boundary[p]: D's tet kernels of this substep have read them
+//   sent[p]      recorded on the halo stream after this partition's transfers (RCCL: sends AND receives)
+//   the next substep's first ghost-reading tet kernel waits for every neighbour's sent[p] -- and for OUR sent[p], because
+//   our next boundary pass overwrites the very buffer our transfer reads
+int halo_start(tetsim_body* h) {
+    const uint32_t p = h->halo_parity;
+    if (h->flag_sync) {  // the halo stream already waited for this substep's particle pass (wait V): stay in stream order
+        for (auto& nb : h->neigh)
+            if (!nb.contiguous && nb.send_count) util_launch_gather4(h->comm_stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+    } else {
+        for (auto& nb : h->neigh)
+            if (!nb.contiguous && nb.send_count) util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+        { HP("record packed"); HIPCHK(h, hipEventRecord(h->ev_packed2[p], h->stream)); }
+        { HP("comm wait packed"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_packed2[p], 0)); }
+    }
+    static const bool lb_copy = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_COPY"); return e && e[0] == '1'; }();
+    if (h->comm && h->loopback && lb_copy) {  // measurement only: the loopback transfer as a plain copy kernel instead of RCCL
+        for (auto& nb : h->neigh)
+            if (nb.send_count) util_launch_copy(h->comm_stream, nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf, h->pj.pos_pred + nb.recv_start, nb.send_count);
+    } else if (h->comm) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
+        for (auto& nb : h->neigh) {
+            if (nb.send_count) {
+                const float4* src = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
+                r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
+                if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
+            }
+            if (nb.recv_count) {
+                // posted on OUR halo stream, i.e. after our boundary pass of this substep: the ghosts are overwritten only
+                // once this partition's tet kernels (which read them) are done
+                r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
+                if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
+            }
+        }
+        r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
+    } else {  // in-process group: sender-driven copies with the ordering guarantees a posted receive gives
+        for (auto& nb : h->neigh) {
+            if (!nb.send_count) continue;
+            tetsim_body* dst = h->group[nb.rank];
+            const NeighDev* back = nullptr;
+            for (auto& r : dst->neigh) if (r.rank == h->opt.part_index) back = &r;
+            if (!back || back->recv_count != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan");
+            { HP("comm wait dst boundary"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, dst->ev_boundary2[p], 0)); }  // receiver finished reading its ghosts
+            const float4* from = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
+            { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
+        }
+    }
+    if (!(h->flag_sync && h->comm)) { HP("record sent"); HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream)); }  // (RCCL + flags: stream order is all there is)
+    h->halo_pending = true;
+    return 0;
+}
+// Make this partition's main stream wait until the previous substep's halo is complete (see halo_start).
+int halo_wait(tetsim_body* h, hipStream_t on) {
+    if (!h->halo_pending) return 0;
+    const uint32_t p = h->halo_parity ^ 1u;  // the previous substep's parity
+    // our own transfers (RCCL: includes our receives); implied by stream order when the consumer runs on the halo stream
+    if (on != h->comm_stream) { HP("wait own sent"); HIPCHK(h, hipStreamWaitEvent(on, h->ev_sent2[p], 0)); }
+    if (!h->comm)
+        for (auto& nb : h->neigh)
+            if (nb.recv_count) { HP("wait peer sent"); HIPCHK(h, hipStreamWaitEvent(on, h->group[nb.rank]->ev_sent2[p], 0)); }
+    h->halo_pending = false;
+    return 0;
+}
+// Bound of the device-side waits of the flag path.  `wait G` sits behind a transfer, i.e. behind the PEER's progress: a rank
+// that steps this much later than its neighbour is reported as TETSIM_ECOMM at the next synchronisation.  0 = wait for ever.
+uint32_t halo_timeout_ms() {
+    static const uint32_t ms = [] { const char* e = getenv("TETSIM_HALO_TIMEOUT_MS"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 30000u; }();
+    return ms;
+}
+bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
+// blocked bodies with a transport and ghost-touching tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
+bool uses_flag_sync(const tetsim_body* h) {
+    static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();
+    static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
+    return use_flags && !one_stream && has_transport(h) && h->blocked && h->blk.nb > h->blk.nb_interior;
+}
+
+// Host cost matters here: a substep is ~42 us of GPU work and every launch / event call costs 1.5-4 us, so the eager
+// halo path issues as few operations as possible -- 3 kernel launches (interior tiles, boundary tiles, ONE particle pass),
+// 1 event record + 1 cross-stream wait to start the transfer, 1 record after it, 1 wait before the next boundary tiles.
+// The transfer overlaps the NEXT substep's interior tet kernel (~30 us), which is ample for a 200 KB message.
+//
+// In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
+// boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
+int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
+    if (h->blocked) {
+        const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
+        static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
+        static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();  // "events" = the older path
+        if (nbnd && !one_stream && use_flags) {
+            // Two queues, synchronised through device counters instead of events (util_kernels.hip: a cross-stream event costs
+            // ~15 us eagerly and ~6 us as a graph edge here, and a substep has two on its critical path):
+            //   main stream:  interior tiles(s) -> wait G(s) -> particles(s) -> signal V(s)
+            //   halo stream:  ghost tiles G(s) -> signal G(s) -> wait V(s) -> transfer(s)              [transfer(s-1) precedes G(s)]
+            // signal / wait are one-wave kernels (pj_blocked.hip).  Host submission order follows the dependencies (G, signal G,
+            // interior, wait G, particles, signal V, wait V, transfer): every wait is submitted after its signal, so the path
+            // stays live even if the runtime maps both streams onto one hardware queue (it then merely serialises).
+            if (!h->d_sync) {
+                int rc = dev_alloc(h, &h->d_sync, kSyncWords);
+                if (rc) return rc;
+                HIPCHK(h, hipMemset(h->d_sync, 0, kSyncWords * sizeof(uint32_t)));
+                HIPCHK(h, hipDeviceSynchronize());   // once: the halo stream must also see everything create() uploaded
+            }
+            h->flag_sync = true;
+            const uint32_t seq = ++h->halo_seq;
+            PJSync yg, yv;   // word 0: "G tiles of substep seq are done"; word 2: "particles of substep seq are done"
+            yg.wait = yg.signal = h->d_sync + 0; yg.error = h->d_sync + 4; yg.seq = seq; yg.timeout_ms = halo_timeout_ms();
+            yv.wait = yv.signal = h->d_sync + 2; yv.error = h->d_sync + 4; yv.seq = seq; yv.timeout_ms = yg.timeout_ms;
+            int rc = halo_wait(h, h->comm_stream);   // in-process groups: the neighbours' transfers of the previous substep (events)
+            if (rc) return rc;
+            { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
+            { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+            if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
+            { HP("wait G"); pjb_launch_wait(h->stream, yg); }
+            { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+            { HP("signal V"); pjb_launch_signal(h->stream, yv); }
+            { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            return 0;
+        }
+        if (nbnd && !one_stream) {
+            // (TETSIM_HALO_SYNC=events) Interior tiles read no ghost and start at once on the main stream.  The few boundary tiles (272 of 3984 on a
+            // 1 M-tet slab) are launched on the HALO stream, right behind the transfer they depend on: after the interior
+            // kernel on the main stream they cost a whole extra kernel latency (10-16 us: load -> 9 rotation iterations ->
+            // store, however few tiles); beside it their workgroups slot in as interior ones retire (the halo stream has high
+            // priority).  It also saves host work, which matters at ~2-4 us per HIP call against ~42 us of GPU work per
+            // substep: no event between the transfer and its consumer.
+            // Ordering: the halo stream is behind packed[p-1], recorded after the previous particle pass, so the boundary
+            // kernel is behind everything it reads; the first substep of a call forks explicitly.
+            if (h->fork_needed || !h->halo_pending) {
+                HP("fork");
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_fork, 0));
+                h->fork_needed = false;
+            }
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
+            int rc = halo_wait(h, h->comm_stream);
+            if (rc) return rc;
+            { HP("launch tet boundary"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
+            { HP("record bnd_tet"); HIPCHK(h, hipEventRecord(h->ev_bnd_tet, h->comm_stream)); }
+            { HP("main wait bnd_tet"); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_bnd_tet, 0)); }
+        } else {
+            pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior);
+            int rc = halo_wait(h, h->stream);
+            if (rc) return rc;
+            pjb_launch_tet(h->stream, h->blk, h->blk.nb_interior, nbnd);
+        }
+    } else {
+        int rc = halo_wait(h, h->stream);
+        if (rc) return rc;
+        pj_tet(h);
+    }
+    { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+    if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream)); }  // group transport only
+    return 0;
+}
+int enqueue_phase_b(tetsim_body* h) {  // halo start
+    int rc = halo_start(h);
+    if (rc) return rc;
+    h->halo_parity ^= 1u;
+    return 0;
+}
+
+// one substep's launches (parameters already on the device)
+// first / last: position inside a run of substeps enqueued back to back with one dt (NEOHOOKEAN_GS fuses the particle pass
+
+}  // namespace tetsim
+
+extern "C" {
+
+// ---- multi-GPU -----------------------------------------------------------------------------------------------
+int tetsim_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, TETSIM_EINVAL, "null id buffer");
+    if (!g_rccl.load()) return fail(nullptr, TETSIM_ECOMM, g_rccl.err);
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, TETSIM_ECOMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t nranks) {
+    if (!h || !id128) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "halo exchange exists only for POLAR_JACOBI");
+    // Measurement aid: TETSIM_DEBUG_LOOPBACK_HALO=1 + nranks == 1 on a PARTITIONED body makes every neighbour this rank itself:
+    // the real RCCL send/recv kernels then run in the real choreography on one GPU (ghosts receive this rank's own interface
+    // values, so the physics is meaningless -- timing and liveness only).
+    const char* lb = getenv("TETSIM_DEBUG_LOOPBACK_HALO");
+    if (lb && lb[0] == '1' && nranks == 1 && rank == 0 && h->opt.part_count > 1) {
+        for (auto& nb : h->neigh)
+            if (nb.send_count != nb.recv_count) return fail(h, TETSIM_ESTATE, "loopback halo needs equal send and receive counts per neighbour (use equal slabs)");
+        h->loopback = true;
+        fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_LOOPBACK_HALO: partition %d exchanges halos with ITSELF; results are not physics\n", h->opt.part_index);
+    } else if (nranks != h->opt.part_count || rank != h->opt.part_index) return fail(h, TETSIM_EINVAL, "rank/nranks must equal part_index/part_count");
+    if (!g_rccl.load()) return fail(h, TETSIM_ECOMM, g_rccl.err);
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail(h, r, "ncclCommInitRank"); }
+    h->comm_rank = rank;
+    h->comm_size = nranks;
+    { int rc = create_halo_stream(h); if (rc) return rc; }
+    // Connection set-up happens on the first transfer between two ranks and can take seconds; do it here, with the real
+    // message sizes on scratch buffers and a host-side wait, so that the stepping path (whose device-side waits are
+    // bounded, TETSIM_HALO_TIMEOUT_MS) never sees it.  Collective: every rank of the communicator is inside this call.
+    size_t most = 0;
+    for (auto& nb : h->neigh) most = std::max<size_t>(most, std::max(nb.send_count, nb.recv_count));
+    if (most) {
+        float4 *src = nullptr, *dst = nullptr;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), most * sizeof(float4)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), most * h->neigh.size() * sizeof(float4)));
+        int rc = TETSIM_OK;
+        if (hipMemsetAsync(src, 0, most * sizeof(float4), h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up memset failed");
+        r = rc ? ncclSuccess : g_rccl.GroupStart();
+        size_t k = 0;
+        for (auto& nb : h->neigh) {
+            const int peer = h->loopback ? h->comm_rank : nb.rank;
+            if (!rc && r == ncclSuccess && nb.send_count) r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, peer, h->comm, h->comm_stream);
+            if (!rc && r == ncclSuccess && nb.recv_count) r = g_rccl.Recv(dst + most * k, 4ull * nb.recv_count, ncclFloat, peer, h->comm, h->comm_stream);
+            k++;
+        }
+        if (!rc && r == ncclSuccess) r = g_rccl.GroupEnd();
+        if (!rc && r != ncclSuccess) rc = rccl_fail(h, r, "halo warm-up send/recv");
+        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up did not complete");
+        (void)hipFree(src);
+        (void)hipFree(dst);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int tetsim_comm_selftest(tetsim_handle h) {
+    if (!h) return TETSIM_EINVAL;
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    constexpr size_t kN = 256;  // floats
+    float *src = nullptr, *dst = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), kN * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), kN * sizeof(float)));
+    std::vector<float> host(kN), back(kN, 0.0f);
+    for (size_t i = 0; i < kN; i++) host[i] = static_cast<float>(i) * 0.5f + static_cast<float>(h->comm_rank);
+    int rc = TETSIM_OK;
+    if (hipMemcpy(src, host.data(), kN * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(dst, 0, kN * sizeof(float)) != hipSuccess) rc = fail(h, TETSIM_EHIP, "selftest upload failed");
+    if (!rc) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(src, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) rc = rccl_fail(h, r, "selftest send/recv");
+    }
+    if (!rc && (hipStreamSynchronize(h->comm_stream) != hipSuccess ||
+                hipMemcpy(back.data(), dst, kN * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(h, TETSIM_EHIP, "selftest download failed");
+    if (!rc && back != host) rc = fail(h, TETSIM_ECOMM, "selftest: received bytes differ from the bytes sent");
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}
+
+// Measurement helper (multi-GPU design input): cost of ONE grouped ncclSend+ncclRecv of `bytes` to this rank itself,
+// issued `reps` times back to back -- eagerly (use_graph = 0) or captured `per_graph` at a time into a HIP graph and
+// replayed (use_graph = 1).  host_us = host time spent issuing, per group; total_us = wall time to completion, per group.
+int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph, double* host_us, double* total_us) {
+    if (!h || !host_us || !total_us || reps == 0 || bytes < 4) return fail(h, TETSIM_EINVAL, "bad argument");
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const size_t n = bytes / sizeof(float);
+    float *src = nullptr, *dst = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), n * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), n * sizeof(float)));
+    std::vector<float> host(n), back(n, 0.0f);
+    for (size_t i = 0; i < n; i++) host[i] = static_cast<float>(i % 977) + 0.25f;
+    int rc = TETSIM_OK;
+    if (hipMemcpy(src, host.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, n * sizeof(float)) != hipSuccess)
+        rc = fail(h, TETSIM_EHIP, "probe upload failed");
+    auto group = [&]() -> ncclResult_t {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(src, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
+        if (r == ncclSuccess) r = g_rccl.GroupEnd();
+        return r;
+    };
+    using clk = std::chrono::steady_clock;
+    if (!rc) {  // warm-up (connection setup happens on first use)
+        ncclResult_t r = group();
+        if (r != ncclSuccess) rc = rccl_fail(h, r, "probe warm-up");
+        else if (hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe warm-up sync failed");
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (!rc && use_graph) {
+        if (per_graph == 0) per_graph = 1;
+        if (hipStreamBeginCapture(h->comm_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: begin capture failed");
+        for (uint32_t i = 0; !rc && i < per_graph; i++) {
+            ncclResult_t r = group();
+            if (r != ncclSuccess) rc = rccl_fail(h, r, "probe: send/recv under stream capture");
+        }
+        hipError_t e = hipStreamEndCapture(h->comm_stream, &graph);
+        if (!rc && e != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("probe: end capture: ") + hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph instantiate failed");
+    }
+    if (!rc) {
+        (void)hipMemset(dst, 0, n * sizeof(float));
+        (void)hipDeviceSynchronize();
+        const auto t0 = clk::now();
+        uint32_t done = 0;
+        if (use_graph) {
+            for (; done < reps && !rc; done += per_graph)
+                if (hipGraphLaunch(exec, h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph launch failed");
+        } else {
+            for (; done < reps && !rc; done++) {
+                ncclResult_t r = group();
+                if (r != ncclSuccess) rc = rccl_fail(h, r, "probe send/recv");
+            }
+        }
+        const auto t1 = clk::now();
+        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe sync failed");
+        const auto t2 = clk::now();
+        if (!rc) {
+            *host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / done;
+            *total_us = std::chrono::duration<double, std::micro>(t2 - t0).count() / done;
+            if (hipMemcpy(back.data(), dst, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe download failed");
+            else if (back != host) rc = fail(h, TETSIM_ECOMM, "probe: received bytes differ from the bytes sent");
+        }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}
+
+int tetsim_get_halo_plan(tetsim_handle h, int32_t* neigh, int32_t* send_counts, int32_t* recv_counts, int32_t* send_ids, int32_t* recv_ids) {
+    if (!h) return TETSIM_EINVAL;
+    size_t so = 0, ro = 0;
+    for (size_t i = 0; i < h->neigh.size(); i++) {
+        const NeighDev& nb = h->neigh[i];
+        if (neigh) neigh[i] = nb.rank;
+        if (send_counts) send_counts[i] = static_cast<int32_t>(nb.send_count);
+        if (recv_counts) recv_counts[i] = static_cast<int32_t>(nb.recv_count);
+        if (send_ids) std::copy(nb.send_global.begin(), nb.send_global.end(), send_ids + so);
+        if (recv_ids) std::copy(nb.recv_global.begin(), nb.recv_global.end(), recv_ids + ro);
+        so += nb.send_global.size();
+        ro += nb.recv_global.size();
+    }
+    return 0;
+}
+
+int tetsim_halo_export(tetsim_handle h, uint32_t n, float* out_xyzw) {
+    if (!h || !out_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    NeighDev& nb = h->neigh[n];
+    if (!nb.send_count) return 0;
+    util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out_xyzw, nb.send_buf, nb.send_count * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
+    if (!h || !in_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    NeighDev& nb = h->neigh[n];
+    if (!nb.recv_count) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->pj.pos_pred + nb.recv_start, in_xyzw, nb.recv_count * sizeof(float4), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
+    if (!hs || count == 0) return TETSIM_EINVAL;
+    for (uint32_t i = 0; i < count; i++) {
+        tetsim_body* h = hs[i];
+        if (!h || h->opt.part_count != static_cast<int32_t>(count) || h->opt.part_index != static_cast<int32_t>(i) || h->comm)
+            return fail(h, TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition without an RCCL communicator");
+        if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
+        if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream
+            h->group.assign(hs, hs + count);
+            { int rc = create_halo_stream(h); if (rc) return rc; }
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        int rc = push_params(hs[i], dt, params);
+        if (!rc) rc = ensure_prediction(hs[i], dt);
+        if (rc) return rc;
+    }
+    bool refresh = false;
+    for (uint32_t i = 0; i < count; i++) refresh = refresh || hs[i]->needs_halo_refresh;
+    if (refresh) {  // dt changed: every member redid its predictions; re-send them (all "ghosts are free" records, then all copies)
+        for (uint32_t i = 0; i < count; i++) {
+            hs[i]->needs_halo_refresh = false;
+            // "my ghosts may be overwritten": flag bodies record it on the halo stream, which ensure_prediction put behind the re-prediction
+            HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->flag_sync ? hs[i]->comm_stream : hs[i]->stream));
+        }
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
+    }
+    static const bool dbg_sync = getenv("TETSIM_DEBUG_GROUP_SYNC") != nullptr;  // development: serialise every phase
+    for (uint32_t s = 0; s < n; s++) {
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_a(hs[i]); if (rc) return rc; }
+        if (dbg_sync) (void)hipDeviceSynchronize();
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
+        if (dbg_sync) (void)hipDeviceSynchronize();
+    }
+    return 0;
+}
+
+int tetsim_halo_exchange_local(tetsim_handle* hs, uint32_t count) {
+    if (!hs || count == 0) return TETSIM_EINVAL;
+    for (uint32_t i = 0; i < count; i++) {
+        if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i))
+            return fail(hs[i], TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition");
+    }
+    // every partition must have finished its vertex kernel before anyone's ghosts are overwritten
+    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    for (uint32_t i = 0; i < count; i++) {
+        tetsim_body* src = hs[i];
+        for (auto& nb : src->neigh) {
+            if (!nb.send_count) continue;
+            tetsim_body* dst = hs[nb.rank];
+            NeighDev* back = nullptr;
+            for (auto& r : dst->neigh) if (r.rank == static_cast<int>(i)) back = &r;
+            if (!back || back->recv_count != nb.send_count) return fail(src, TETSIM_ESTATE, "asymmetric halo plan");
+            const float4* from = nb.contiguous ? src->pj.pos_pred + nb.send_first : nb.send_buf;
+            if (!nb.contiguous) util_launch_gather4(src->stream, src->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+            HIPCHK(src, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, src->stream));
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    return 0;
+}
+}  // extern "C"

@@ -1,0 +1,146 @@
+// tetsim_host.cpp -- entry points that never touch a device: preprocessing, partition plans, the .tetsim container.
+#include "body.h"
+
+using namespace tetsim;
+
+extern "C" {
+
+// ---- .tetsim mesh container ---------------------------------------------------------------------------------------
+struct tetsim_mesh_file { tetsim::MeshFile* m; };
+
+int tetsim_mesh_write(const char* path, const TetSimMeshArrays* a) {
+    if (!a) return fail(nullptr, TETSIM_EINVAL, "arrays is null");
+    const std::string e = mesh_write(path, *a);
+    return e.empty() ? TETSIM_OK : fail(nullptr, TETSIM_EINVAL, e);
+}
+int tetsim_mesh_open(const char* path, tetsim_mesh* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "out is null");
+    *out = nullptr;
+    tetsim::MeshFile* m = nullptr;
+    const std::string e = mesh_open(path, &m);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *out = new tetsim_mesh_file{m};
+    return TETSIM_OK;
+}
+int tetsim_mesh_arrays(tetsim_mesh m, TetSimMeshArrays* out) {
+    if (!m || !out) return fail(nullptr, TETSIM_EINVAL, "null argument");
+    *out = mesh_arrays(m->m);
+    return TETSIM_OK;
+}
+int tetsim_mesh_close(tetsim_mesh m) {
+    if (!m) return TETSIM_OK;
+    mesh_close(m->m);
+    delete m;
+    return TETSIM_OK;
+}
+
+// ---- host-only preprocessing ---------------------------------------------------------------------------------
+int tetsim_prep_levels(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* level, uint32_t* num_levels) {
+    if ((nt && (!tets || !level)) || !num_levels) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *num_levels = prep_levels(tets, nt, nv, level);
+    return 0;
+}
+int tetsim_prep_colours(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* colour, uint32_t* num_colours) {
+    if ((nt && (!tets || !colour)) || !num_colours) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    *num_colours = prep_colours(tets, nt, nv, colour);
+    return 0;
+}
+int tetsim_prep_clusters(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t* order, int32_t* launch, int32_t* lane, int32_t* step,
+                         uint32_t* num_launches, uint32_t* num_clusters) {
+    if ((nt && (!tets || !order || !launch || !lane || !step)) || !num_launches) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    const ClusterPlan P = prep_clusters(tets, nt, nv);
+    for (uint32_t i = 0; i < nt; i++) order[i] = P.pre[i];
+    const uint32_t nl = static_cast<uint32_t>(P.launch_off.size() - 1);
+    for (uint32_t l = 0; l < nl; l++)
+        for (uint32_t j = P.step_off[l]; j < P.step_off[l + 1]; j++)
+            for (uint32_t i = 0; i < P.step_count[j]; i++) {
+                const uint32_t pos = P.exec_pos[P.step_first[j] + i];
+                launch[pos] = static_cast<int32_t>(l);
+                lane[pos] = static_cast<int32_t>(i);
+                step[pos] = static_cast<int32_t>(j - P.step_off[l]);
+            }
+    *num_launches = nl;
+    if (num_clusters) *num_clusters = P.num_clusters;
+    return 0;
+}
+int tetsim_prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t ref_quirk, int32_t* slots, uint32_t* dropped) {
+    if ((nt && !tets) || !slots) return TETSIM_EINVAL;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    const uint32_t d = prep_slot_table(tets, nt, nv, ref_quirk != 0, slots);
+    if (dropped) *dropped = d;
+    return 0;
+}
+int tetsim_prep_ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]) {
+    if (!out) return TETSIM_EINVAL;
+    ref_grab_texels(grab_id, num_elems, num_particles, out);
+    return 0;
+}
+int tetsim_prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, double density, float* inv_mass, float* inv_rest_pose, float* inv_rest_volume) {
+    if (!inv_mass || (nt && (!inv_rest_pose || !inv_rest_volume))) return TETSIM_EINVAL;
+    std::string e = validate_mesh(verts, nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    prep_rest(verts, nv, tets, nt, density, inv_mass, inv_rest_pose, inv_rest_volume);
+    return 0;
+}
+
+// ---- partition plan (host only) ---------------------------------------------------------------------------------
+struct tetsim_plan_s { Partition P; };
+
+int tetsim_plan_create(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
+                       const int32_t* vert_owner, tetsim_plan* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "null plan pointer");
+    *out = nullptr;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    tetsim_plan_s* p = new tetsim_plan_s();
+    e = build_partition(tets, nt, nv, part_count, part_index, vert_owner, &p->P);
+    if (!e.empty()) { delete p; return fail(nullptr, TETSIM_EINVAL, e); }
+    *out = p;
+    return 0;
+}
+void tetsim_plan_destroy(tetsim_plan p) { delete p; }
+int tetsim_plan_sizes(tetsim_plan p, TetSimPlanSizes* out) {
+    if (!p || !out) return TETSIM_EINVAL;
+    out->owned_particles = p->P.n_owned;
+    out->boundary_particles = p->P.n_boundary;
+    out->local_particles = static_cast<uint32_t>(p->P.local_to_global_vert.size());
+    out->local_elems = static_cast<uint32_t>(p->P.local_to_global_tet.size());
+    out->owned_elems = p->P.owned_tets;
+    out->num_neighbours = static_cast<uint32_t>(p->P.neigh.size());
+    return 0;
+}
+int tetsim_plan_arrays(tetsim_plan p, int32_t* l2gv, int32_t* l2gt, int32_t* ltets) {
+    if (!p) return TETSIM_EINVAL;
+    if (l2gv) std::copy(p->P.local_to_global_vert.begin(), p->P.local_to_global_vert.end(), l2gv);
+    if (l2gt) std::copy(p->P.local_to_global_tet.begin(), p->P.local_to_global_tet.end(), l2gt);
+    if (ltets) std::copy(p->P.local_tets.begin(), p->P.local_tets.end(), ltets);
+    return 0;
+}
+int tetsim_plan_neighbour(tetsim_plan p, uint32_t i, int32_t* rank, uint32_t* send_count, uint32_t* recv_start,
+                          uint32_t* recv_count, int32_t* contiguous) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (rank) *rank = nb.rank;
+    if (send_count) *send_count = static_cast<uint32_t>(nb.send_local.size());
+    if (recv_start) *recv_start = nb.recv_start;
+    if (recv_count) *recv_count = nb.recv_count;
+    if (contiguous) *contiguous = nb.send_contiguous ? 1 : 0;
+    return 0;
+}
+int tetsim_plan_neighbour_ids(tetsim_plan p, uint32_t i, int32_t* send_local, int32_t* send_global, int32_t* recv_global) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (send_local) std::copy(nb.send_local.begin(), nb.send_local.end(), send_local);
+    if (send_global) std::copy(nb.send_global.begin(), nb.send_global.end(), send_global);
+    if (recv_global) std::copy(nb.recv_global.begin(), nb.recv_global.end(), recv_global);
+    return 0;
+}
+
+}  // extern "C"
