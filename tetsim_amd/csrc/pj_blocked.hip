@@ -132,23 +132,30 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     if (tid < nu) {
         const uint32_t first = range & 0xffffu, last = range >> 16;
         const uint16_t* ent = reinterpret_cast<const uint16_t*>(s_ent);
-        // 4 entries per trip: the 4 index reads, then the 16 value reads, are independent LDS ops in flight together
-        // (one entry at a time is a ~9-deep chain of dependent LDS round trips: 4.9k cycles per tile in the
-        // s_memtime trace).  Accumulation order stays entry order, i.e. deterministic.
+        // An entry is the word offset corner * kTile + tet of a corner goal in the planes (host_prep.cpp), so its byte offset
+        // and the byte offset of its tet's weight are one shift and one mask.  4 entries per trip: the 4 index reads, then
+        // the 16 value reads, are independent LDS ops in flight together (one entry at a time is a ~9-deep chain of
+        // dependent LDS round trips: 4.9k cycles per tile in the s_memtime trace); whole groups of 4 run unmasked, the
+        // 0-3 left over one by one.  Accumulation order stays entry order, i.e. deterministic.
+        auto plane = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (uint32_t i = first; i < last; i += 4u) {
-            uint32_t en[4];
+        uint32_t i = first;
+        for (; i + 4u <= last; i += 4u) {
+            uint32_t o[4];
             float gx[4], gy[4], gz[4], gv[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) en[j] = ent[min(i + j, last - 1u)];
+            for (uint32_t j = 0; j < 4u; j++) o[j] = static_cast<uint32_t>(ent[i + j]) << 2;
 #pragma unroll
             for (uint32_t j = 0; j < 4u; j++) {
-                const uint32_t at = (en[j] & 3u) * kTile + (en[j] >> 2);
-                gx[j] = s_gx[at]; gy[j] = s_gy[at]; gz[j] = s_gz[at]; gv[j] = s_v[en[j] >> 2];
+                gx[j] = plane(s_gx, o[j]); gy[j] = plane(s_gy, o[j]); gz[j] = plane(s_gz, o[j]);
+                gv[j] = plane(s_v, o[j] & (4u * kTile - 4u));
             }
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++)
-                if (i + j < last) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; acc.w += gv[j]; }
+            for (uint32_t j = 0; j < 4u; j++) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; acc.w += gv[j]; }
+        }
+        for (; i < last; i++) {
+            const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
+            acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o); acc.w += plane(s_v, o & (4u * kTile - 4u));
         }
         store_wt(d.partial, v0 + tid, acc);
     }
