@@ -91,7 +91,7 @@ struct BlockPlan {
     std::vector<int32_t> blk_verts;      // vertex ids of each tile's LDS slots
     std::vector<uint8_t> tet_lidx;       // [4*nt] LDS slot of every corner (new tet order)
     std::vector<uint32_t> lc_range;      // per tile vertex: first | (last+1) << 16 into the tile's lc_ent
-    std::vector<uint16_t> lc_ent;        // [4*nt] per tile: (tetLocal*4+corner) grouped by LDS slot, tet order inside
+    std::vector<uint16_t> lc_ent;        // [4*nt] per tile: corner*256 + tetLocal (word offset into the goal planes) grouped by LDS slot, tet order inside
     std::vector<uint32_t> vp_off;        // [nv_sum+1] per summed vertex: range into vp_idx
     std::vector<uint32_t> vp_idx;        // indices into the partial-sum array, ascending tile
     std::vector<uint32_t> vp_ell;        // the same lists as ELL [max_partials][nv_pad], 0xffffffff = none

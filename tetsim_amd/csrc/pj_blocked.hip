@@ -203,18 +203,21 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
     const DevParams& P = *d.params;
 
     // P5 (SoftbodyGPU.js:302-320) from tile partial sums, ascending tile order.  The index lists are ELL
-    // (column-major, coalesced, no offset lookup first), fetched 4 columns at a time so 4 gathers are in flight.
+    // (column-major, coalesced, no offset lookup first), fetched 8 columns at a time: the kernel is two dependent memory
+    // round trips (indices, then partial sums) and little else, so a trip must cover almost every particle -- 8 columns
+    // do on the lattice (up to 9 partials; 18 particles have 9), where 4 columns made every wave pay three trips.
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t* col = d.vp_ell + v;
-    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 4u) {
-        uint32_t idx[4];
-        float4 g[4];
+    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 8u) {
+        uint32_t idx[8];
+        float4 g[8];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
+        for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t j = 0; j < 8u; j++) g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
+        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
+        if (__all(idx[7] == 0xffffffffu)) break;  // lists are front-packed: nobody in this wave has a ninth partial
     }
     const float rw = __builtin_amdgcn_rcpf(acc.w);
     f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
