@@ -126,7 +126,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const int32_t* c = &ltets[4 * lt];
             const float4 p0 = pos[c[0]], p1 = pos[c[1]], p2 = pos[c[2]], p3 = pos[c[3]];
             float4 r0 = p0, r1 = p1, r2 = p2, r3 = p3;
-            if (k.lean) {  // centred rest shape, with the arithmetic the kernel would use (f32, same association)
+            {  // the blocked kernels keep the (carried or constant) shape relative to its centroid; f32, the kernel's association
                 const float cx = (((p0.x + p1.x) + p2.x) + p3.x) * 0.25f, cy = (((p0.y + p1.y) + p2.y) + p3.y) * 0.25f,
                             cz = (((p0.z + p1.z) + p2.z) + p3.z) * 0.25f;
                 r0 = make_float4(p0.x - cx, p0.y - cy, p0.z - cz, 0.0f); r1 = make_float4(p1.x - cx, p1.y - cy, p1.z - cz, 0.0f);
