@@ -276,9 +276,8 @@ static uint32_t tet_mode(const PJBlk& d) {
     if (dbg < 0) {  // timing ablations only (see kernel comment); unset => 9 iterations, all stores
         const char* it = getenv("TETSIM_DEBUG_ITERS");
         const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
-        const char* pl = getenv("TETSIM_DEBUG_PLAIN_STORES");
         const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
-        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((pl && pl[0] == '1') ? 32 : 0) | ((np && np[0] == '1') ? 64 : 0);
+        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((np && np[0] == '1') ? 64 : 0);
         if ((dbg & 15) != 9 || (dbg & 16))  // these two change the physics: never silently
             fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_ITERS / TETSIM_DEBUG_SKIP_REST_STORE are set: timing ablation, the results are NOT the solver's\n");
     }
