@@ -369,6 +369,28 @@ def test_lattice_8m_eight_slabs_match_monolithic():
     assert np.abs(np.linalg.norm(mono.quats, axis=1) - 1.0).max() < 1e-5
 
 
+def test_long_run_fast_stays_with_precise():
+    """3 s of simulated time (3,600 substeps: free fall, floor impact with friction, settling) on the Dragon: the FAST
+    blocked path (carried shape relative to its centroid, R/2 iteration, hardware rcp/rsq/sin) must neither drift away from
+    the reference-order PRECISE path nor lose the unit length of its quaternions."""
+    v, t = load_mesh("dragon")
+    pp = dict(PP)
+    prec = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="precise")
+    fast = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast")
+    worst = 0.0
+    for frame in range(180):
+        prec.simulateSubsteps(20, DT20, pp)
+        fast.simulateSubsteps(20, DT20, pp)
+        if frame % 30 == 29:
+            a, b = prec.pos, fast.pos
+            assert np.isfinite(a).all() and np.isfinite(b).all()
+            worst = max(worst, float(np.abs(a - b).max()))
+    assert worst < 5e-3, worst                       # rounding differences amplified by 3 s of contact dynamics: mm, not cm
+    assert np.abs(np.linalg.norm(fast.quats, axis=1) - 1.0).max() < 1e-5
+    assert prec.pos[:, 1].min() > -1e-6 and fast.pos[:, 1].min() > -1e-6      # on the floor, not through it
+    assert abs(prec.pos[:, 1].mean() - fast.pos[:, 1].mean()) < 1e-3
+
+
 def test_rccl_transport_selftest():
     """The RCCL entry points are resolved with dlopen at run time; a 1-rank communicator + a send/recv to self on
     the halo stream proves they work on this host (real multi-rank halos need >1 GPU: driver's scaling run)."""
