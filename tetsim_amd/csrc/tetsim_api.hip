@@ -423,7 +423,7 @@ int tetsim_sync(tetsim_handle h) {
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted
         uint32_t err = 0;
         HIPCHK(h, hipMemcpy(&err, h->d_sync + 4, sizeof err, hipMemcpyDeviceToHost));
-        if (err) return fail(h, TETSIM_ECOMM, "a halo dependency was not signalled within 2 s (device-side wait timed out): a rank or a queue is stuck");
+        if (err) return fail(h, TETSIM_ECOMM, "a halo dependency was not signalled in time (device-side wait reached TETSIM_HALO_TIMEOUT_MS): a rank or a queue is stuck");
     }
     return 0;
 }

@@ -193,9 +193,6 @@ int enqueue_phase_b(tetsim_body* h) {  // halo start
     return 0;
 }
 
-// one substep's launches (parameters already on the device)
-// first / last: position inside a run of substeps enqueued back to back with one dt (NEOHOOKEAN_GS fuses the particle pass
-
 }  // namespace tetsim
 
 extern "C" {
