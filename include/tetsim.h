@@ -223,6 +223,16 @@ int tetsim_set_visual_mesh(tetsim_handle h, const float *vis_verts, uint32_t nvi
  * bit-exact with it) or like the vertex shader of SoftbodyGPU.js:429-435 (POLAR_JACOBI, f32).
  * normals_out [3*nvis] (may be NULL): Rotate(rest_normal, quat[tetNr]) as SoftbodyGPU.js:440 -- POLAR_JACOBI only. */
 int tetsim_read_visual_mesh(tetsim_handle h, float *positions_out, float *normals_out);
+/* The visual mesh's triangle list, as the reference hands it to the geometry index (Dragon.js `dragonAttachedTriIds`;
+ * Softbody.js:48-50, SoftbodyGPU.js:455-457): [3*ntri] ids of visual vertices.  Needed by tetsim_read_visual_vertex_normals. */
+int tetsim_set_visual_triangles(tetsim_handle h, const int32_t *tri_ids, uint32_t ntri);
+/* `visMesh.geometry.computeVertexNormals()` (Softbody.js:273, every frame -- 37 ms of the CPU path's frame, SURVEY.md §8(f)-1;
+ * SoftbodyGPU.js:687 when physicsParams.computeNormals) on the device, for the positions tetsim_read_visual_mesh returns:
+ * three.js r160 BufferGeometry.computeVertexNormals (indexed) + normalizeNormals -- face normal (pC-pB) x (pA-pB) in f64 from
+ * the f32 positions, added to the triangle's three vertices in triangle order with an f32 store per add, then scaled by
+ * 1/(length || 1) in f64 and stored f32.  Each vertex gathers its triangles in that order, so the result equals the
+ * reference's bit for bit (golden recorded from three.js).  normals_out [3*nvis].  Synchronises. */
+int tetsim_read_visual_vertex_normals(tetsim_handle h, float *normals_out);
 
 /* --- grab (Softbody.js:279-298 ; SoftbodyGPU.js:692-712) --------------------------------------- */
 

@@ -74,7 +74,12 @@ async function main() {
         body.endFrame();
         const vis = body.visMesh.geometry.attributes.position.array;
         writeF32('dragon_vispos_10.f32', vis);
-        golden.vis = { dragon_vispos_10: sha(vis), numVisVerts: body.numVisVerts };
+        // ... and the vertex normals three.js derives from them every frame (Softbody.js:273 -> BufferGeometry.computeVertexNormals)
+        const nrm = body.visMesh.geometry.attributes.normal.array;
+        writeF32('dragon_visnormal_10.f32', nrm);
+        const tris = Uint16Array.from(D.dragonAttachedTriIds);   // input data: the visual mesh's triangle list (Dragon.js; 29,800 vertices fit u16)
+        fs.writeFileSync(path.join(outDir, 'dragon_vistris.u16'), Buffer.from(tris.buffer));
+        golden.vis = { dragon_vispos_10: sha(vis), dragon_visnormal_10: sha(nrm), numVisVerts: body.numVisVerts, numVisTris: tris.length / 3 };
         console.log('vis', golden.vis);
     }
     fs.writeFileSync(path.join(outDir, 'golden.json'), JSON.stringify(golden, null, 1));

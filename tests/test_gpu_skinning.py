@@ -26,6 +26,38 @@ def test_neohookean_skinning_bit_exact_vs_reference(golden):
     assert sha16(got) == "8df79c236ba69d61"
 
 
+def test_vertex_normals_bit_exact_vs_threejs(golden):
+    """`visMesh.geometry.computeVertexNormals()` (Softbody.js:273: the bulk of the CPU path's frame once the solve is fast) on
+    the device: 29,800 normals over 59,657 triangles after 10 substeps, bit-identical to what three.js r160 produced inside
+    the reference (golden recorded by tests/golden/make_golden.mjs)."""
+    import os
+    from conftest import GOLDEN
+    v, t = load_mesh("dragon")
+    vis = load_f32("dragon_vis.f32").reshape(-1, 4)
+    tris = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int32).reshape(-1, 3)
+    assert len(tris) == 59657
+    body = SoftBodyHIP(v, t, None, dict(PP), vis, solver="neohookean", precision="precise")
+    body.setVisualTriangles(tris)
+    dt = (1.0 * (1.0 / 60.0)) / 10
+    for _ in range(10):
+        body.simulate(dt, PP)
+    got = body.visualVertexNormals()
+    ref = load_f32("dragon_visnormal_10.f32").reshape(-1, 3)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert sha16(got) == "77a1f9768ab27ed3"   # golden.json: vis.dragon_visnormal_10
+    # degenerate input: a triangle that lists a vertex twice has a zero face normal; a vertex without triangles keeps (0,0,0)
+    small = SoftBodyHIP(v, t, None, dict(PP), vis[:8], solver="neohookean", precision="precise")
+    small.setVisualTriangles(np.array([[0, 1, 2], [2, 1, 3], [4, 4, 5]], np.int32))
+    n = small.visualVertexNormals()
+    assert np.isfinite(n).all() and np.all(n[6] == 0) and np.all(n[7] == 0) and np.all(n[4] == 0)
+    assert np.abs(np.linalg.norm(n[:4], axis=1) - 1.0).max() < 1e-6
+    with pytest.raises(Exception):
+        small.setVisualTriangles(np.array([[0, 1, 2]], np.int32))        # attached once
+    other = SoftBodyHIP(v, t, None, dict(PP), vis[:8], solver="neohookean", precision="precise")
+    with pytest.raises(Exception):
+        other.setVisualTriangles(np.array([[0, 1, 8]], np.int32))        # id outside the visual mesh
+
+
 @pytest.mark.parametrize("precision", ["precise", "fast"])
 def test_polar_skinning_and_normals(precision):
     """Vertex-shader formula of SoftbodyGPU.js:429-440 evaluated on the device: positions from the (internally

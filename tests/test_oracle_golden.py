@@ -99,3 +99,28 @@ def test_js_port_bit_exact(name, step, golden):
         assert r["vol_error"] is None          # NaN serialises as null
     else:
         assert r["vol_error"] == want
+
+
+def test_vertex_normals_golden_is_threejs_computeVertexNormals():
+    """The golden normals (three.js r160 inside the reference, tests/golden/make_golden.mjs) equal a plain restatement of
+    BufferGeometry.computeVertexNormals + normalizeNormals: f64 face normals from f32 positions, accumulated in triangle order
+    with an f32 store per add, normalised in f64, stored f32.  This pins what the device kernel (skin_kernels.hip) follows."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN, load_f32
+    pos = load_f32("dragon_vispos_10.f32").reshape(-1, 3)
+    tri = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int64).reshape(-1, 3)
+    ref = load_f32("dragon_visnormal_10.f32").reshape(-1, 3)
+    P = pos.astype(np.float64)
+    cb, ab = P[tri[:, 2]] - P[tri[:, 1]], P[tri[:, 0]] - P[tri[:, 1]]
+    face = np.stack([cb[:, 1] * ab[:, 2] - cb[:, 2] * ab[:, 1], cb[:, 2] * ab[:, 0] - cb[:, 0] * ab[:, 2],
+                     cb[:, 0] * ab[:, 1] - cb[:, 1] * ab[:, 0]], axis=1)
+    n = np.zeros_like(pos)
+    for t in range(len(tri)):
+        for v in tri[t]:
+            n[v] = (n[v].astype(np.float64) + face[t]).astype(np.float32)
+    N = n.astype(np.float64)
+    length = np.sqrt(N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1] + N[:, 2] * N[:, 2])
+    length[length == 0] = 1.0
+    out = (N * (1.0 / length)[:, None]).astype(np.float32)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))

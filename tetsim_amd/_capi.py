@@ -67,7 +67,7 @@ SYMBOLS = [
     "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
-    "tetsim_read_visual_mesh", "tetsim_set_grab",
+    "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
@@ -121,6 +121,8 @@ def lib():
         getattr(L, "tetsim_get_" + n).argtypes = [H, ip]
     L.tetsim_set_visual_mesh.argtypes = [H, fp, u32, fp]
     L.tetsim_read_visual_mesh.argtypes = [H, fp, fp]
+    L.tetsim_set_visual_triangles.argtypes = [H, ip, u32]
+    L.tetsim_read_visual_vertex_normals.argtypes = [H, fp]
     L.tetsim_set_grab.argtypes = [H, i32, fp]
     L.tetsim_start_grab.argtypes = [H, fp, ip]
     L.tetsim_profile.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]

@@ -139,9 +139,16 @@ struct SkinDev {
     const float4* normal0 = nullptr; // rest normals (may be null)
     float4* out_pos = nullptr;
     float4* out_nrm = nullptr;
+    // computeVertexNormals (tetsim_set_visual_triangles): triangles and, per visual vertex, its triangles in triangle order
+    uint32_t ntri = 0;
+    const int4* tri = nullptr;          // (a, b, c, 0)
+    const uint32_t* vt_off = nullptr;   // [nvis + 1]
+    const uint32_t* vt_tri = nullptr;   // triangle ids (a triangle listing a vertex twice appears twice)
+    float4* out_vnrm = nullptr;
 };
 // js_order: Softbody.js:259-277 arithmetic (f64 accumulate, f32 store per step); else SoftbodyGPU.js:431-435 (f32)
 void skin_launch(hipStream_t s, const SkinDev& d, const float4* pos, const float4* quat, bool js_order);
+void skin_launch_vertex_normals(hipStream_t s, const SkinDev& d);   // three.js computeVertexNormals of d.out_pos -> d.out_vnrm
 
 void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map, float* out, uint32_t n);
 void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, uint32_t n, double px, double py, double pz,

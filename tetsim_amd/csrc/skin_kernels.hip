@@ -47,7 +47,39 @@ __global__ __launch_bounds__(256) void skin_kernel(SkinDev d, const float4* __re
     }
 }
 
+// three.js r160 BufferGeometry.computeVertexNormals (indexed branch) + normalizeNormals, as a gather: the reference walks the
+// triangles in order and adds each face normal to its three vertices through Float32Array stores, so vertex v's normal is the
+// f32-rounded running sum over ITS triangles in triangle order -- which one lane per vertex reproduces exactly.
+//   cb = pC - pB; ab = pA - pB; cb.cross(ab)  (Vector3: f64);   n[v] = f32(f64(n[v]) + cb);   n = f32(n * (1 / (|n| || 1)))
+__global__ __launch_bounds__(256) void vertex_normals_kernel(SkinDev d) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= d.nvis) return;
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    for (uint32_t q = d.vt_off[v]; q < d.vt_off[v + 1]; q++) {
+        const int4 t = d.tri[d.vt_tri[q]];
+        const float4 a = d.out_pos[t.x], b = d.out_pos[t.y], c = d.out_pos[t.z];
+        const double cbx = static_cast<double>(c.x) - static_cast<double>(b.x), cby = static_cast<double>(c.y) - static_cast<double>(b.y),
+                     cbz = static_cast<double>(c.z) - static_cast<double>(b.z);
+        const double abx = static_cast<double>(a.x) - static_cast<double>(b.x), aby = static_cast<double>(a.y) - static_cast<double>(b.y),
+                     abz = static_cast<double>(a.z) - static_cast<double>(b.z);
+        const double x = cby * abz - cbz * aby, y = cbz * abx - cbx * abz, z = cbx * aby - cby * abx;   // Vector3.cross
+        nx = static_cast<float>(static_cast<double>(nx) + x);
+        ny = static_cast<float>(static_cast<double>(ny) + y);
+        nz = static_cast<float>(static_cast<double>(nz) + z);
+    }
+    const double X = nx, Y = ny, Z = nz;
+    double len = sqrt(X * X + Y * Y + Z * Z);          // Vector3.length
+    if (len == 0.0 || len != len) len = 1.0;            // `length() || 1` (0 and NaN are falsy)
+    const double s = 1.0 / len;                         // divideScalar(s) = multiplyScalar(1 / s)
+    d.out_vnrm[v] = make_float4(static_cast<float>(X * s), static_cast<float>(Y * s), static_cast<float>(Z * s), 0.0f);
+}
+
 }  // namespace
+
+void skin_launch_vertex_normals(hipStream_t s, const SkinDev& d) {
+    if (d.nvis == 0) return;
+    hipLaunchKernelGGL(vertex_normals_kernel, dim3((d.nvis + 255u) / 256u), dim3(256), 0, s, d);
+}
 
 void skin_launch(hipStream_t s, const SkinDev& d, const float4* pos, const float4* quat, bool js_order) {
     if (d.nvis == 0) return;

@@ -620,6 +620,56 @@ int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normal
     return 0;
 }
 
+int tetsim_set_visual_triangles(tetsim_handle h, const int32_t* tri_ids, uint32_t ntri) {
+    if (!h || (ntri && !tri_ids)) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->skin.nvis) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
+    if (h->skin.vt_off) return fail(h, TETSIM_ESTATE, "visual triangles are already attached");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const uint32_t nvis = h->skin.nvis;
+    std::vector<int4> tri(ntri);
+    std::vector<uint32_t> off(nvis + 1, 0);
+    for (uint32_t t = 0; t < ntri; t++) {
+        for (int k = 0; k < 3; k++) {
+            const int32_t v = tri_ids[3 * t + k];
+            if (v < 0 || static_cast<uint32_t>(v) >= nvis) return fail(h, TETSIM_EINVAL, "triangle " + std::to_string(t) + " references a visual vertex outside the mesh");
+            off[v + 1]++;
+        }
+        tri[t] = make_int4(tri_ids[3 * t], tri_ids[3 * t + 1], tri_ids[3 * t + 2], 0);
+    }
+    for (uint32_t v = 0; v < nvis; v++) off[v + 1] += off[v];
+    std::vector<uint32_t> ent(3ull * ntri), fill(off.begin(), off.end() - 1);
+    for (uint32_t t = 0; t < ntri; t++)   // triangle order, corner order: the order of the reference's accumulation
+        for (int k = 0; k < 3; k++) ent[fill[tri_ids[3 * t + k]]++] = t;
+    SkinDev& k = h->skin;
+    int4* dt; uint32_t *doff, *dent;
+    int rc;
+    if ((rc = dev_alloc(h, &dt, ntri))) return rc;
+    if ((rc = dev_alloc(h, &doff, off.size()))) return rc;
+    if ((rc = dev_alloc(h, &dent, ent.size()))) return rc;
+    if ((rc = dev_alloc(h, &k.out_vnrm, nvis))) return rc;
+    if ((rc = upload(h, dt, tri))) return rc;
+    if ((rc = upload(h, doff, off))) return rc;
+    if ((rc = upload(h, dent, ent))) return rc;
+    k.ntri = ntri; k.tri = dt; k.vt_tri = dent;
+    k.vt_off = doff;
+    return 0;
+}
+
+int tetsim_read_visual_vertex_normals(tetsim_handle h, float* normals_out) {
+    if (!h || !normals_out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->skin.vt_off) return fail(h, TETSIM_ESTATE, "no visual triangles attached (tetsim_set_visual_triangles)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
+    skin_launch_vertex_normals(h->stream, h->skin);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t n = h->skin.nvis;
+    std::vector<float4> tmp(n);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->skin.out_vnrm, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { normals_out[3 * i] = tmp[i].x; normals_out[3 * i + 1] = tmp[i].y; normals_out[3 * i + 2] = tmp[i].z; }
+    return 0;
+}
+
 int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {
     if (!h) return TETSIM_EINVAL;
     if (id >= static_cast<int32_t>(h->info.num_particles)) return fail(h, TETSIM_EINVAL, "grab id out of range");

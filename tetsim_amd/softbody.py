@@ -238,6 +238,17 @@ class SoftBodyHIP:
         capi.check(self._L.tetsim_read_visual_mesh(self._h, _fp(out), _fp(nrm) if with_normals else None), self._h)
         return (out.reshape(-1, 3), nrm.reshape(-1, 3)) if with_normals else out.reshape(-1, 3)
 
+    def setVisualTriangles(self, visTriIds):
+        """The visual mesh's triangle list (the reference's `visTriIds`, Softbody.js:48-50): enables visualVertexNormals()."""
+        tri = np.ascontiguousarray(np.asarray(visTriIds).reshape(-1), dtype=np.int32)
+        capi.check(self._L.tetsim_set_visual_triangles(self._h, tri.ctypes.data_as(C.POINTER(C.c_int32)), tri.size // 3), self._h)
+
+    def visualVertexNormals(self):
+        """`visMesh.geometry.computeVertexNormals()` (Softbody.js:273) evaluated on the device, bit-exact with three.js r160."""
+        out = np.empty(3 * self.numVisVerts, dtype=np.float32)
+        capi.check(self._L.tetsim_read_visual_vertex_normals(self._h, _fp(out)), self._h)
+        return out.reshape(-1, 3)
+
     # -- caller-provided transports (include/tetsim.h: tetsim_get_halo_plan / tetsim_halo_export / tetsim_halo_import) --
     def haloPlan(self):
         """[(neighbour rank, global ids sent, global ids received)] in neighbour-slot order."""
