@@ -69,6 +69,10 @@ class SoftBodyHIP {
         if (this.numVisVerts > 0) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1); createFromFile attached it already
             if (!_meshFile) api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
             this._visOnDevice = true;
+            // ... and its vertex normals too: Softbody.js:273 runs geometry.computeVertexNormals() every frame (37 ms of the
+            // CPU path's frame); the device reproduces three.js's result bit for bit (tetsim_read_visual_vertex_normals)
+            this._visTris = visTriIds && visTriIds.length ? (visTriIds instanceof Int32Array ? visTriIds : Int32Array.from(visTriIds)) : null;
+            if (this._visTris) api.setVisualTriangles(this._h, this._visTris);
         }
         if (THREE) {
             let geometry = new THREE.BufferGeometry();
@@ -148,11 +152,21 @@ class SoftBodyHIP {
         const positions = this.visMesh.geometry.attributes.position.array;   // done by the device kernel
         this.readVisualPositions(positions);
         // Softbody.js:273 always recomputes the normals; SoftbodyGPU.js:687 only when physicsParams.computeNormals is set
-        if (this._solver !== 'polar' || this.physicsParams.computeNormals) this.visMesh.geometry.computeVertexNormals();
+        if (this._solver !== 'polar' || this.physicsParams.computeNormals) {
+            const normal = this.visMesh.geometry.attributes.normal;
+            if (this._visTris && normal) { this.readVisualVertexNormals(normal.array); normal.needsUpdate = true; }   // = computeVertexNormals()
+            else this.visMesh.geometry.computeVertexNormals();
+        }
         this.visMesh.geometry.attributes.position.needsUpdate = true;
         this.visMesh.geometry.computeBoundingSphere();
     }
 
+    readVisualVertexNormals(out) {                      // Float32Array [3*numVisVerts]: three.js computeVertexNormals on the GPU
+        out = out || new Float32Array(3 * this.numVisVerts);
+        if (!this._visTris) throw new Error('no visual triangles (visTriIds) were given');
+        this._api.readVisualVertexNormals(this._h, out);
+        return out;
+    }
     readVisualPositions(out) {                          // Float32Array [3*numVisVerts], skinned on the GPU
         out = out || new Float32Array(3 * this.numVisVerts);
         if (this._visOnDevice) this._api.readVisualMesh(this._h, out, null);

@@ -36,6 +36,8 @@ struct Api {
     decltype(&tetsim_get_local_tets) get_local_tets = nullptr;
     decltype(&tetsim_set_visual_mesh) set_visual_mesh = nullptr;
     decltype(&tetsim_read_visual_mesh) read_visual_mesh = nullptr;
+    decltype(&tetsim_set_visual_triangles) set_visual_triangles = nullptr;
+    decltype(&tetsim_read_visual_vertex_normals) read_visual_vertex_normals = nullptr;
     decltype(&tetsim_set_grab) set_grab = nullptr;
     decltype(&tetsim_start_grab) start_grab = nullptr;
     decltype(&tetsim_abi_version) abi_version = nullptr;
@@ -62,6 +64,7 @@ bool load_lib(const std::string& hint) {
     SYM(read_velocities, "tetsim_read_velocities") SYM(read_quats, "tetsim_read_quats") SYM(read_vol_error, "tetsim_read_vol_error")
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
+    SYM(set_visual_triangles, "tetsim_set_visual_triangles") SYM(read_visual_vertex_normals, "tetsim_read_visual_vertex_normals")
     SYM(abi_version, "tetsim_abi_version")
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
@@ -348,6 +351,26 @@ napi_value ReadVisualMesh(napi_env env, napi_callback_info info) {
     typed_array(env, a[2], napi_float32_array, &no, &nn);
     return check(env, g.read_visual_mesh(h, po, nn ? no : nullptr), h);
 }
+// setVisualTriangles(handle, Int32Array visTriIds)
+napi_value SetVisualTriangles(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    int32_t* tri; size_t n3;
+    if (!typed_array(env, a[1], napi_int32_array, &tri, &n3) || n3 % 3) return throw_err(env, "visTriIds must be an Int32Array of 3 ids per triangle");
+    return check(env, g.set_visual_triangles(h, tri, static_cast<uint32_t>(n3 / 3)), h);
+}
+// readVisualVertexNormals(handle, Float32Array normalsOut): geometry.computeVertexNormals() of the skinned mesh, on the device
+napi_value ReadVisualVertexNormals(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    float* no; size_t nn;
+    if (!typed_array(env, a[1], napi_float32_array, &no, &nn)) return throw_err(env, "normals output must be a Float32Array");
+    return check(env, g.read_visual_vertex_normals(h, no), h);
+}
 // setGrab(handle, id, x, y, z)
 napi_value SetGrab(napi_env env, napi_callback_info info) {
     napi_value a[5];
@@ -448,6 +471,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setVisualTriangles", nullptr, SetVisualTriangles, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readVisualVertexNormals", nullptr, ReadVisualVertexNormals, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"startGrab", nullptr, StartGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"info", nullptr, Info, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
