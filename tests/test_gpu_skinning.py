@@ -36,8 +36,7 @@ def test_vertex_normals_bit_exact_vs_threejs(golden):
     vis = load_f32("dragon_vis.f32").reshape(-1, 4)
     tris = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int32).reshape(-1, 3)
     assert len(tris) == 59657
-    body = SoftBodyHIP(v, t, None, dict(PP), vis, solver="neohookean", precision="precise")
-    body.setVisualTriangles(tris)
+    body = SoftBodyHIP(v, t, None, dict(PP), vis, tris, solver="neohookean", precision="precise")   # visTriIds as the reference's 6th argument
     dt = (1.0 * (1.0 / 60.0)) / 10
     for _ in range(10):
         body.simulate(dt, PP)

@@ -5,7 +5,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import load_f32, load_mesh
+from conftest import GOLDEN, load_f32, load_mesh
 from tetsim_amd import SoftBodyHIP, TetSimError, make_lattice
 from tetsim_amd.meshfile import MeshFile, greedy_colours, write_mesh
 
@@ -103,6 +103,15 @@ def test_create_from_file_equals_create_from_arrays(tmp_path):
         b.simulateSubsteps(30, dt, PP)
         assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32)), kw
         assert np.array_equal(a.visualPositions().view(np.uint32), b.visualPositions().view(np.uint32)), kw
+    # a container that also carries the visual triangle list gives the body its vertex normals (computeVertexNormals on the device)
+    tris = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int32).reshape(-1, 3)
+    path2, _, _, _ = _dragon(os.path.join(tmp_path, "."), vis_tri_ids=tris)
+    a = SoftBodyHIP(v, t, None, dict(PP), vis, tris, solver="neohookean", precision="precise")
+    b = SoftBodyHIP.fromFile(path2, dict(PP), solver="neohookean", precision="precise")
+    for body in (a, b):
+        body.simulateSubsteps(10, dt, PP)
+    assert np.array_equal(a.visualVertexNormals().view(np.uint32), b.visualVertexNormals().view(np.uint32))
+    assert np.array_equal(b.visualVertexNormals().view(np.uint32), load_f32("dragon_visnormal_10.f32").reshape(-1, 3).view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -66,6 +66,8 @@ class SoftBodyHIP:
                 vertices, tetIds = mf.verts.copy(), mf.tets.copy()
                 if visVerts is None and mf.vis_verts is not None and part_count <= 1:
                     visVerts = mf.vis_verts.copy()
+                    if visTriIds is None and mf.vis_tri_ids is not None:
+                        visTriIds = mf.vis_tri_ids.copy()
         self._verts = _f32(vertices).reshape(-1)
         self._tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
         if self._verts.size % 3 or self._tets.size % 4:
@@ -114,6 +116,8 @@ class SoftBodyHIP:
                 self.numVisVerts, self._has_normals = len(np.asarray(visVerts).reshape(-1)) // 4, False
             else:
                 self.setVisualMesh(visVerts)
+            if visTriIds is not None and len(visTriIds):   # Softbody.js:48-50: enables visualVertexNormals()
+                self.setVisualTriangles(visTriIds)
 
     @classmethod
     def fromFile(cls, path, physicsParams=None, visMaterial=None, world=None, **kw):
