@@ -336,7 +336,7 @@ def run(args, rank, world, local_rank, ranks):
             "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
                                    "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
                        "solver": "polar_jacobi", "arithmetic": args.precision,
-                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (carried world-space rest shape)", "substeps_per_step": SUBSTEPS,
+                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
         }
