@@ -26,7 +26,7 @@ int main() {
         hipExtMallocWithFlags(reinterpret_cast<void**>(&w2), 8, hipMallocSignalMemory) != hipSuccess) { printf("signal memory alloc failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
     hipMemset(w, 0, 8); hipMemset(w2, 0, 8);
     int* d; hipMalloc(&d, 4); hipMemset(d, 0, 4);
-    const int hops = 200; const long long cyc = 200;  // 2 us of "work" per kernel (100 MHz wall clock)
+    const int hops = 200; const long long cyc = 2000;  // 20 us of "work" per kernel (100 MHz wall clock): the host runs ahead, the hand-overs' DEVICE cost shows
     uint32_t seq = 0;
     auto run = [&](int mode) {   // 0: kernels, 1: value ops, 2: no hand-over at all (two independent streams, lower bound)
         for (int i = 0; i < hops; i++) {
