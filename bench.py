@@ -202,6 +202,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="fast", choices=["fast", "precise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver", default="polar", choices=["polar", "neohookean"],
+                    help="polar (default: the headline, BASELINE configs 3/5) or neohookean (config 4: coloured Gauss-Seidel on the same "
+                         "lattice; single GPU only -- it does not partition)")
+    ap.add_argument("--order", default="clustered", choices=["coloured", "clustered"], help="--solver neohookean: Gauss-Seidel schedule")
     ap.add_argument("--constant-rest-shape", action="store_true",
                     help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
     ap.add_argument("--cells", type=int, default=CELLS, help="lattice cells per side (default 55 = the 1 M-tet headline; 110 = 8 M tets)")
@@ -273,6 +277,58 @@ def main():
     faulthandler.cancel_dump_traceback_later()
 
 
+def run_neohookean(args, verts, tets, device):
+    """BASELINE config 4 on request (`--solver neohookean`): Neo-Hookean XPBD Gauss-Seidel (Softbody.js's algorithm, coloured or
+    clustered schedule) on the same lattice and metric.  PRECISE reproduces Softbody.js bit for bit on the permuted tet order."""
+    from tetsim_amd import SoftBodyHIP
+    body = SoftBodyHIP(verts, tets, None, dict(PP), solver="neohookean", precision=args.precision, order=args.order, device=device)
+    for _ in range(args.warmup):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    elapsed = time.perf_counter() - t0
+    if not np.isfinite(body.pos).all():
+        raise SystemExit("non-finite positions after the timed region")
+    value = len(tets) * SUBSTEPS * args.steps / elapsed / 1e6
+    b_alg = 56.0 + 124.0 * len(verts) / len(tets)   # SURVEY.md 8(d): idx 16 + invRestPose 36 + invRestVolume 4; 124 B per particle
+    agg = b_alg * value * 1e6 / 1e9
+    pr = body.profile(SUBSTEPS * 3, DT, PP)
+    out = {
+        "metric": "tet_solves_per_sec", "value": round(value, 1), "unit": "M tet-solves/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if args.precision == "precise" else "f32", "data": "synthetic",
+        "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), Neo-Hookean XPBD Gauss-Seidel (%s schedule, "
+                               "%d launches per substep), %d substeps/frame, dt=1/1200 s" % (args.cells, args.cells, args.cells, len(tets), len(verts), args.order,
+                                                                                           body.info.num_levels, SUBSTEPS),
+                   "solver": "neohookean_gs", "arithmetic": args.precision, "order": args.order, "substeps_per_step": SUBSTEPS,
+                   "tets": len(tets), "particles": len(verts), "parallelism": "single GPU"},
+        # the bound of this solver is its dependency chain (launches x (launch + round trips) + sequential tet solves, DESIGN.md 4);
+        # the HBM figure is reported because the contract asks for one
+        "roofline": {"bound": "hbm", "kernel": "whole substep (Gauss-Seidel sweep + particle pass)", "achieved": round(agg, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(agg / HBM_PEAK_GBS, 4), "traffic": None,
+                     "sweep_us_per_substep": round(pr["tet_ms"] / pr["substeps"] * 1e3, 2),
+                     "particle_us_per_substep": round(pr["vertex_ms"] / pr["substeps"] * 1e3, 2),
+                     "substep_alg_bytes_per_tet": round(b_alg, 1)},
+    }
+    if not args.no_cpu_baseline:
+        body.close()
+        from oracle import OracleNH
+        nh = OracleNH(verts, tets, PP)
+        nh.simulate(DT, PP)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 10.0:
+            nh.simulate(DT, PP)
+            n += 1
+        out["cpu_baseline"] = {"value": round(n * len(tets) / (time.perf_counter() - t0) / 1e6, 3), "unit": "M tet-solves/s", "cores": 1,
+                               "kind": "port", "sample": "%d substeps of the same lattice, sequential Gauss-Seidel in the caller's tet order "
+                                                         "(oracle/tetsim_oracle.c section A: Softbody.js's algorithm, bit-exact with its goldens)" % n}
+    return out, body
+
+
 def run(args, rank, world, local_rank, ranks):
     """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
     barrier / max_float."""
@@ -294,6 +350,10 @@ def run(args, rank, world, local_rank, ranks):
         zext = 0.5 * (nz / cells) + 2.0
         PP["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
         kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
+    if args.solver == "neohookean":
+        if world > 1:
+            raise SystemExit("--solver neohookean is a single-GPU benchmark: Gauss-Seidel would need one halo per colour (replicas only)")
+        return run_neohookean(args, verts, tets, local_rank)
     if args.constant_rest_shape:
         kw["constant_rest_shape"] = True
     body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,

@@ -35,6 +35,13 @@ def test_single_gpu_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
+def test_neohookean_line_on_request():
+    """`--solver neohookean` (BASELINE config 4): same metric and JSON shape, never the default."""
+    d = _run(["--solver", "neohookean", "--order", "clustered", "--cells", "10", "--steps", "3", "--warmup", "1", "--precision", "precise", "--no-cpu-baseline"])
+    assert REQUIRED <= set(d) and d["config"]["solver"] == "neohookean_gs" and d["dtype"] == "f64" and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["substep_alg_bytes_per_tet"] > 56
+
+
 @pytest.mark.parametrize("extra", [[], ["--profile-ranks"], ["--scaling", "strong"]])
 def test_multi_rank_code_path_with_thread_ranks(extra):
     here = os.path.join(ROOT, "tests", "mock_rccl")
