@@ -124,6 +124,45 @@ if (process.env.TETSIM_TEST_MESH) {
     console.log('visual mesh: 29,800 vertex normals over 59,657 triangles bit-exact vs three.js computeVertexNormals');
     body6.dispose();
 }
+// 4d. the display objects main.js:67-68 adds to the scene (SURVEY.md 8(b)): built when three.js is injected.  three.js itself cannot
+//     travel to the GPU box, so a stand-in with the handful of members SoftBodyHIP.js touches is injected here; it counts what a
+//     renderer would need to see (needsUpdate flags, bounding spheres) and keeps its own computeVertexNormals OUT of the way.
+{
+    const calls = { computeVertexNormals: 0, computeBoundingSphere: 0 };
+    class BufferAttribute { constructor(array, itemSize) { this.array = array; this.itemSize = itemSize; this.needsUpdate = false; } }
+    class BufferGeometry {
+        constructor() { this.attributes = {}; this.index = null; }
+        setAttribute(name, a) { this.attributes[name] = a; return this; }
+        setIndex(ids) { this.index = ids; return this; }
+        computeVertexNormals() { calls.computeVertexNormals++; if (!this.attributes.normal) this.attributes.normal = new BufferAttribute(new Float32Array(this.attributes.position.array.length), 3); }
+        computeBoundingSphere() { calls.computeBoundingSphere++; }
+    }
+    class Layers { constructor() { this.mask = 1; } enable(l) { this.mask |= 1 << l; } }
+    class Object3D { constructor(geometry, material) { this.geometry = geometry; this.material = material; this.layers = new Layers(); this.userData = {}; this.visible = true; } }
+    const THREE = { BufferAttribute, BufferGeometry, LineSegments: Object3D, Mesh: Object3D };
+    const b = fs.readFileSync(path.join(G, 'dragon_vistris.u16'));
+    const tris = Array.from(new Uint16Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)));   // a plain Array, as Dragon.js has it
+    const caller = verts.slice(0);
+    const p7 = Object.assign({}, pp, { numSubsteps: 10, tetsim: { solver: 'neohookean', precision: 'precise' } });
+    const material = { name: 'visMaterial' };
+    const body7 = new SoftBodyHIP(caller, tets, [0, 1, 1, 2], p7, f32('dragon_vis.f32'), tris, material, { THREE });
+    assert.ok(body7.edgeMesh && body7.visMesh, 'display objects missing');
+    assert.strictEqual(body7.edgeMesh.userData, body7); assert.strictEqual(body7.visMesh.userData, body7);      // for the grabber's raycast
+    assert.strictEqual(body7.edgeMesh.layers.mask & 2, 2); assert.strictEqual(body7.visMesh.layers.mask & 2, 2); // layer 1 (Softbody.js:40,54)
+    assert.strictEqual(body7.visMesh.material, material); assert.strictEqual(body7.visMesh.castShadow, true);
+    assert.strictEqual(body7.edgeMesh.geometry.attributes.position.array, caller, 'the edge mesh aliases the caller\'s vertices (Softbody.js:37)');
+    const cvn = calls.computeVertexNormals;
+    for (let step = 1; step <= 10; step++) body7.simulate(dt, p7);
+    body7.endFrame();
+    assert.strictEqual(bitsEqual(caller, f32('dragon_pos_10.f32')), -1, 'edge mesh / caller vertices after endFrame (Softbody.js:252)');
+    assert.strictEqual(bitsEqual(body7.visMesh.geometry.attributes.position.array, f32('dragon_vispos_10.f32')), -1);
+    assert.strictEqual(bitsEqual(body7.visMesh.geometry.attributes.normal.array, f32('dragon_visnormal_10.f32')), -1, 'normal attribute after endFrame');
+    assert.strictEqual(calls.computeVertexNormals, cvn, 'the per-frame computeVertexNormals must come from the device');
+    assert.ok(body7.visMesh.geometry.attributes.position.needsUpdate && body7.visMesh.geometry.attributes.normal.needsUpdate && body7.edgeMesh.geometry.attributes.position.needsUpdate);
+    assert.ok(calls.computeBoundingSphere >= 2);
+    console.log('display objects: edgeMesh/visMesh with userData + layer 1, positions and normals refreshed by endFrame() from the device');
+    body7.dispose();
+}
 // 5. partitioned bodies and the RCCL communicator from Node (one rank here: the entry points and the bookkeeping)
 {
     const nv = verts.length / 3;
