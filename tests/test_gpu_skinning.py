@@ -57,6 +57,39 @@ def test_vertex_normals_bit_exact_vs_threejs(golden):
         other.setVisualTriangles(np.array([[0, 1, 8]], np.int32))        # id outside the visual mesh
 
 
+def _threejs_vertex_normals(pos, tri):
+    """BufferGeometry.computeVertexNormals + normalizeNormals of three.js r160, restated (pinned against the reference's own
+    output by tests/test_oracle_golden.py::test_vertex_normals_golden_is_threejs_computeVertexNormals)."""
+    P = pos.astype(np.float64)
+    cb, ab = P[tri[:, 2]] - P[tri[:, 1]], P[tri[:, 0]] - P[tri[:, 1]]
+    face = np.stack([cb[:, 1] * ab[:, 2] - cb[:, 2] * ab[:, 1], cb[:, 2] * ab[:, 0] - cb[:, 0] * ab[:, 2],
+                     cb[:, 0] * ab[:, 1] - cb[:, 1] * ab[:, 0]], axis=1)
+    n = np.zeros_like(pos)
+    for t in range(len(tri)):
+        for v in tri[t]:
+            n[v] = (n[v].astype(np.float64) + face[t]).astype(np.float32)
+    N = n.astype(np.float64)
+    length = np.sqrt(N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1] + N[:, 2] * N[:, 2])
+    length[length == 0] = 1.0
+    return (N * (1.0 / length)[:, None]).astype(np.float32)
+
+
+def test_vertex_normals_on_the_polar_path():
+    """SoftbodyGPU.js:687 (`physicsParams.computeNormals`): the same device routine on the polar solver's skinned positions
+    (internally renumbered particles, FAST), bit-identical to three.js's algorithm applied to those positions."""
+    import os
+    from conftest import GOLDEN
+    v, t = load_mesh("dragon")
+    vis = load_f32("dragon_vis.f32").reshape(-1, 4)
+    tris = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int32).reshape(-1, 3)
+    body = SoftBodyHIP(v, t, None, dict(PP), vis, tris, solver="polar", precision="fast")
+    body.simulateSubsteps(40, (1.0 / 60.0) / 20, PP)
+    pos = body.visualPositions()
+    got = body.visualVertexNormals()
+    ref = _threejs_vertex_normals(pos, tris.astype(np.int64))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("precision", ["precise", "fast"])
 def test_polar_skinning_and_normals(precision):
     """Vertex-shader formula of SoftbodyGPU.js:429-440 evaluated on the device: positions from the (internally
