@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TETSIM_ABI_VERSION 2
+#define TETSIM_ABI_VERSION 3
 
 typedef struct tetsim_body *tetsim_handle;
 
@@ -195,11 +195,25 @@ int tetsim_read_velocities(tetsim_handle h, float *out);     /* .vel */
 /* POLAR_JACOBI: per-tet rotation quaternion xyzw (textureQuat, SoftbodyGPU.js:55,181), [4*local_elems]
  * in tetsim_get_local_tets order. */
 int tetsim_read_quats(tetsim_handle h, float *out);
+/* Zero-copy variant of tetsim_read_quats (SURVEY.md §8(f)-2 "position/quaternion"; the normal path of SoftbodyGPU.js:440
+ * consumes textureQuat every frame): one DMA straight into a pinned host buffer owned by the handle ([4*local_elems]
+ * floats in tetsim_get_local_tets order, valid until tetsim_destroy, overwritten by the next call).  Synchronises. */
+int tetsim_read_quats_pinned(tetsim_handle h, const float **out);
 /* NEOHOOKEAN_GS: `.volError` of the last substep (Softbody.js:163,206,209), summed in the caller's
  * tet order in f64. */
 int tetsim_read_vol_error(tetsim_handle h, double *out);
-/* Overwrite positions and velocities of the owned particles (checkpoint restore). */
+/* Overwrite positions and velocities of the owned particles.  NEOHOOKEAN_GS: that is the whole solver state.
+ * POLAR_JACOBI also carries per-tet state (quaternions and the rotated rest shape, SoftbodyGPU.js:49-55 `elems`/`quats`),
+ * which this call leaves untouched: to continue a trajectory use tetsim_save_state / tetsim_load_state. */
 int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
+/* Checkpoint / resume of the COMPLETE solver state of an unpartitioned body (both solvers): positions, velocities and, for
+ * POLAR_JACOBI, every tet's quaternion and carried rest shape -- everything the reference keeps in its ping-pong render
+ * targets (SoftbodyGPU.js:49-55).  The blob is only meaningful for a body created from the same mesh with the same options by
+ * the same library build family (it starts with a header that tetsim_load_state validates: magic, ABI, solver, precision,
+ * flags, counts).  A body restored from a blob continues the original trajectory bit for bit.  Both calls synchronise. */
+int tetsim_state_size(tetsim_handle h, uint64_t *bytes_out);
+int tetsim_save_state(tetsim_handle h, void *blob, uint64_t bytes);
+int tetsim_load_state(tetsim_handle h, const void *blob, uint64_t bytes);
 
 /* global vertex id of each owned particle, [owned_particles] (identity when unpartitioned) */
 int tetsim_get_owned_ids(tetsim_handle h, int32_t *out);
@@ -345,6 +359,21 @@ int tetsim_plan_neighbour(tetsim_plan p, uint32_t i, int32_t *rank, uint32_t *se
 int tetsim_plan_neighbour_ids(tetsim_plan p, uint32_t i, int32_t *send_local, int32_t *send_global, int32_t *recv_global);
 
 int tetsim_abi_version(void);
+/* What exactly is loaded.  source_sha: first 16 hex digits of the SHA-256 over the library's sources (csrc/, include/) and
+ * build flags, stamped by tetsim_amd/build.py; kernel_sha: the same over the files that determine the polar tet kernel and
+ * its tiling (what profiles/pmc_traffic.json is keyed by); ablation != 0: the development build (-DTETSIM_ABLATION) whose
+ * tet kernel obeys TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL -- never the product; debug_env: bit i set = the i-th of
+ * {TETSIM_DEBUG_LOOPBACK_HALO, TETSIM_DEBUG_LOOPBACK_COPY, TETSIM_DEBUG_ONE_STREAM, TETSIM_DEBUG_GROUP_SYNC,
+ * TETSIM_DEBUG_HOSTPROF, TETSIM_DEBUG_TRACE, TETSIM_HALO_SYNC, TETSIM_HALO_GRAPH} is set in the environment.  bench.py
+ * records all of it in its JSON line. */
+typedef struct TetSimLibraryInfo {
+    int32_t abi;
+    int32_t ablation;
+    uint32_t debug_env;
+    char source_sha[20];
+    char kernel_sha[20];
+} TetSimLibraryInfo;
+int tetsim_library_info(TetSimLibraryInfo *out);
 
 /* --- .tetsim mesh container (GPU-free except tetsim_create_from_file) ---------------------------
  * The five arrays of the reference's Dragon.js (:1 verts, :311 tetIds, :1080 tetEdgeIds, :1705 attachedVerts

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Builds the headless Mesa/llvmpipe GL binding used ONLY to generate the polar-solver golden vectors
+# Builds the headless Mesa (swrast_dri.so; the goldens are recorded with its softpipe driver) GL binding used ONLY to generate the polar-solver golden vectors
 # (tests/golden/make_golden_gpu.sh).  Output goes to oracle/_ref/ (git-ignored).
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"

@@ -1,6 +1,6 @@
 // mesa_gl.cc -- TEST INFRASTRUCTURE (golden-vector generation only; never loaded by the product or by any test).
 //
-// A minimal headless OpenGL ES 3.0 binding for Node (N-API) on top of Mesa's software rasteriser (llvmpipe), so that
+// A minimal headless OpenGL ES 3.0 binding for Node (N-API) on top of Mesa's software rasteriser (swrast_dri.so: softpipe is what the goldens are recorded with; llvmpipe was rejected, see tests/golden/make_golden_gpu.sh), so that
 // the REFERENCE's own GLSL passes (SoftbodyGPU.js:59-376) and its own pass scheduler
 // (MultiTargetGPUComputationRenderer.js) can be executed in the build container, which has no GPU, no X server and
 // no EGL: the context is created straight through the DRI software-rasteriser interface that libGLX/libEGL use

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Golden vectors for the POLAR (WebGL) solver: runs the REFERENCE's own SoftbodyGPU.js +
-# MultiTargetGPUComputationRenderer.js + vendored three.js under Node, with GL executed by Mesa llvmpipe
+# MultiTargetGPUComputationRenderer.js + vendored three.js under Node, with GL executed by Mesa softpipe (swrast_dri.so, GALLIUM_DRIVER=softpipe)
 # (oracle/glsl_ref).  BUILD container only: needs /root/reference, node and Mesa's swrast_dri.so.
 # Reference files are copied to a scratch directory (never into the repo); only DATA is written here.
 set -euo pipefail

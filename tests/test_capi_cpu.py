@@ -23,7 +23,23 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.tetsim_abi_version() == 2
+    assert L.tetsim_abi_version() == 3
+
+
+def test_library_info_matches_the_tree():
+    """The loaded library says which sources it was built from; the product build is never the ablation build."""
+    from tetsim_amd.build import source_shas
+    info = capi.library_info()
+    assert info["abi"] == 3 and info["ablation"] is False
+    assert (info["source_sha"], info["kernel_sha"]) == source_shas(), "libtetsim_hip.so is stale: run python -m tetsim_amd.build"
+    assert re.fullmatch(r"[0-9a-f]{16}", info["source_sha"]) and re.fullmatch(r"[0-9a-f]{16}", info["kernel_sha"])
+
+
+def test_product_kernel_has_no_ablation_knobs():
+    """TETSIM_DEBUG_ITERS & co. exist only in the -DTETSIM_ABLATION build: the product binary does not even contain the names."""
+    blob = open(capi.LIB_PATH, "rb").read()
+    for name in (b"TETSIM_DEBUG_ITERS", b"TETSIM_DEBUG_SKIP_REST_STORE", b"TETSIM_DEBUG_NO_PEEL"):
+        assert name not in blob, name
 
 
 def test_no_cpu_fallback():

@@ -49,6 +49,15 @@ class TetSimProfile(C.Structure):
                 ("substeps", C.c_uint32), ("tets_per_tet_launch", C.c_uint32)]
 
 
+class TetSimLibraryInfo(C.Structure):
+    _fields_ = [("abi", C.c_int32), ("ablation", C.c_int32), ("debug_env", C.c_uint32), ("source_sha", C.c_char * 20),
+                ("kernel_sha", C.c_char * 20)]
+
+
+DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "TETSIM_DEBUG_ONE_STREAM", "TETSIM_DEBUG_GROUP_SYNC",
+                   "TETSIM_DEBUG_HOSTPROF", "TETSIM_DEBUG_TRACE", "TETSIM_HALO_SYNC", "TETSIM_HALO_GRAPH"]
+
+
 class TetSimPlanSizes(C.Structure):
     _fields_ = [("owned_particles", C.c_uint32), ("boundary_particles", C.c_uint32), ("local_particles", C.c_uint32),
                 ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32), ("num_neighbours", C.c_uint32)]
@@ -64,6 +73,7 @@ class TetSimError(RuntimeError):
 SYMBOLS = [
     "tetsim_abi_version", "tetsim_default_options", "tetsim_default_params", "tetsim_create", "tetsim_destroy",
     "tetsim_last_error", "tetsim_get_info", "tetsim_step", "tetsim_step_n", "tetsim_sync",
+    "tetsim_library_info", "tetsim_read_quats_pinned", "tetsim_state_size", "tetsim_save_state", "tetsim_load_state",
     "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
@@ -115,6 +125,11 @@ def lib():
     for n in ("positions", "prev_positions", "velocities", "quats", "inv_mass"):
         getattr(L, "tetsim_read_" + n).argtypes = [H, fp]
     L.tetsim_read_positions_pinned.argtypes = [H, C.POINTER(fp)]
+    L.tetsim_read_quats_pinned.argtypes = [H, C.POINTER(fp)]
+    L.tetsim_library_info.argtypes = [C.POINTER(TetSimLibraryInfo)]
+    L.tetsim_state_size.argtypes = [H, C.POINTER(C.c_uint64)]
+    L.tetsim_save_state.argtypes = [H, C.c_void_p, C.c_uint64]
+    L.tetsim_load_state.argtypes = [H, C.c_void_p, C.c_uint64]
     L.tetsim_read_vol_error.argtypes = [H, dp]
     L.tetsim_write_state.argtypes = [H, fp, fp]
     for n in ("owned_ids", "local_tets", "tet_order", "level_offsets"):
@@ -157,6 +172,14 @@ def lib():
             f.restype = C.c_int
     _lib = L
     return L
+
+
+def library_info():
+    """{"abi", "ablation", "source_sha", "kernel_sha", "debug_env": [names set]} of the loaded libtetsim_hip.so."""
+    li = TetSimLibraryInfo()
+    check(lib().tetsim_library_info(C.byref(li)))
+    return {"abi": li.abi, "ablation": bool(li.ablation), "source_sha": li.source_sha.decode(), "kernel_sha": li.kernel_sha.decode(),
+            "debug_env": [n for i, n in enumerate(DEBUG_ENV_NAMES) if li.debug_env >> i & 1], "path": LIB_PATH}
 
 
 def check(rc, handle=None):

@@ -1,10 +1,15 @@
 """Builds libtetsim_hip.so (gfx950) in-tree with hipcc.  No GPU needed: hipcc cross-compiles.
 
-    python -m tetsim_amd.build [--force]
+    python -m tetsim_amd.build [--force] [--ablation]
 
 Per-file flags matter: the PRECISE translation units and the host preprocessing reproduce the reference's
 rounding and must not fuse multiply-add (-ffp-contract=off); the FAST units are built with contraction on.
+
+--ablation additionally builds libtetsim_hip_ablation.so: the same sources with -DTETSIM_ABLATION, whose polar tet kernel
+takes the timing-ablation knobs (TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL) and the per-tile trace.  Development
+only (tools/ab_iters.py, tools/trace_tet.py); the product library has none of that code.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -12,8 +17,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libtetsim_hip.so")
+LIB_ABLATION = os.path.join(HERE, "libtetsim_hip_ablation.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -36,43 +41,84 @@ UNITS = {
     "nh_fast.hip": ["-ffp-contract=fast"],
     "util_kernels.hip": ["-ffp-contract=off"],
     "skin_kernels.hip": ["-ffp-contract=off"],
+    "build_info.cpp": ["-x", "hip"],
 }
 HEADERS = ["body.h", "dev_common.h", "dev_store.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
+# what determines the polar tet kernel (pjb_tet_kernel), its tiling and therefore its HBM traffic: profiles/pmc_traffic.json
+# is keyed by the hash of these (+ their flags), so a stale counter figure is never attached to a different kernel
+KERNEL_FILES = ["pj_blocked.hip", "pj_math.inc", "dev_common.h", "dev_store.h", "host_prep.cpp", "host_prep.h"]
+
+
+def _sha(files, extra):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(repr(extra).encode())
+    return h.hexdigest()[:16]
+
+
+def source_shas():
+    """(source_sha, kernel_sha) of the tree as it is now -- what a library built now would report."""
+    every = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".inc")) and f != "build_info.cpp") + \
+        [os.path.join("..", "..", "include", "tetsim.h")]
+    flags = (COMMON, sorted(UNITS.items()))
+    return _sha(every, flags), _sha(KERNEL_FILES, (COMMON, UNITS["pj_blocked.hip"], UNITS["host_prep.cpp"]))
 
 
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def _compile(unit, flags, force):
+def _compile(unit, flags, force, objdir, extra):
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(OBJ, os.path.splitext(unit)[0] + ".o")
+    obj = os.path.join(objdir, os.path.splitext(unit)[0] + ".o")
     deps = [src] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= _newest(deps):
+    stamp = obj + ".flags"
+    want = " ".join(flags + extra)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == want
+    if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= _newest(deps):
         return obj, False
-    cmd = [HIPCC] + COMMON + flags + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + COMMON + flags + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (unit, " ".join(cmd), r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
     return obj, True
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def _build_one(lib, objdir, defines, force, verbose):
+    os.makedirs(objdir, exist_ok=True)
+    src_sha, ker_sha = source_shas()
+    info = ['-DTETSIM_SOURCE_SHA="%s"' % src_sha, '-DTETSIM_KERNEL_SHA="%s"' % ker_sha]
+
+    def one(kv):
+        unit, flags = kv
+        return _compile(unit, flags, force, objdir, defines + (info if unit == "build_info.cpp" else []))
+
     with ThreadPoolExecutor(max_workers=min(12, len(UNITS))) as ex:
-        results = list(ex.map(lambda kv: _compile(kv[0], kv[1], force), UNITS.items()))
+        results = list(ex.map(one, UNITS.items()))
     objs = [o for o, _ in results]
-    if force or any(c for _, c in results) or not os.path.exists(LIB):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs + ["-ldl"]
+    if force or any(c for _, c in results) or not os.path.exists(lib):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
         if verbose:
-            print("linked", LIB)
-    return LIB
+            print("linked", lib)
+    return lib
+
+
+def build(force=False, verbose=False, ablation=False):
+    lib = _build_one(LIB, os.path.join(CSRC, "obj"), [], force, verbose)
+    if ablation:
+        _build_one(LIB_ABLATION, os.path.join(CSRC, "obj_ablation"), ["-DTETSIM_ABLATION"], force, verbose)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

@@ -143,6 +143,7 @@ struct tetsim_body {
     SkinDev skin;  // embedded visual mesh
     float* pinned_pos = nullptr;   // tetsim_read_positions_pinned: host-pinned xyz
     float* d_packed = nullptr;     //   and its device-side staging
+    float* pinned_quat = nullptr;  // tetsim_read_quats_pinned: host-pinned xyzw per local tet
     uint32_t* d_api2dev = nullptr; // device copy of api2dev (pack / nearest kernels), null = identity
     double* d_best = nullptr; uint32_t* d_best_id = nullptr;  // tetsim_start_grab candidates
 

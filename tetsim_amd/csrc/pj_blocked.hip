@@ -53,12 +53,27 @@ constexpr uint32_t kTile = 256;
 
 // LDS per workgroup is kept at 19 KB (4 + 12 + 1 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
-// `dbg` is a development knob for timing ablations (bits 0-3: rotation iterations, bit 4: skip the rest-shape
-// write-back); the product always passes 9 / 0 -- anything else produces wrong physics.
+// Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
+// exist only in the separate development build (-DTETSIM_ABLATION -> libtetsim_hip_ablation.so, tools/ab_iters.py): there the
+// kernel takes a run-time `dbg` word (bits 0-3: iterations, bit 4: skip the write-back, bit 6: no peel).  The product kernel
+// has no such argument: 9 iterations, peeled, every store -- compile-time constants.
+#ifdef TETSIM_ABLATION
+#define TETSIM_DBG_PARAM , uint32_t dbg
+#define TETSIM_DBG_ARG , dbg
+#define TETSIM_DBG_ITERS static_cast<int>(dbg & 15u)
+#define TETSIM_DBG_PEEL (!(dbg & 64u))
+#define TETSIM_DBG_STORE_REST (!(dbg & 16u))
+#else
+#define TETSIM_DBG_PARAM
+#define TETSIM_DBG_ARG
+#define TETSIM_DBG_ITERS 9
+#define TETSIM_DBG_PEEL true
+#define TETSIM_DBG_STORE_REST true
+#endif
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 template <bool kLean>
-__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t dbg) {
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -70,9 +85,13 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
+#ifdef TETSIM_ABLATION  // per-tile phase timestamps (TETSIM_DEBUG_TRACE): development build only
 #define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    TETSIM_STAMP(0);
     if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+#else
+#define TETSIM_STAMP(i) do { } while (0)
+#endif
+    TETSIM_STAMP(0);
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
 
@@ -114,7 +133,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         // world-space goal is goal + cc.  Same bytes as the reference's world-space shape, 21 instructions fewer per tet
         // (no rest centroid, no subtraction), and without the add-then-subtract of a position-sized number every substep.
         f3 cc;
-        pj_solve_tet(cur, rest, q_old, q_new, goal, static_cast<int>(dbg & 15u), !(dbg & 64u), kLean, !kLean, &cc);
+        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc);
         TETSIM_STAMP(3);  // solved
         // LDS staging first, global results after it: nothing below may have to wait for the write-through stores
         const f3 vcc = cc * V;
@@ -126,7 +145,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         }
         s_v[tid] = V;
         store_wt(d.quat, e, q_new);
-        if (!kLean && !(dbg & 16u)) {  // constant-rest-shape bodies never write the shape back
+        if (!kLean && TETSIM_DBG_STORE_REST) {  // constant-rest-shape bodies never write the shape back
             store_wt(d.rest_a, e, make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
             store_wt(d.rest_b, e, make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
             store_wt(d.rest_c, e, make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
@@ -172,12 +191,12 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 }
 
 __global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                        uint32_t tiles_per_xcd, uint32_t dbg) {
-    pjb_tet_body<false>(d, tile_first, tile_count, tiles_per_xcd, dbg);
+                                                        uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 __global__ __launch_bounds__(256, 2) void pjb_tet_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                                      uint32_t tiles_per_xcd, uint32_t dbg) {
-    pjb_tet_body<true>(d, tile_first, tile_count, tiles_per_xcd, dbg);
+                                                                      uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 
 // ---- cross-queue hand-over of partitioned bodies ----------------------------------------------------------
@@ -271,25 +290,28 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 
 }  // namespace
 
-static uint32_t tet_mode(const PJBlk& d) {
+#ifdef TETSIM_ABLATION
+static uint32_t tet_mode() {
     static int dbg = -1;
-    if (dbg < 0) {  // timing ablations only (see kernel comment); unset => 9 iterations, all stores
+    if (dbg < 0) {  // timing ablations (see the kernel comment); unset => 9 iterations, peeled, all stores
         const char* it = getenv("TETSIM_DEBUG_ITERS");
         const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
         const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
         dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((np && np[0] == '1') ? 64 : 0);
-        if ((dbg & 15) != 9 || (dbg & 16))  // these two change the physics: never silently
-            fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_ITERS / TETSIM_DEBUG_SKIP_REST_STORE are set: timing ablation, the results are NOT the solver's\n");
+        fprintf(stderr, "[tetsim] WARNING: ABLATION build of libtetsim_hip (mode 0x%x): timing experiments only, the results are NOT the solver's\n", dbg);
     }
     return static_cast<uint32_t>(dbg);
 }
+#define TETSIM_DBG_LAUNCH , tet_mode()
+#else
+#define TETSIM_DBG_LAUNCH
+#endif
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
     if (tile_count == 0) return;
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    const uint32_t mode = tet_mode(d);
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, mode);
-    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd, mode);
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }

@@ -79,6 +79,7 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
 int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
+    HIPCHK(h, hipSetDevice(h->opt.device));  // group stepping walks over handles that may live on different devices
     const int slot = h->ring_pos;
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
@@ -200,6 +201,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
 
 int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out) {
     if (!out) return fail(h, TETSIM_EINVAL, "output pointer is null");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     std::vector<float4> tmp(n);
@@ -348,6 +350,7 @@ void tetsim_destroy(tetsim_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->pinned_pos) (void)hipHostFree(h->pinned_pos);
+    if (h->pinned_quat) (void)hipHostFree(h->pinned_quat);
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
@@ -418,6 +421,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
 
 int tetsim_sync(tetsim_handle h) {
     if (!h) return TETSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted
@@ -475,13 +479,131 @@ int tetsim_read_velocities(tetsim_handle h, float* out) {
 int tetsim_read_quats(tetsim_handle h, float* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "quaternions exist only for POLAR_JACOBI");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     if (h->pj.nt) HIPCHK(h, hipMemcpy(out, h->pj.quat, h->pj.nt * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
 }
+int tetsim_read_quats_pinned(tetsim_handle h, const float** out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "quaternions exist only for POLAR_JACOBI");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const size_t n = h->pj.nt;
+    if (!h->pinned_quat) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned_quat), std::max<size_t>(n, 1) * sizeof(float4), hipHostMallocDefault));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));  // ghost tiles write their quaternions on the halo stream
+    if (n) HIPCHK(h, hipMemcpyAsync(h->pinned_quat, h->pj.quat, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = h->pinned_quat;
+    return 0;
+}
+
+// ---- checkpoint / resume: the complete solver state as one blob (device order: only this library reads it back) -----------
+namespace {
+struct StateHeader {
+    uint32_t magic, abi, solver, precision, flags, blocked, order;
+    uint32_t nv, nt, pred_any_dt;
+    float dt_pred;
+    uint32_t reserved;
+    uint64_t payload;
+};
+constexpr uint32_t kStateMagic = 0x54535354u;  // "TSST"
+struct StateSection { void* ptr; size_t bytes; };
+void state_sections(tetsim_body* h, std::vector<StateSection>& v) {
+    if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
+        const size_t nvl = h->pj.nv_local, nt = h->pj.nt;
+        v.push_back({h->pj.pos_final, nvl * sizeof(float4)});
+        v.push_back({h->pj.vel, nvl * sizeof(float4)});
+        v.push_back({h->pj.pos_pred, nvl * sizeof(float4)});
+        v.push_back({h->pj.quat, nt * sizeof(float4)});
+        if (h->blocked) {
+            if (!h->blk.lean) {  // constant-rest-shape bodies carry no shape state
+                v.push_back({h->blk.rest_a, nt * sizeof(float4)});
+                v.push_back({h->blk.rest_b, nt * sizeof(float4)});
+                v.push_back({h->blk.rest_c, nt * sizeof(float4)});
+            }
+        } else v.push_back({h->pj.elem, 4ull * h->pj.nt_pad * sizeof(float4)});
+    } else {
+        const size_t nv = h->nh.nv;
+        v.push_back({h->nh.pos, nv * sizeof(float4)});
+        v.push_back({h->nh.prev, nv * sizeof(float4)});
+        v.push_back({h->nh.vel, nv * sizeof(float4)});
+        v.push_back({h->nh.vol_err, h->nh.nt * sizeof(double)});
+    }
+}
+StateHeader state_header(tetsim_body* h) {
+    StateHeader hd{};
+    hd.magic = kStateMagic; hd.abi = TETSIM_ABI_VERSION;
+    hd.solver = static_cast<uint32_t>(h->opt.solver); hd.precision = static_cast<uint32_t>(h->opt.precision);
+    hd.flags = h->opt.flags; hd.blocked = h->blocked ? 1u : 0u; hd.order = static_cast<uint32_t>(h->opt.order);
+    hd.nv = h->info.num_particles; hd.nt = h->info.num_elems;
+    hd.pred_any_dt = h->pred_any_dt ? 1u : 0u; hd.dt_pred = h->dt_pred;
+    std::vector<StateSection> secs;
+    state_sections(h, secs);
+    for (const StateSection& sec : secs) hd.payload += sec.bytes;
+    return hd;
+}
+int state_guard(tetsim_body* h) {
+    if (h->partitioned && h->opt.part_count > 1) return fail(h, TETSIM_ESTATE, "save/load_state is supported on unpartitioned bodies only");
+    return 0;
+}
+}  // namespace
+
+int tetsim_state_size(tetsim_handle h, uint64_t* bytes_out) {
+    if (!h || !bytes_out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (int rc = state_guard(h)) return rc;
+    *bytes_out = sizeof(StateHeader) + state_header(h).payload;
+    return 0;
+}
+int tetsim_save_state(tetsim_handle h, void* blob, uint64_t bytes) {
+    if (!h || !blob) return fail(h, TETSIM_EINVAL, "null argument");
+    if (int rc = state_guard(h)) return rc;
+    const StateHeader hd = state_header(h);
+    if (bytes < sizeof(hd) + hd.payload) return fail(h, TETSIM_EINVAL, "state buffer too small (tetsim_state_size)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    char* out = static_cast<char*>(blob);
+    std::memcpy(out, &hd, sizeof(hd));
+    out += sizeof(hd);
+    std::vector<StateSection> secs;
+    state_sections(h, secs);
+    for (const StateSection& sec : secs) {
+        if (sec.bytes) HIPCHK(h, hipMemcpy(out, sec.ptr, sec.bytes, hipMemcpyDeviceToHost));
+        out += sec.bytes;
+    }
+    return 0;
+}
+int tetsim_load_state(tetsim_handle h, const void* blob, uint64_t bytes) {
+    if (!h || !blob) return fail(h, TETSIM_EINVAL, "null argument");
+    if (int rc = state_guard(h)) return rc;
+    StateHeader in{};
+    if (bytes < sizeof(in)) return fail(h, TETSIM_EINVAL, "state blob is truncated");
+    std::memcpy(&in, blob, sizeof(in));
+    const StateHeader want = state_header(h);
+    if (in.magic != kStateMagic) return fail(h, TETSIM_EINVAL, "not a tetsim state blob (bad magic)");
+    if (in.abi != want.abi) return fail(h, TETSIM_EINVAL, "state blob was written by ABI " + std::to_string(in.abi) + ", this library is ABI " + std::to_string(want.abi));
+    if (in.solver != want.solver || in.precision != want.precision || in.flags != want.flags || in.blocked != want.blocked || in.order != want.order ||
+        in.nv != want.nv || in.nt != want.nt || in.payload != want.payload)
+        return fail(h, TETSIM_EINVAL, "state blob belongs to a body with another mesh or other options");
+    if (bytes < sizeof(in) + in.payload) return fail(h, TETSIM_EINVAL, "state blob is truncated");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const char* src = static_cast<const char*>(blob) + sizeof(in);
+    std::vector<StateSection> secs;
+    state_sections(h, secs);
+    for (const StateSection& sec : secs) {
+        if (sec.bytes) HIPCHK(h, hipMemcpy(sec.ptr, src, sec.bytes, hipMemcpyHostToDevice));
+        src += sec.bytes;
+    }
+    h->pred_any_dt = in.pred_any_dt != 0;
+    h->dt_pred = in.dt_pred;
+    return 0;
+}
+
 int tetsim_read_vol_error(tetsim_handle h, double* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
     if (h->opt.solver != TETSIM_SOLVER_NEOHOOKEAN_GS) return fail(h, TETSIM_ESTATE, "volError exists only for NEOHOOKEAN_GS");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<double> ve(h->nh.nt);
     if (h->nh.nt) HIPCHK(h, hipMemcpy(ve.data(), h->nh.vol_err, h->nh.nt * sizeof(double), hipMemcpyDeviceToHost));
@@ -492,6 +614,7 @@ int tetsim_read_vol_error(tetsim_handle h, double* out) {
 }
 int tetsim_write_state(tetsim_handle h, const float* pos, const float* vel) {
     if (!h || !pos || !vel) return fail(h, TETSIM_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     const uint32_t n = pjs ? h->pj.nv_owned : h->nh.nv;
@@ -751,7 +874,10 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     // POLAR_JACOBI: every kernel carries its own begin/end events (hipExtLaunchKernelGGL), so kernel_ms is the sum of
     // the kernels' OWN durations inside the real tet -> particle -> tet ... sequence (what rocprofv3 reports), not the
     // spacing of event markers.  NEOHOOKEAN_GS: one span per kernel class (hundreds of tiny level launches).
-    std::vector<hipEvent_t> ev(4ull * n + 2);
+    struct Events : std::vector<hipEvent_t> {  // destroyed on every exit path
+        using std::vector<hipEvent_t>::vector;
+        ~Events() { for (hipEvent_t e : *this) if (e) (void)hipEventDestroy(e); }
+    } ev(4ull * n + 2, nullptr);
     for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     hipEvent_t first_ev = ev[4ull * n], last_ev = ev[4ull * n + 1];
@@ -775,7 +901,7 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     HIPCHK(h, hipEventRecord(last_ev, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-    if (rc) { for (auto& e : ev) (void)hipEventDestroy(e); return rc; }
+    if (rc) return rc;
     float ms = 0.0f;
     for (uint32_t i = 0; i < n; i++) {
         float a = 0, b = 0, c = 0;
@@ -795,7 +921,6 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     HIPCHK(h, hipEventElapsedTime(&ms, first_ev, last_ev));
     out->total_ms = ms;
     out->substeps = n;
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return 0;
 }
 

@@ -115,6 +115,7 @@ bool uses_flag_sync(const tetsim_body* h) {
 // In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
+    if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));  // in-process groups may span devices: streams, events and lazy allocations below are per device
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
@@ -187,6 +188,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
     return 0;
 }
 int enqueue_phase_b(tetsim_body* h) {  // halo start
+    if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = halo_start(h);
     if (rc) return rc;
     h->halo_parity ^= 1u;
@@ -380,6 +382,7 @@ int tetsim_get_halo_plan(tetsim_handle h, int32_t* neigh, int32_t* send_counts, 
 
 int tetsim_halo_export(tetsim_handle h, uint32_t n, float* out_xyzw) {
     if (!h || !out_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     NeighDev& nb = h->neigh[n];
     if (!nb.send_count) return 0;
     util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
@@ -389,6 +392,7 @@ int tetsim_halo_export(tetsim_handle h, uint32_t n, float* out_xyzw) {
 }
 int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
     if (!h || !in_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
+    HIPCHK(h, hipSetDevice(h->opt.device));
     NeighDev& nb = h->neigh[n];
     if (!nb.recv_count) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -403,8 +407,9 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
         if (!h || h->opt.part_count != static_cast<int32_t>(count) || h->opt.part_index != static_cast<int32_t>(i) || h->comm)
             return fail(h, TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition without an RCCL communicator");
         if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
-        if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream
+        if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream (on ITS device)
             h->group.assign(hs, hs + count);
+            HIPCHK(h, hipSetDevice(h->opt.device));
             { int rc = create_halo_stream(h); if (rc) return rc; }
         }
     }
@@ -418,6 +423,7 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
     if (refresh) {  // dt changed: every member redid its predictions; re-send them (all "ghosts are free" records, then all copies)
         for (uint32_t i = 0; i < count; i++) {
             hs[i]->needs_halo_refresh = false;
+            HIPCHK(hs[i], hipSetDevice(hs[i]->opt.device));
             // "my ghosts may be overwritten": flag bodies record it on the halo stream, which ensure_prediction put behind the re-prediction
             HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->flag_sync ? hs[i]->comm_stream : hs[i]->stream));
         }
@@ -440,9 +446,10 @@ int tetsim_halo_exchange_local(tetsim_handle* hs, uint32_t count) {
             return fail(hs[i], TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition");
     }
     // every partition must have finished its vertex kernel before anyone's ghosts are overwritten
-    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    for (uint32_t i = 0; i < count; i++) { HIPCHK(hs[i], hipSetDevice(hs[i]->opt.device)); HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream)); }
     for (uint32_t i = 0; i < count; i++) {
         tetsim_body* src = hs[i];
+        HIPCHK(src, hipSetDevice(src->opt.device));
         for (auto& nb : src->neigh) {
             if (!nb.send_count) continue;
             tetsim_body* dst = hs[nb.rank];
@@ -454,7 +461,7 @@ int tetsim_halo_exchange_local(tetsim_handle* hs, uint32_t count) {
             HIPCHK(src, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, src->stream));
         }
     }
-    for (uint32_t i = 0; i < count; i++) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+    for (uint32_t i = 0; i < count; i++) { HIPCHK(hs[i], hipSetDevice(hs[i]->opt.device)); HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream)); }
     return 0;
 }
 }  // extern "C"

@@ -189,6 +189,25 @@ class SoftBodyHIP:
         return out.reshape(-1, 4)
 
     @property
+    def quatsPinned(self):
+        """Zero-copy twin of `quats`: a numpy VIEW of the handle's pinned host buffer, refreshed by every access."""
+        ptr = C.POINTER(C.c_float)()
+        capi.check(self._L.tetsim_read_quats_pinned(self._h, C.byref(ptr)), self._h)
+        return np.ctypeslib.as_array(ptr, shape=(self.info.local_elems, 4))
+
+    def saveState(self):
+        """The complete solver state (positions, velocities, per-tet quaternions and carried rest shape) as bytes."""
+        n = C.c_uint64()
+        capi.check(self._L.tetsim_state_size(self._h, C.byref(n)), self._h)
+        buf = (C.c_char * n.value)()
+        capi.check(self._L.tetsim_save_state(self._h, buf, n.value), self._h)
+        return bytes(buf.raw)
+
+    def loadState(self, blob):
+        """Resume from saveState() of a body with the same mesh and options: the trajectory continues bit for bit."""
+        capi.check(self._L.tetsim_load_state(self._h, bytes(blob), len(blob)), self._h)
+
+    @property
     def volError(self):
         v = C.c_double()
         capi.check(self._L.tetsim_read_vol_error(self._h, C.byref(v)), self._h)

@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["TETSIM_DEBUG_TRACE"] = "/tmp/tet_trace.bin"
+# the stamps exist only in the ablation build (python -m tetsim_amd.build --ablation)
+os.environ.setdefault("TETSIM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tetsim_amd", "libtetsim_hip_ablation.so"))
 import numpy as np
 from tetsim_amd import SoftBodyHIP, make_lattice
 pp = dict(gravity=-9.81, friction=1000.0, density=1000.0)
