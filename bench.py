@@ -17,6 +17,12 @@ The JSON line carries two extra objects:
                 algorithmic bytes per launch / mean launch duration measured here with HIP events on the
                 handle's own stream.  Bytes per tet are SURVEY.md §8(d)'s tet row (148 B) -- see DESIGN.md.
   cpu_baseline  the CPU restatement (oracle/, "port") of the same algorithm on this host's cores, bounded sample.
+and, outside the timed region:
+  library        what was loaded: ABI, source / kernel hashes, "ablation": false for the product build, debug env knobs set
+  other_configs  (N = 1) BASELINE configs 1, 2 and 4 on the same box, bounded to a few seconds
+  multi_gpu      (N > 1) ranks RCCL itself reports, per-rank step time min/max, halo bytes, host enqueue time per substep;
+                 the run FAILS if RCCL's rank count differs from --gpus
+  config5_strong (N = 8, or --config5 on) BASELINE config 5 literally: the 110^3-cell lattice cut into N slabs
 """
 import argparse
 import json
@@ -119,6 +125,87 @@ def cpu_baseline(verts, tets):
     return res
 
 
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def other_configs():
+    """BASELINE configs 1, 2 and 4 on this box, outside the timed region, a few seconds in total.  (Config 3 is the line itself,
+    config 5 needs N > 1.)  Same metric everywhere: M tet-solves/s = tets x substeps / wall."""
+    import shutil
+    import subprocess
+    from tetsim_amd import SoftBodyHIP, make_lattice
+    out = {}
+    dv = np.fromfile(os.path.join(GOLD, "dragon_verts.f32"), dtype="<f4").reshape(-1, 3)
+    dtets = np.fromfile(os.path.join(GOLD, "dragon_tets.i32"), dtype="<i4").reshape(-1, 4)
+
+    def hip_rate(v, t, n_sub, frames, **kw):
+        body = SoftBodyHIP(v, t, None, dict(PP), **kw)
+        dt = (PP["timeScale"] * PP["timeStep"]) / n_sub
+        body.simulateSubsteps(n_sub, dt, PP)
+        body.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            body.simulateSubsteps(n_sub, dt, PP)
+        body.sync()
+        el = time.perf_counter() - t0
+        levels = body.info.num_levels
+        body.close()
+        return {"value": round(len(t) * n_sub * frames / el / 1e6, 2), "unit": "M tet-solves/s", "ms_per_frame": round(el / frames * 1e3, 4),
+                "us_per_substep": round(el / frames / n_sub * 1e6, 2), "frames": frames, "launches_per_substep": (levels + 1) if levels else 2}
+
+    # config 1: Dragon, the reference's CPU solver (Neo-Hookean Gauss-Seidel), 10 substeps per frame
+    c1 = {"workload": "Dragon (%d tets, %d particles), Neo-Hookean XPBD Gauss-Seidel, 10 substeps/frame" % (len(dtets), len(dv))}
+    node = shutil.which("node")
+    if node:
+        try:
+            r = subprocess.run([node, os.path.join(ROOT, "oracle", "nh_port.js"), "--verts", os.path.join(GOLD, "dragon_verts.f32"), "--tets",
+                                os.path.join(GOLD, "dragon_tets.i32"), "--substeps", "400", "--warmup", "100", "--per-frame", "10"],
+                               capture_output=True, text=True, timeout=120)
+            jr = json.loads(r.stdout)
+            c1["softbody_js_algorithm_node_1thread"] = {"value": round(jr["m_tet_solves_per_s"], 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
+                                                        "sample": "400 substeps after 100 warm-up, oracle/nh_port.js under node " + jr["node"]}
+        except Exception as e:  # node is optional
+            c1["softbody_js_algorithm_node_1thread"] = {"error": str(e)[:200]}
+    c1["hip_original_order_precise"] = dict(hip_rate(dv, dtets, 10, 10, solver="neohookean", precision="precise", order="original"),
+                                            note="bit-exact with Softbody.js in the caller's tet order (703 dependency levels)")
+    c1["hip_coloured_precise"] = dict(hip_rate(dv, dtets, 10, 100, solver="neohookean", precision="precise", order="coloured"),
+                                      note="bit-exact with Softbody.js fed tetIds[tetsim_get_tet_order()]")
+    out["config1_dragon_neohookean_cpu_path"] = c1
+    # config 2: Dragon, polar-decomposition Jacobi, f32, 20 substeps per frame
+    out["config2_dragon_polar_jacobi"] = {
+        "workload": "Dragon, polar-decomposition Jacobi, 20 substeps/frame (2 kernels per substep in one graph launch per frame)",
+        "fast": hip_rate(dv, dtets, 20, 400, solver="polar", precision="fast"),
+        "precise": hip_rate(dv, dtets, 20, 200, solver="polar", precision="precise")}
+    # config 4: Neo-Hookean Gauss-Seidel on the 1 M-tet lattice + convergence against Jacobi (dropped 2 cm onto the floor)
+    v, t = make_lattice(CELLS, y0=0.02)
+    Dm_inv = np.linalg.inv((v[t[:, 1:]] - v[t[:, :1]]).astype(np.float64).transpose(0, 2, 1))
+
+    def vol_residual(pos):   # mean |det F - 1|: the reference's volError analogue (Softbody.js:163)
+        F = (pos[t[:, 1:]] - pos[t[:, :1]]).astype(np.float64).transpose(0, 2, 1) @ Dm_inv
+        return float(np.abs(np.linalg.det(F) - 1.0).mean())
+
+    c4 = {"workload": "Kuhn-6 lattice %d^3 cells (%d tets) dropped 2 cm onto the floor, %d substeps/frame" % (CELLS, len(t), SUBSTEPS),
+          "residual": "mean |det F - 1| after 1 / 5 / 30 frames, evaluated on the host in f64 from the returned positions"}
+    for key, kw in (("neohookean_clustered_gs_fast", dict(solver="neohookean", precision="fast", order="clustered")),
+                    ("neohookean_clustered_gs_precise", dict(solver="neohookean", precision="precise", order="clustered")),
+                    ("polar_jacobi_fast", dict(solver="polar", precision="fast"))):
+        body = SoftBodyHIP(v, t, None, dict(PP), **kw)
+        res, done, el = [], 0, 0.0
+        for frames in (1, 5, 30):
+            t0 = time.perf_counter()
+            for _ in range(frames - done):
+                body.simulateSubsteps(SUBSTEPS, DT, PP)
+            body.sync()
+            el += time.perf_counter() - t0
+            done = frames
+            res.append(float("%.3e" % vol_residual(body.pos)))
+        c4[key] = {"value": round(len(t) * SUBSTEPS * 30 / el / 1e6, 1), "unit": "M tet-solves/s", "ms_per_frame": round(el / 30 * 1e3, 4),
+                   "mean_abs_detF_minus_1_after_1_5_30_frames": res, "launches_per_substep": (body.info.num_levels + 1) if body.info.num_levels else 2}
+        body.close()
+    out["config4_lattice_1m_neohookean_gs_vs_jacobi"] = c4
+    return out
+
+
 class stdout_to_stderr:
     """Route fd 1 to fd 2 while native libraries initialise (RCCL prints a version banner on stdout): rank 0's stdout
     must carry exactly one JSON line."""
@@ -161,6 +248,9 @@ class TorchRanks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_float(self, x):
+        return -self.max_float(-x)
+
     def close(self):
         self.dist.destroy_process_group()
 
@@ -191,6 +281,9 @@ class ThreadRanks:
         self.s["barrier"].wait()
         return out
 
+    def min_float(self, x):
+        return -self.max_float(-x)
+
     def close(self):
         pass
 
@@ -215,6 +308,11 @@ def parse_args():
     ap.add_argument("--profile-ranks", action="store_true",
                     help="N > 1: after the timed region every rank runs 60 more substeps with per-kernel events and rank 0 reports "
                          "its interior tet kernel in `roofline` (default at N > 1: whole-substep figures only)")
+    ap.add_argument("--config5", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: append BASELINE config 5 literally (the --config5-cells^3 lattice cut into N slabs, strong scaling) as "
+                         "`config5_strong` of the same JSON line; auto = when N == 8")
+    ap.add_argument("--config5-cells", type=int, default=110, help="cells per side of the config-5 body (110 = 7,986,000 tets)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     ap.add_argument("--fake-ranks", type=int, default=0,
                     help="development: run N ranks as threads on ONE GPU against the RCCL test double (needs TETSIM_RCCL_LIB=tests/mock_rccl/...)")
@@ -329,64 +427,118 @@ def run_neohookean(args, verts, tets, device):
     return out, body
 
 
-def run(args, rank, world, local_rank, ranks):
-    """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
-    barrier / max_float."""
-    use_dist = ranks is not None
-    from tetsim_amd import SoftBodyHIP, make_lattice, measure_copy_bandwidth
+def slab_owner(nverts, cells, nz, world):
+    """vertex -> rank: whole z-planes, ceil(nz / world) cell layers per slab."""
+    plane = (cells + 1) * (cells + 1)
+    layers = -(-nz // world)
+    return np.minimum((np.arange(nverts) // plane) // layers, world - 1).astype(np.int32)
 
-    # ---- workload ------------------------------------------------------------------------------------
-    cells = args.cells
-    nz = cells * world if args.scaling == "weak" else cells
+
+def make_body(args, cells, scaling, rank, world, local_rank, ranks):
+    """This rank's body of the cells^2 x (cells [x world when weak]) lattice (+ communicator when ranks is not None)."""
+    from tetsim_amd import SoftBodyHIP, make_lattice
+    nz = cells * world if scaling == "weak" else cells
     verts, tets = make_lattice(cells, nz=nz)
-    nt_global = len(tets)
+    pp = dict(PP)
     kw = {}
-    if use_dist:
-        plane = (cells + 1) * (cells + 1)
-        layers = cells if args.scaling == "weak" else -(-cells // world)   # cell layers per slab
-        owner = np.minimum((np.arange(len(verts)) // plane) // layers, world - 1).astype(np.int32)
+    if ranks is not None:
         # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
         # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
         zext = 0.5 * (nz / cells) + 2.0
-        PP["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
-        kw = dict(part_count=world, part_index=rank, vert_owner=owner, ref_fixed_bounds=False)
-    if args.solver == "neohookean":
-        if world > 1:
-            raise SystemExit("--solver neohookean is a single-GPU benchmark: Gauss-Seidel would need one halo per colour (replicas only)")
-        return run_neohookean(args, verts, tets, local_rank)
+        pp["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
+        kw = dict(part_count=world, part_index=rank, vert_owner=slab_owner(len(verts), cells, nz, world), ref_fixed_bounds=False)
     if args.constant_rest_shape:
         kw["constant_rest_shape"] = True
-    body = SoftBodyHIP(verts, tets, None, dict(PP), solver="polar", precision=args.precision,
-                       device=local_rank, **kw)
-    if use_dist:
+    body = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision=args.precision, device=local_rank, **kw)
+    if ranks is not None:
         from tetsim_amd import comm_init, comm_unique_id
         uid = ranks.broadcast_bytes(comm_unique_id() if rank == 0 else None, 128)
         comm_init(body, uid, rank, world)
+    return body, verts, tets, pp, nz
 
+
+def timed_frames(body, pp, steps, warmup, ranks):
+    """W untimed + K timed frames bracketed by sync + barrier.  Returns (wall seconds of this rank, host seconds this rank spent
+    inside the K stepping calls -- the enqueue cost; the calls do not synchronise)."""
     def barrier():
         body.sync()
-        if use_dist:
+        if ranks is not None:
             ranks.barrier()
 
-    # ---- timed region --------------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    for _ in range(warmup):
+        body.simulateSubsteps(SUBSTEPS, DT, pp)
     barrier()
+    host = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        body.simulateSubsteps(SUBSTEPS, DT, pp)
+        host += time.perf_counter() - h0
     barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        elapsed = ranks.max_float(elapsed)
-    pos = body.pos
-    if not np.isfinite(pos).all():
-        raise SystemExit("non-finite positions after the timed region")
+    return time.perf_counter() - t0, host
 
+
+def multi_gpu_report(body, world, elapsed_local, host_local, steps, ranks):
+    """What makes an N-rank run self-diagnosing: RCCL's own rank count (must equal --gpus), the spread of the ranks' step times,
+    this rank's halo volume, the host enqueue time per substep."""
+    from tetsim_amd import comm_info
+    ci = comm_info(body)
+    if ci["rccl_ranks"] != world:
+        raise SystemExit("RCCL reports %d ranks in the halo communicator but --gpus is %d: refusing to report a number" % (ci["rccl_ranks"], world))
+    ms = elapsed_local / steps * 1e3
+    hq = host_local / (steps * SUBSTEPS) * 1e6
+    rep = {"rccl_ranks": ci["rccl_ranks"],
+           "ranks_ms_per_step": {"min": round(ranks.min_float(ms), 4), "max": round(ranks.max_float(ms), 4)},
+           "host_enqueue_us_per_substep": {"min": round(ranks.min_float(hq), 2), "max": round(ranks.max_float(hq), 2)},
+           "halo_rank0": {"neighbours": ci["neighbours"], "send_bytes_per_substep": ci["send_bytes_per_substep"],
+                          "recv_bytes_per_substep": ci["recv_bytes_per_substep"], "max_message_bytes": ci["max_message_bytes"]},
+           "halo_max_message_bytes_over_ranks": int(ranks.max_float(float(ci["max_message_bytes"]))),
+           "owned_tets_rank0": int(body.info.owned_elems), "local_tets_rank0": int(body.info.local_elems)}
+    if ci["loopback"]:
+        rep["loopback"] = True
+    return rep
+
+
+def pmc_traffic(kname, kernel_sha):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) -- only if they were taken on
+    THIS kernel build (same kernel_sha); a stale figure is reported as null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        return t.get(kname, {}).get("hbm_bytes_per_launch") if t.get("kernel_sha") == kernel_sha else None
+    except Exception:
+        return None
+
+
+def run(args, rank, world, local_rank, ranks):
+    """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
+    barrier / max_float / min_float."""
+    use_dist = ranks is not None
+    from tetsim_amd import library_info, measure_copy_bandwidth
+
+    cells = args.cells
+    if args.solver == "neohookean":
+        if world > 1:
+            raise SystemExit("--solver neohookean is a single-GPU benchmark: Gauss-Seidel would need one halo per colour (replicas only)")
+        from tetsim_amd import make_lattice
+        verts, tets = make_lattice(cells)
+        out, body = run_neohookean(args, verts, tets, local_rank)
+        out["library"] = library_info()
+        return out, body
+    body, verts, tets, pp, nz = make_body(args, cells, args.scaling, rank, world, local_rank, ranks)
+    nt_global = len(tets)
+
+    # ---- timed region --------------------------------------------------------------------------------
+    elapsed_local, host_local = timed_frames(body, pp, args.steps, args.warmup, ranks)
+    elapsed = ranks.max_float(elapsed_local) if use_dist else elapsed_local
+    if not np.isfinite(body.pos).all():
+        raise SystemExit("non-finite positions after the timed region")
+    mg = multi_gpu_report(body, world, elapsed_local, host_local, args.steps, ranks) if use_dist else None
+
+    lib = library_info()
     out = None
     if rank == 0:
-        tet_solves = nt_global * SUBSTEPS * args.steps
-        value = tet_solves / elapsed / 1e6
+        value = nt_global * SUBSTEPS * args.steps / elapsed / 1e6
         nv_global = len(verts)
         out = {
             "metric": "tet_solves_per_sec", "value": round(value, 1), "unit": "M tet-solves/s",
@@ -399,7 +551,12 @@ def run(args, rank, world, local_rank, ranks):
                        "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
+            "library": lib,
         }
+        if world == 1:
+            out["host_enqueue_us_per_substep"] = round(host_local / (args.steps * SUBSTEPS) * 1e6, 2)
+        if mg is not None:
+            out["multi_gpu"] = mg
     # dominant kernel: its OWN begin/end HIP events (hipExtLaunchKernelGGL) on the handle's stream, inside the real
     # tet -> particle -> tet ... sequence, 60 substeps right after the timed region (same kernels as the graph).  N > 1: every
     # rank takes part (the substeps exchange halos as usual); rank 0 reports ITS interior tet kernel -- the boundary tiles run
@@ -408,46 +565,60 @@ def run(args, rank, world, local_rank, ranks):
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
         # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
         # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
-        batches = sorted((body.profile(SUBSTEPS * 3, DT, PP) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])
+        batches = sorted((body.profile(SUBSTEPS * 3, DT, pp) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])
         pr = batches[1]
-        barrier()
+        body.sync()
+        if use_dist:
+            ranks.barrier()
+    tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)   # constant rest shape: read only, never written back
+    b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
     if rank == 0 and pr is not None:
         tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3
-        # constant-rest-shape option: the 48 B/tet shape is read only (never written back): 148 - 48 = 100 B/tet
-        tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)
         units = pr["tets_per_tet_launch"]
         achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
-        b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
-        traffic = None
-        if world == 1:
-            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if present
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    traffic = None if args.constant_rest_shape else json.load(f).get(kname, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+        traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
         out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
                            "alg_bytes_per_launch": tet_bytes * units,
                            "substep_alg_bytes_per_tet": round(b_alg, 1),
-                           "substep_achieved": round(b_alg * value * 1e6 / 1e9, 1),
-                           "substep_frac": round(b_alg * value * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+                           "substep_achieved": round(b_alg * out["value"] * 1e6 / 1e9, 1),
+                           "substep_frac": round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
         if world == 1:
             out["roofline"]["measured_copy_peak"] = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0),
                                                      "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
     if rank == 0 and pr is None:
         # N > 1 without --profile-ranks: the whole-job figure only (no extra GPU work after the timed region)
-        b_alg = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0) + VERTEX_BYTES * len(verts) / len(tets)
-        agg = b_alg * value * 1e6 / 1e9
+        agg = b_alg * out["value"] * 1e6 / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "whole substep, all ranks (tet + particle kernels)", "achieved": round(agg, 1),
                            "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4), "traffic": None,
                            "substep_alg_bytes_per_tet": round(b_alg, 1)}
+    # ---- BASELINE config 5, literally: the 110^3-cell lattice (7,986,000 tets) cut into N slabs -- strong scaling -----------
+    if use_dist and (args.config5 == "on" or (args.config5 == "auto" and world == 8)) and not (args.scaling == "strong" and cells == args.config5_cells):
+        c5 = None
+        body.close()
+        body, v5, t5, pp5, _ = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks)
+        steps5 = max(1, min(args.steps, 10))
+        e5_local, h5_local = timed_frames(body, pp5, steps5, min(args.warmup, 2), ranks)
+        e5 = ranks.max_float(e5_local)
+        finite = ranks.min_float(1.0 if np.isfinite(body.pos).all() else 0.0)
+        mg5 = multi_gpu_report(body, world, e5_local, h5_local, steps5, ranks)
+        if rank == 0:
+            v = len(t5) * SUBSTEPS * steps5 / e5 / 1e6
+            c5 = {"workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles) cut into %d z-slabs, %d-particle interface planes, "
+                              "polar-decomposition Jacobi, %d substeps/frame" % (args.config5_cells, len(t5), len(v5), world, (args.config5_cells + 1) ** 2, SUBSTEPS),
+                  "scaling": "strong", "value": round(v, 1), "unit": "M tet-solves/s", "steps": steps5, "ms_per_step": round(e5 / steps5 * 1e3, 4),
+                  "finite": bool(finite), "multi_gpu": mg5,
+                  "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+            out["config5_strong"] = c5
     if world == 1:
+        body.close()
+        if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
+            out["other_configs"] = other_configs()
         if not args.no_cpu_baseline:
-            body.close()
             out["cpu_baseline"] = cpu_baseline(verts, tets)
     return out, body
 

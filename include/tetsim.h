@@ -137,6 +137,7 @@ typedef struct TetSimInfo {
     uint64_t device_bytes;       /* HBM allocated by this handle */
     int32_t solver, precision, order, device;
     uint32_t flags;
+    uint32_t num_vis_verts;      /* visual vertices attached by tetsim_set_visual_mesh / a .tetsim file (0 = none); since ABI 3 */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
@@ -286,6 +287,16 @@ int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps,
  * partitions every substep (grouped ncclSend/ncclRecv on a dedicated stream). */
 int tetsim_comm_unique_id(void *id128);
 int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t nranks);
+/* What RCCL itself says about this handle's communicator (ncclCommCount / ncclCommUserRank) -- not what the caller passed to
+ * tetsim_comm_init -- plus the halo this partition moves per substep: neighbours, bytes sent to and received from all of them,
+ * and the largest single message.  bench.py puts it in its JSON line and refuses to report a run whose ranks != --gpus. */
+typedef struct TetSimCommInfo {
+    int32_t rccl_ranks, rccl_rank;
+    uint32_t neighbours;
+    uint64_t send_bytes_per_substep, recv_bytes_per_substep, max_message_bytes;
+    int32_t loopback;            /* TETSIM_DEBUG_LOOPBACK_HALO: the halo partner is this rank itself (measurement only) */
+} TetSimCommInfo;
+int tetsim_comm_info(tetsim_handle h, TetSimCommInfo *out);
 /* Send 1 KiB to this handle's own rank and receive it back through the initialised communicator, on the halo
  * stream, and verify the bytes: exercises the run-time-resolved RCCL entry points on hosts with a single GPU. */
 int tetsim_comm_selftest(tetsim_handle h);

@@ -90,9 +90,16 @@ def main():
     make_hub()
     cases.append(dict(name="hub", mesh="hub", params=PARAMS, numSubsteps=20, timeScale=1.0, timeStep=1 / 60, nsteps=150, dumps=[1, 20, 150],
                       grab=[], dumpTables=True))
+    # a lattice big enough for the blocked formulation to cut it into 41 workgroup tiles (12^3 cells = 10,368 tets, 2,197
+    # particles), dropped 2 mm onto the floor: contact from substep ~24 on.  Quaternions are kept for the last dump only (size).
+    from tetsim_amd import make_lattice
+    v12, t12 = make_lattice(12, y0=0.002)
+    v12.astype("<f4").tofile(os.path.join(HERE, "lat12_verts.f32"))
+    t12.astype("<i4").tofile(os.path.join(HERE, "lat12_tets.i32"))
+    cases.append(dict(base, name="lat12", mesh="lat12", nsteps=40, dumps=[1, 20, 40], quatDumps=[40]))
     with open(os.path.join(HERE, "cases_gpu.json"), "w") as f:
         json.dump(cases, f, indent=1)
-    print("wrote cases_gpu.json (%d cases) and the hub mesh" % len(cases))
+    print("wrote cases_gpu.json (%d cases), the hub mesh and the lat12 mesh" % len(cases))
 
 
 if __name__ == "__main__":

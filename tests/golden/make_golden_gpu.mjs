@@ -1,5 +1,5 @@
 // Golden-vector generator for the polar-decomposition (WebGL) solver: imports the REFERENCE SoftBodyGPU from a scratch
-// copy, gives it a headless renderer whose GL is Mesa llvmpipe (oracle/glsl_ref), and records texturePos / textureVel /
+// copy, gives it a headless renderer whose GL is Mesa softpipe (oracle/glsl_ref), and records texturePos / textureVel /
 // textureQuat after the substeps listed in cases_gpu.json.  Only data is written to the repo.
 // usage: node make_golden_gpu.mjs <scratch-dir-with-reference> <output-dir> <mesa_gl.node>
 import fs from 'fs';
@@ -79,7 +79,7 @@ async function main() {
                 const pos = grab3(body.pos, nv), vel = grab3(body.vel, nv), prev = grab3(body.prevPos, nv), quat = grab4(body.quats, nt);
                 write(`${c.name}_gpu_pos_${step}.f32`, pos);
                 write(`${c.name}_gpu_vel_${step}.f32`, vel);
-                write(`${c.name}_gpu_quat_${step}.f32`, quat);
+                if (!c.quatDumps || c.quatDumps.includes(step)) write(`${c.name}_gpu_quat_${step}.f32`, quat);
                 let ymin = Infinity;
                 for (let i = 0; i < nv; i++) ymin = Math.min(ymin, pos[3 * i + 1]);
                 out.steps[step] = { pos: sha(pos), vel: sha(vel), prev: sha(prev), quat: sha(quat), ymin };

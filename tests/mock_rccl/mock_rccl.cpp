@@ -1,7 +1,7 @@
 // mock_rccl.cpp -- TEST DOUBLE for librccl (tests only; loaded through TETSIM_RCCL_LIB).
 //
-// The multi-GPU halo path of libtetsim_hip talks to RCCL through eight entry points resolved with dlopen.  A real
-// multi-rank run needs more than one GPU, which the test box does not have, so this file implements those eight entry
+// The multi-GPU halo path of libtetsim_hip talks to RCCL through ten entry points resolved with dlopen.  A real
+// multi-rank run needs more than one GPU, which the test box does not have, so this file implements those ten entry
 // points for ranks that live in ONE process on ONE device (one host thread per rank), strictly enough to catch misuse:
 //   * every ncclSend must meet a ncclRecv of the same element count and type from the addressed peer, in order
 //     (otherwise: error / 30 s rendezvous timeout instead of silent corruption);
@@ -131,6 +131,18 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (!c || !c->alive) return ncclInvalidArgument;
     c->alive = false;   // kept allocated on purpose: a use-after-destroy is reported, not a crash
+    return ncclSuccess;
+}
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    const Comm* c = reinterpret_cast<const Comm*>(comm);
+    if (!c || !c->alive || !count) return ncclInvalidArgument;
+    *count = c->world->nranks;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+    const Comm* c = reinterpret_cast<const Comm*>(comm);
+    if (!c || !c->alive || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
     return ncclSuccess;
 }
 ncclResult_t ncclGroupStart() { t_depth++; return ncclSuccess; }

@@ -11,7 +11,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "config", "roofline"}
+            "dtype", "data", "config", "roofline", "library"}
 
 
 def _run(args, env=None):
@@ -33,6 +33,29 @@ def test_single_gpu_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    lib = d["library"]
+    assert lib["abi"] == 3 and lib["ablation"] is False and lib["debug_env"] == [] and len(lib["kernel_sha"]) == 16
+    assert rf["traffic"] is None          # not the headline lattice: no counter figure is attached to it
+
+
+def test_headline_line_carries_every_baseline_config():
+    """The default workload (1 M-tet lattice): `other_configs` reports BASELINE configs 1, 2 and 4 next to the headline
+    (config 3), and roofline.traffic is either null or keyed to this very kernel build."""
+    d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["config"]["tets"] == 998250
+    oc = d["other_configs"]
+    c1, c2, c4 = oc["config1_dragon_neohookean_cpu_path"], oc["config2_dragon_polar_jacobi"], oc["config4_lattice_1m_neohookean_gs_vs_jacobi"]
+    assert c1["hip_original_order_precise"]["value"] > 0 and c1["hip_coloured_precise"]["value"] > c1["hip_original_order_precise"]["value"]
+    assert c2["fast"]["value"] > 50 and c2["fast"]["us_per_substep"] < 100 and c2["precise"]["value"] > 0
+    for k in ("neohookean_clustered_gs_fast", "neohookean_clustered_gs_precise", "polar_jacobi_fast"):
+        r = c4[k]["mean_abs_detF_minus_1_after_1_5_30_frames"]
+        assert c4[k]["value"] > 1000 and len(r) == 3 and all(0 <= x < 0.5 for x in r)
+    # Gauss-Seidel holds the volume under contact where one Jacobi iteration per substep goes soft (DESIGN.md 4)
+    assert c4["neohookean_clustered_gs_precise"]["mean_abs_detF_minus_1_after_1_5_30_frames"][2] < c4["polar_jacobi_fast"]["mean_abs_detF_minus_1_after_1_5_30_frames"][2]
+    import hashlib  # noqa: F401
+    tr = d["roofline"]["traffic"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert (tr is None) == (pmc.get("kernel_sha") != d["library"]["kernel_sha"])
 
 
 def test_neohookean_line_on_request():
@@ -42,7 +65,7 @@ def test_neohookean_line_on_request():
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["substep_alg_bytes_per_tet"] > 56
 
 
-@pytest.mark.parametrize("extra", [[], ["--profile-ranks"], ["--scaling", "strong"]])
+@pytest.mark.parametrize("extra", [[], ["--profile-ranks"], ["--scaling", "strong"], ["--config5", "on", "--config5-cells", "18"]])
 def test_multi_rank_code_path_with_thread_ranks(extra):
     here = os.path.join(ROOT, "tests", "mock_rccl")
     lib = os.path.join(here, "libmock_rccl.so")
@@ -60,3 +83,16 @@ def test_multi_rank_code_path_with_thread_ranks(extra):
         assert "interior tiles" in d["roofline"]["kernel"] and d["roofline"]["kernel_us"] > 0
     else:
         assert d["roofline"]["peak"] == 3 * 8000.0
+    # what makes a real N-rank run self-diagnosing: RCCL's own rank count, the spread over ranks, halo volume, host enqueue time
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == 3 and 0 < mg["ranks_ms_per_step"]["min"] <= mg["ranks_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
+    assert 0 < mg["host_enqueue_us_per_substep"]["min"] <= mg["host_enqueue_us_per_substep"]["max"]
+    plane = (cells + 1) ** 2
+    assert mg["halo_rank0"] == {"neighbours": 1, "send_bytes_per_substep": 16 * plane, "recv_bytes_per_substep": 16 * plane, "max_message_bytes": 16 * plane}
+    assert mg["halo_max_message_bytes_over_ranks"] == 16 * plane
+    if "--config5" in extra:
+        c5 = d["config5_strong"]
+        assert c5["scaling"] == "strong" and c5["value"] > 0 and c5["finite"] is True and "18^3" in c5["workload"] and "3 z-slabs" in c5["workload"]
+        assert c5["multi_gpu"]["rccl_ranks"] == 3 and c5["multi_gpu"]["halo_rank0"]["max_message_bytes"] == 16 * 19 * 19
+    else:
+        assert "config5_strong" not in d

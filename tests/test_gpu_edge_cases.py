@@ -162,3 +162,89 @@ def test_pinned_zero_copy_readback_equals_copying_readback(solver, precision):
     view2 = b.posPinned
     assert view2.ctypes.data == addr                      # same pinned memory, refreshed in place
     assert np.array_equal(view2.view(np.uint32), b.pos.view(np.uint32))
+
+
+@pytest.mark.parametrize("kw", [dict(precision="precise"), dict(precision="fast"), dict(precision="fast", gather=True),
+                                dict(precision="fast", constant_rest_shape=True)])
+def test_polar_save_load_state_continues_bit_for_bit(kw):
+    """tetsim_save_state / tetsim_load_state carry the COMPLETE polar state (positions, velocities, quaternions, carried rest
+    shape): a fresh body restored from the blob continues the original trajectory bit for bit -- which tetsim_write_state
+    (positions + velocities only) cannot do, and says so."""
+    v, t = load_mesh("dragon")
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", **kw)
+    a.simulateSubsteps(30, DT, PP)
+    blob = a.saveState()
+    pos30, vel30 = a.pos, a.vel
+    a.simulateSubsteps(25, DT, PP)
+    b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", **kw)
+    b.loadState(blob)
+    assert np.array_equal(b.pos.view(np.uint32), pos30.view(np.uint32))
+    b.simulateSubsteps(25, DT, PP)
+    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+    assert np.array_equal(a.quats.view(np.uint32), b.quats.view(np.uint32))
+    # positions + velocities alone are NOT the state of this solver: the quaternions / carried shape of a fresh body differ
+    c = SoftBodyHIP(v, t, None, dict(PP), solver="polar", **kw)
+    c.writeState(pos30, vel30)
+    c.simulateSubsteps(25, DT, PP)
+    assert not np.array_equal(a.quats.view(np.uint32), c.quats.view(np.uint32))
+    # blobs are validated: other options, truncation, garbage
+    other = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", ref_slot_table=False)
+    for bad in (blob[:100], b"\0" * len(blob), blob[:-16]):
+        with pytest.raises(TetSimError):
+            b.loadState(bad)
+    if kw != dict(precision="precise"):
+        with pytest.raises(TetSimError, match="another mesh or other options"):
+            other.loadState(blob)
+
+
+def test_neohookean_save_load_state():
+    v, t = load_mesh("dragon")
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured")
+    a.simulateSubsteps(12, DT * 2, PP)
+    blob = a.saveState()
+    a.simulateSubsteps(9, DT * 2, PP)
+    b = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured")
+    b.loadState(blob)
+    b.simulateSubsteps(9, DT * 2, PP)
+    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32)) and a.volError == b.volError
+
+
+@pytest.mark.parametrize("kw", [dict(precision="precise"), dict(precision="fast")])
+def test_pinned_quaternion_view_equals_copying_read(kw):
+    """SURVEY.md 8(f)-2, quaternion half: tetsim_read_quats_pinned is a view of a pinned host buffer (same address every
+    call) and holds what tetsim_read_quats returns."""
+    v, t = load_mesh("dragon")
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", **kw)
+    body.simulateSubsteps(20, DT, PP)
+    q1 = body.quatsPinned
+    addr = q1.ctypes.data
+    assert np.array_equal(q1.view(np.uint32), body.quats.view(np.uint32)) and q1.shape == (len(t), 4)
+    body.simulateSubsteps(5, DT, PP)
+    q2 = body.quatsPinned
+    assert q2.ctypes.data == addr and np.array_equal(q2.view(np.uint32), body.quats.view(np.uint32))
+    with pytest.raises(TetSimError):
+        SoftBodyHIP(v, t, None, dict(PP), solver="neohookean").quatsPinned
+
+
+def test_library_info_on_the_gpu_box():
+    from tetsim_amd import library_info
+    info = library_info()
+    assert info["abi"] == 3 and info["ablation"] is False and len(info["source_sha"]) == 16
+
+
+def test_partitioned_body_ignores_the_visual_mesh(tmp_path):
+    """A partition owns a subset of the particles; a visual mesh handed to it (arrays or a .tetsim file that stores one) is
+    ignored instead of making the constructor fail."""
+    from conftest import load_f32
+    from tetsim_amd.meshfile import write_mesh
+    v, t = load_mesh("dragon")
+    vis = load_f32("dragon_vis.f32")
+    part = SoftBodyHIP(v, t, None, dict(PP), vis, solver="polar", precision="fast", part_count=2, part_index=1)
+    assert part.info.num_vis_verts == 0 and part.info.owned_particles < len(v)
+    path = str(tmp_path / "d.tetsim")
+    write_mesh(path, v, t, vis_verts=vis)
+    part2 = SoftBodyHIP.fromFile(path, dict(PP), solver="polar", precision="fast", part_count=2, part_index=0)
+    part2.simulate(DT, PP)
+    assert part2.info.num_vis_verts == 0 and np.isfinite(part2.pos).all()
+    whole = SoftBodyHIP.fromFile(path, dict(PP), solver="polar", precision="fast")
+    assert whole.info.num_vis_verts == len(vis) // 4

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_f32, load_mesh, sha16
+from conftest import load_f32, load_mesh, sha16, within
 from oracle import OraclePJ
 from tetsim_amd import SoftBodyHIP
 
@@ -113,9 +113,9 @@ def test_polar_skinning_and_normals(precision):
     b3 = np.float32(1.0) - ((b[:, 0] + b[:, 1]) + b[:, 2])
     c = t[tn]
     ref = ((p[c[:, 0]] * b[:, :1] + p[c[:, 1]] * b[:, 1:2]) + p[c[:, 2]] * b[:, 2:3]) + p[c[:, 3]] * b3[:, None]
-    assert np.abs(pos - ref).max() < (1e-6 if precision == "precise" else 1e-4)
+    within("skinning %s vs oracle positions" % precision, np.abs(pos - ref).max(), 1e-6 if precision == "precise" else 1e-4)
     qq = q[tn]
     qv, w = qq[:, :3], qq[:, 3:]
     refn = n0 + 2.0 * np.cross(qv, np.cross(qv, n0) + w * n0)
-    assert np.abs(nrm - refn).max() < (1e-5 if precision == "precise" else 1e-3)
+    within("skinning %s vs oracle normals" % precision, np.abs(nrm - refn).max(), 1e-5 if precision == "precise" else 1e-3)
     assert np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-4

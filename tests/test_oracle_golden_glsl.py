@@ -22,6 +22,7 @@ TOL = {
     "dragon_grab": {10: 5e-6, 60: 5e-5},
     "lat4_drag": {60: 5e-5, 200: 2e-4},
     "hub": {1: 0.0, 20: 1e-5, 150: 2e-4},     # Delaunay ball around a hub particle of valence >> 36 (slots silently dropped)
+    "lat12": {1: 0.0, 20: 4e-6, 40: 5e-6},    # 10,368 tets (41 workgroup tiles of the blocked kernel), floor contact from substep ~24; observed 1.3e-6 / 1.7e-6
 }
 
 
@@ -96,7 +97,7 @@ def test_host_tables_bit_exact(mesh, glsl_golden):
     assert np.array_equal(out, slots.ravel())
 
 
-@pytest.mark.parametrize("name", ["lat4", "dragon", "dragon_grab", "lat4_drag", "hub"])
+@pytest.mark.parametrize("name", ["lat4", "dragon", "dragon_grab", "lat4_drag", "hub", "lat12"])
 def test_trajectory_tracks_the_reference_glsl(name, glsl_golden):
     g, cases = glsl_golden
     c, gc = cases[name], g["cases"][name]
@@ -107,17 +108,20 @@ def test_trajectory_tracks_the_reference_glsl(name, glsl_golden):
     def on_dump(step):
         gp = load_f32(f"{name}_gpu_pos_{step}.f32").reshape(-1, 3)
         gv = load_f32(f"{name}_gpu_vel_{step}.f32").reshape(-1, 3)
-        gq = load_f32(f"{name}_gpu_quat_{step}.f32").reshape(-1, 4)
+        has_q = step in c.get("quatDumps", c["dumps"])   # big cases keep the quaternion dump of the last step only (its hash always)
+        gq = load_f32(f"{name}_gpu_quat_{step}.f32").reshape(-1, 4) if has_q else None
         assert sha16(gp) == gc["steps"][str(step)]["pos"]
         tol = TOL[name][step]
         if tol == 0.0:
             assert np.array_equal(o.pos.view(np.uint32), gp.view(np.uint32)), (name, step)
             assert np.array_equal(o.vel.view(np.uint32), gv.view(np.uint32)), (name, step)
-            assert np.array_equal(o.quats.view(np.uint32), gq.view(np.uint32)), (name, step)
+            assert sha16(o.quats) == gc["steps"][str(step)]["quat"], (name, step)
         else:
-            assert np.abs(o.pos - gp).max() <= tol, (name, step, np.abs(o.pos - gp).max())
+            err = np.abs(o.pos - gp).max()
+            assert err <= tol, "%s step %d: observed %.3g m, allowed %.3g m" % (name, step, err, tol)
             assert np.abs(o.vel - gv).max() <= 2.0 * tol / gc["dt"], (name, step)   # v = dx/dt: position ulps / dt
-            assert np.abs(o.quats - gq).max() <= max(50 * tol, 1e-5), (name, step)
+            if has_q:
+                assert np.abs(o.quats - gq).max() <= max(50 * tol, 1e-5), (name, step)
         seen.append(step)
 
     replay(o, c, gc, on_dump, o.setGrab, o.endGrab)

@@ -41,7 +41,8 @@ class TetSimInfo(C.Structure):
                 ("local_particles", C.c_uint32), ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32),
                 ("num_levels", C.c_uint32), ("max_valence", C.c_uint32), ("dropped_slots", C.c_uint32),
                 ("num_neighbours", C.c_uint32), ("device_bytes", C.c_uint64), ("solver", C.c_int32),
-                ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("num_vis_verts", C.c_uint32)]
 
 
 class TetSimProfile(C.Structure):
@@ -56,6 +57,11 @@ class TetSimLibraryInfo(C.Structure):
 
 DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "TETSIM_DEBUG_ONE_STREAM", "TETSIM_DEBUG_GROUP_SYNC",
                    "TETSIM_DEBUG_HOSTPROF", "TETSIM_DEBUG_TRACE", "TETSIM_HALO_SYNC", "TETSIM_HALO_GRAPH"]
+
+
+class TetSimCommInfo(C.Structure):
+    _fields_ = [("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("neighbours", C.c_uint32), ("send_bytes_per_substep", C.c_uint64),
+                ("recv_bytes_per_substep", C.c_uint64), ("max_message_bytes", C.c_uint64), ("loopback", C.c_int32)]
 
 
 class TetSimPlanSizes(C.Structure):
@@ -79,7 +85,7 @@ SYMBOLS = [
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
     "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
-    "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
+    "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
     "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
@@ -147,6 +153,7 @@ def lib():
     L.tetsim_comm_unique_id.argtypes = [C.c_void_p]
     L.tetsim_comm_init.argtypes = [H, C.c_void_p, i32, i32]
     L.tetsim_comm_selftest.argtypes = [H]
+    L.tetsim_comm_info.argtypes = [H, C.POINTER(TetSimCommInfo)]
     L.tetsim_group_step_n.argtypes = [C.POINTER(H), u32, u32, dbl, PP]
     L.tetsim_halo_exchange_local.argtypes = [C.POINTER(H), u32]
     L.tetsim_get_halo_plan.argtypes = [H, ip, ip, ip, ip, ip]

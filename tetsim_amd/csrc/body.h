@@ -40,6 +40,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -62,12 +64,14 @@ struct Rccl {
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(sym("ncclCommUserRank"));
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+        return GetUniqueId && CommInitRank && CommDestroy && CommCount && CommUserRank && Send && Recv && GroupStart && GroupEnd && GetErrorString;
     }
 };
 extern Rccl g_rccl;

@@ -720,6 +720,7 @@ int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvi
     }
     k.corner = dc; k.weight = dw; k.qidx = dq; k.normal0 = dn;
     k.nvis = nvis;
+    h->info.num_vis_verts = nvis;
     return 0;
 }
 

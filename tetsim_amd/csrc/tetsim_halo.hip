@@ -262,6 +262,26 @@ int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t n
     return 0;
 }
 
+int tetsim_comm_info(tetsim_handle h, TetSimCommInfo* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
+    std::memset(out, 0, sizeof(*out));
+    int n = 0, r = -1;
+    ncclResult_t e = g_rccl.CommCount(h->comm, &n);
+    if (e == ncclSuccess) e = g_rccl.CommUserRank(h->comm, &r);
+    if (e != ncclSuccess) return rccl_fail(h, e, "ncclCommCount / ncclCommUserRank");
+    out->rccl_ranks = n;
+    out->rccl_rank = r;
+    out->neighbours = static_cast<uint32_t>(h->neigh.size());
+    for (const NeighDev& nb : h->neigh) {
+        out->send_bytes_per_substep += 16ull * nb.send_count;
+        out->recv_bytes_per_substep += 16ull * nb.recv_count;
+        out->max_message_bytes = std::max<uint64_t>(out->max_message_bytes, 16ull * std::max(nb.send_count, nb.recv_count));
+    }
+    out->loopback = h->loopback ? 1 : 0;
+    return 0;
+}
+
 int tetsim_comm_selftest(tetsim_handle h) {
     if (!h) return TETSIM_EINVAL;
     if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");

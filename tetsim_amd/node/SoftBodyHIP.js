@@ -12,7 +12,8 @@
 // Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
 //     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured' | 'clustered', device: 0,
 //       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false,   (include/tetsim.h flags)
-//       partCount: 1, partIndex: 0, vertOwner: Int32Array }   (one Node process per GPU: see commUniqueId / commInit below)
+//       partCount: 1, partIndex: 0, vertOwner: Int32Array,    (one Node process per GPU: see commUniqueId / commInit below)
+//       refStartGrab: false }   (true: startGrab searches the edge-mesh copy of the positions, exactly as SoftbodyGPU.js:692-704)
 // default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
 const path = require('path');
 
@@ -66,7 +67,10 @@ class SoftBodyHIP {
         this.visMesh = null;
         this.visVerts = visVerts || new Float32Array(0);
         this.numVisVerts = this.visVerts.length / 4;
-        if (this.numVisVerts > 0) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1); createFromFile attached it already
+        this._partitioned = createOptions.partCount > 1;
+        // a partition owns a subset of the particles: the embedded mesh (whose vertices hang on tets anywhere in the body) is
+        // skinned on unpartitioned bodies only; a partitioned body is physics + its own particles, no visual mesh
+        if (this.numVisVerts > 0 && !this._partitioned) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1); createFromFile attached it already
             if (!_meshFile) api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
             this._visOnDevice = true;
             // ... and its vertex normals too: Softbody.js:273 runs geometry.computeVertexNormals() every frame (37 ms of the
@@ -175,7 +179,22 @@ class SoftBodyHIP {
 
     // ---- grab (Softbody.js:279-298) ------------------------------------------------------------------------------
     startGrab(pos) {
-        this.grabId = this._api.startGrab(this._h, pos.x, pos.y, pos.z);   // nearest particle, on the latest positions
+        const opt = this.physicsParams.tetsim || {};
+        if (opt.refStartGrab && this.edgeMesh) {
+            // SoftbodyGPU.js:692-704 to the letter: the search runs over the edge mesh's COPY of the positions, i.e. whatever
+            // the last updateEdgeMesh() left there (GPUGrabber.start refreshes it first, :790-795; a direct call does not)
+            const particles = this.edgeMesh.geometry.attributes.position.array;
+            let minD2 = Number.MAX_VALUE;
+            this.grabId = -1;
+            for (let i = 0; i < this.numParticles; i++) {
+                const dx = pos.x - particles[3 * i], dy = pos.y - particles[3 * i + 1], dz = pos.z - particles[3 * i + 2];
+                const d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < minD2) { minD2 = d2; this.grabId = i; }
+            }
+            this._api.setGrab(this._h, this.grabId, pos.x, pos.y, pos.z);
+        } else {
+            this.grabId = this._api.startGrab(this._h, pos.x, pos.y, pos.z);   // nearest particle among the CURRENT device positions (Softbody.js:279-291)
+        }
         this.grabPos[0] = pos.x; this.grabPos[1] = pos.y; this.grabPos[2] = pos.z;
     }
     moveGrabbed(pos) {
@@ -187,8 +206,26 @@ class SoftBodyHIP {
         this._api.setGrab(this._h, -1, 0, 0, 0);
     }
 
+    // per-tet rotation quaternions (textureQuat, SoftbodyGPU.js:55; consumed by the normal path :440) -- a zero-copy view of the
+    // handle's pinned host buffer, [4 * localElems] in the body's local tet order, refreshed by every call
+    readQuats() {
+        if (!this._quats) this._quats = this._api.mapQuats(this._h);
+        else this._api.refreshQuats(this._h);
+        return this._quats;
+    }
+    // checkpoint / resume of the complete solver state (positions, velocities, per-tet quaternions and carried rest shape)
+    saveState() { return this._api.saveState(this._h); }
+    loadState(blob) { this._api.loadState(this._h, blob); this._dirty = true; }
+
     info() { return this._api.info(this._h); }
-    dispose() { if (this._h) { this._api.destroy(this._h); this._h = null; } }
+    dispose() {
+        if (!this._h) return;
+        // destroy() frees the pinned buffers `pos` / the quaternion view alias (the addon detaches them): keep plain copies
+        if (this._mapped) { this.pos = Float32Array.from(this.pos); this._mapped = false; }
+        if (this._quats) { this._quats = Float32Array.from(this._quats); }
+        this._api.destroy(this._h);
+        this._h = null;
+    }
 }
 SoftBodyHIP.THREE = null;
 

@@ -183,4 +183,73 @@ if (process.env.TETSIM_TEST_MESH) {
     solo.dispose();
     console.log('partition options, ownedIds, commUniqueId/commInit ok');
 }
+// 6. hardening of the shim (round-1 review): typed-array lengths are checked before the C side writes, views of the pinned
+//    buffers do not dangle after dispose(), partitioned bodies ignore the visual mesh instead of throwing
+{
+    const p8 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'fast' } });
+    const b8 = new SoftBodyHIP(verts.slice(0), tets, [], p8, f32('dragon_vis.f32'), [], null, {});
+    assert.strictEqual(b8.info().numVisVerts, 29800);
+    assert.throws(() => b8.readVisualPositions(new Float32Array(10)), /too small/);
+    assert.throws(() => b8._api.readVisualMesh(b8._h, new Float32Array(3 * 29800), new Float32Array(5)), /too small/);
+    assert.throws(() => b8._api.step(b8._h, 'soon', p8), /must be a number/);
+    assert.throws(() => b8._api.stepN(b8._h, -1, dt20, p8), /non-negative integer/);
+    assert.throws(() => b8._api.setGrab(b8._h, {}, 0, 0, 0), /must be a number/);
+    const nvv = verts.length / 3;
+    assert.throws(() => new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', partCount: 2, partIndex: 0, vertOwner: new Int32Array(nvv - 1) } }), new Float32Array(0), [], null, {}), /vertOwner/);
+    // quaternions: zero-copy view == the copying read, unit length; save / load of the complete state continues bit for bit
+    b8.simulateSubsteps(20, dt20, p8);
+    const q = b8.readQuats(), qc = new Float32Array(4 * b8.info().localElems);
+    b8._api.readQuats(b8._h, qc);
+    assert.strictEqual(q.length, qc.length); assert.strictEqual(bitsEqual(q, qc), -1, 'pinned quaternion view differs from readQuats');
+    for (let e = 0; e < q.length; e += 4) assert.ok(Math.abs(Math.hypot(q[e], q[e + 1], q[e + 2], q[e + 3]) - 1) < 1e-5);
+    const blob = b8.saveState();
+    b8.simulateSubsteps(20, dt20, p8); b8.endFrame();
+    const want = Float32Array.from(b8.pos);
+    const b9 = new SoftBodyHIP(verts.slice(0), tets, [], p8, new Float32Array(0), [], null, {});
+    b9.loadState(blob);
+    b9.simulateSubsteps(20, dt20, p8); b9.endFrame();
+    assert.strictEqual(bitsEqual(b9.pos, want), -1, 'a body restored with loadState must continue the trajectory bit for bit');
+    // dispose(): `pos` stays readable (a plain copy), the raw pinned views are detached, the handle is unusable
+    const rawView = b9._api.mapPositions(b9._h), kept = b9.pos;
+    b9.dispose();
+    assert.strictEqual(bitsEqual(b9.pos, want), -1); assert.strictEqual(rawView.length, 0, 'pinned view must be detached by destroy'); assert.strictEqual(kept.length, 0);
+    assert.throws(() => b9._api.sync(b9._h));
+    b8.dispose();
+    console.log('shim hardening: length checks, number checks, detached views after dispose, quaternion view, save/load state ok');
+}
+if (process.env.TETSIM_TEST_MESH) {   // a partitioned body from a file that carries a visual mesh (used to throw)
+    const nvv = verts.length / 3;
+    const owner = new Int32Array(nvv); for (let i = 0; i < nvv; i++) owner[i] = i < nvv / 2 ? 0 : 1;
+    const p10 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'fast', partCount: 2, partIndex: 0, vertOwner: owner } });
+    const part = SoftBodyHIP.fromFile(process.env.TETSIM_TEST_MESH, p10, null, null);
+    assert.strictEqual(part.info().numVisVerts, 0); assert.ok(part.info().ownedParticles < nvv);
+    part.simulate(dt20, p10); part.endFrame();
+    part.dispose();
+    console.log('partitioned fromFile body with a stored visual mesh: constructed, stepped (no visual mesh on partitions)');
+}
+// 7. startGrab exactly as SoftbodyGPU.js:692-704 (tetsim.refStartGrab): the search runs over the edge mesh's copy of the positions
+{
+    class BufferAttribute { constructor(array, itemSize) { this.array = array; this.itemSize = itemSize; this.needsUpdate = false; } }
+    class BufferGeometry { constructor() { this.attributes = {}; } setAttribute(n, a) { this.attributes[n] = a; return this; } setIndex() { return this; } computeVertexNormals() {} computeBoundingSphere() {} }
+    class Layers { enable() {} }
+    class Object3D { constructor(g, m) { this.geometry = g; this.material = m; this.layers = new Layers(); this.userData = {}; this.visible = true; } }
+    const THREE = { BufferAttribute, BufferGeometry, LineSegments: Object3D, Mesh: Object3D };
+    const p11 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'precise', refStartGrab: true } });
+    const b = new SoftBodyHIP(verts.slice(0), tets, [], p11, new Float32Array(0), [], null, { THREE });
+    const probe = { x: verts[3 * 700] + 1e-4, y: verts[3 * 700 + 1] - 0.3, z: verts[3 * 700 + 2] };   // where particle 700 will be after falling ~0.3 m
+    for (let f = 0; f < 15; f++) b.simulateSubsteps(20, dt20, p11);
+    b.readToCPU();                       // positions read back, edge mesh NOT refreshed (SoftbodyGPU.js:643-647 leaves it commented out)
+    b.startGrab(probe);
+    let best = -1, bd = Infinity;        // the reference's loop over the stale copy (= the rest positions here)
+    for (let i = 0; i < b.numParticles; i++) { const d = (probe.x - verts[3 * i]) ** 2 + (probe.y - verts[3 * i + 1]) ** 2 + (probe.z - verts[3 * i + 2]) ** 2; if (d < bd) { bd = d; best = i; } }
+    assert.strictEqual(b.grabId, best, 'refStartGrab must search the edge-mesh copy');
+    b.endGrab();
+    b.updateEdgeMesh();                  // what GPUGrabber.start does first (:790-795): now the copy is current
+    b.startGrab(probe);
+    const cur = b.pos; best = -1; bd = Infinity;
+    for (let i = 0; i < b.numParticles; i++) { const d = (probe.x - cur[3 * i]) ** 2 + (probe.y - cur[3 * i + 1]) ** 2 + (probe.z - cur[3 * i + 2]) ** 2; if (d < bd) { bd = d; best = i; } }
+    assert.strictEqual(b.grabId, best);
+    b.dispose();
+    console.log('refStartGrab: searches the edge-mesh copy (stale until updateEdgeMesh), like SoftbodyGPU.js:692-704');
+}
 console.log('node boundary ok');

@@ -6,6 +6,7 @@
 // addon also loads on hosts without ROCm -- every compute call then fails loudly (no CPU fallback).
 //
 // Build: g++ -std=c++17 -shared -fPIC -I/usr/include/node tetsim_napi.cc -o tetsim_napi.node -ldl
+#define NAPI_VERSION 7   // napi_detach_arraybuffer (Node >= 12.17)
 #include <dlfcn.h>
 #include <node_api.h>
 
@@ -32,6 +33,11 @@ struct Api {
     decltype(&tetsim_read_positions_pinned) read_positions_pinned = nullptr;
     decltype(&tetsim_read_velocities) read_velocities = nullptr;
     decltype(&tetsim_read_quats) read_quats = nullptr;
+    decltype(&tetsim_read_quats_pinned) read_quats_pinned = nullptr;
+    decltype(&tetsim_state_size) state_size = nullptr;
+    decltype(&tetsim_save_state) save_state = nullptr;
+    decltype(&tetsim_load_state) load_state = nullptr;
+    decltype(&tetsim_library_info) library_info = nullptr;
     decltype(&tetsim_read_vol_error) read_vol_error = nullptr;
     decltype(&tetsim_get_local_tets) get_local_tets = nullptr;
     decltype(&tetsim_set_visual_mesh) set_visual_mesh = nullptr;
@@ -65,7 +71,8 @@ bool load_lib(const std::string& hint) {
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(set_visual_triangles, "tetsim_set_visual_triangles") SYM(read_visual_vertex_normals, "tetsim_read_visual_vertex_normals")
-    SYM(abi_version, "tetsim_abi_version")
+    SYM(abi_version, "tetsim_abi_version") SYM(read_quats_pinned, "tetsim_read_quats_pinned") SYM(state_size, "tetsim_state_size")
+    SYM(save_state, "tetsim_save_state") SYM(load_state, "tetsim_load_state") SYM(library_info, "tetsim_library_info")
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
 #undef SYM
@@ -106,10 +113,36 @@ bool get_double(napi_env env, napi_value obj, const char* key, double* out) {
     if (napi_typeof(env, v, &t) != napi_ok || t != napi_number) return false;
     return napi_get_value_double(env, v, out) == napi_ok;
 }
-tetsim_handle handle_of(napi_env env, napi_value v) {
+// What the JS side holds as "the handle".  The pinned host buffers a body hands out (mapPositions / mapQuats) are wrapped as
+// external ArrayBuffers whose memory belongs to the tetsim handle, so the handle must outlive every such buffer that can still
+// be read: each mapped buffer holds a count on the box (released by the buffer's own finalizer), and an explicit destroy()
+// DETACHES the buffers first -- a view kept by the caller then reads as empty instead of freed memory.
+struct Box {
+    tetsim_handle h = nullptr;
+    int refs = 1;                     // the external + one per live mapped ArrayBuffer
+    napi_ref pos_ab = nullptr, quat_ab = nullptr;
+};
+void box_release(Box* b) {
+    if (--b->refs > 0) return;
+    if (b->h) g.destroy(b->h);
+    delete b;
+}
+Box* box_of(napi_env env, napi_value v) {
     void* p = nullptr;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { throw_err(env, "not a tetsim handle (or already destroyed)"); return nullptr; }
-    return *static_cast<tetsim_handle*>(p);
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { throw_err(env, "not a tetsim handle"); return nullptr; }
+    Box* b = static_cast<Box*>(p);
+    if (!b->h) { throw_err(env, "tetsim handle already destroyed"); return nullptr; }
+    return b;
+}
+tetsim_handle handle_of(napi_env env, napi_value v) {
+    Box* b = box_of(env, v);
+    return b ? b->h : nullptr;
+}
+// numbers: a failed conversion throws instead of leaving the value uninitialised
+bool num_arg(napi_env env, napi_value v, double* out, const char* what) {
+    if (napi_get_value_double(env, v, out) == napi_ok) return true;
+    throw_err(env, std::string(what) + " must be a number");
+    return false;
 }
 // physicsParams object (main.js:22-36) -> TetSimParams
 void params_of(napi_env env, napi_value obj, TetSimParams* p) {
@@ -131,10 +164,19 @@ napi_value check(napi_env env, int rc, tetsim_handle h) {
     if (rc == TETSIM_OK) { napi_value u; napi_get_undefined(env, &u); return u; }
     return throw_err(env, std::string("tetsim error ") + std::to_string(rc) + ": " + g.last_error(h));
 }
-void finalize_handle(napi_env, void* data, void*) {
-    tetsim_handle* hp = static_cast<tetsim_handle*>(data);
-    if (*hp) g.destroy(*hp);
-    delete hp;
+void finalize_handle(napi_env env, void* data, void*) {
+    Box* b = static_cast<Box*>(data);
+    if (b->pos_ab) { napi_delete_reference(env, b->pos_ab); b->pos_ab = nullptr; }
+    if (b->quat_ab) { napi_delete_reference(env, b->quat_ab); b->quat_ab = nullptr; }
+    box_release(b);
+}
+void finalize_mapped(napi_env, void*, void* hint) { box_release(static_cast<Box*>(hint)); }
+napi_value wrap_handle(napi_env env, tetsim_handle h) {
+    Box* b = new Box();
+    b->h = h;
+    napi_value ext;
+    if (napi_create_external(env, b, finalize_handle, nullptr, &ext) != napi_ok) { g.destroy(h); delete b; return throw_err(env, "cannot wrap the handle"); }
+    return ext;
 }
 
 // load(path) -> abi version
@@ -151,7 +193,7 @@ napi_value Load(napi_env env, napi_callback_info info) {
 }
 
 // create(Float32Array verts, Int32Array tets, {solver, precision, order, flags, device, density}) -> handle
-void options_of(napi_env env, napi_value obj, TetSimOptions* o);
+void options_of(napi_env env, napi_value obj, TetSimOptions* o, size_t* owner_len);
 napi_value Create(napi_env env, napi_callback_info info) {
     napi_value a[3];
     if (!get_args(env, info, 3, a)) return nullptr;
@@ -161,18 +203,18 @@ napi_value Create(napi_env env, napi_callback_info info) {
     if (!typed_array(env, a[1], napi_int32_array, &tets, &ntf)) return throw_err(env, "tetIds must be an Int32Array");
     if (nvf % 3 || ntf % 4) return throw_err(env, "vertices need 3 floats per particle, tetIds 4 ids per tet");
     TetSimOptions o;
-    options_of(env, a[2], &o);
+    size_t owner_len = 0;
+    options_of(env, a[2], &o, &owner_len);
+    if (o.vert_owner && owner_len != nvf / 3) return throw_err(env, "vertOwner must hold one partition index per particle");
     tetsim_handle h = nullptr;
     const int rc = g.create(verts, static_cast<uint32_t>(nvf / 3), tets, static_cast<uint32_t>(ntf / 4), &o, &h);
     if (rc != TETSIM_OK) return check(env, rc, nullptr);
-    tetsim_handle* hp = new tetsim_handle(h);
-    napi_value ext;
-    napi_create_external(env, hp, finalize_handle, nullptr, &ext);
-    return ext;
+    return wrap_handle(env, h);
 }
 // options object -> TetSimOptions (shared by create / createFromFile)
-void options_of(napi_env env, napi_value obj, TetSimOptions* o) {
+void options_of(napi_env env, napi_value obj, TetSimOptions* o, size_t* owner_len) {
     g.default_options(o);
+    *owner_len = 0;
     double d;
     if (get_double(env, obj, "solver", &d)) o->solver = static_cast<int32_t>(d);
     if (get_double(env, obj, "precision", &d)) o->precision = static_cast<int32_t>(d);
@@ -186,7 +228,7 @@ void options_of(napi_env env, napi_value obj, TetSimOptions* o) {
     napi_value ov; bool has = false;
     if (napi_has_named_property(env, obj, "vertOwner", &has) == napi_ok && has && napi_get_named_property(env, obj, "vertOwner", &ov) == napi_ok) {
         int32_t* own; size_t n;
-        if (typed_array(env, ov, napi_int32_array, &own, &n)) o->vert_owner = own;   // read during create only
+        if (typed_array(env, ov, napi_int32_array, &own, &n)) { o->vert_owner = own; *owner_len = n; }   // read during create only; length checked by the caller
     }
 }
 // createFromFile(path, options) -> handle      (tetsim_create_from_file: the library maps the .tetsim container itself)
@@ -197,14 +239,22 @@ napi_value CreateFromFile(napi_env env, napi_callback_info info) {
     char path[4096]; size_t n = 0;
     if (napi_get_value_string_utf8(env, a[0], path, sizeof path, &n) != napi_ok) return throw_err(env, "path must be a string");
     TetSimOptions o;
-    options_of(env, a[1], &o);
+    size_t owner_len = 0;
+    options_of(env, a[1], &o, &owner_len);
+    if (o.vert_owner) {   // its length must match the file's particle count: look before the library reads it
+        tetsim_mesh m = nullptr;
+        int mrc = g.mesh_open(path, &m);
+        if (mrc != TETSIM_OK) return check(env, mrc, nullptr);
+        TetSimMeshArrays A;
+        g.mesh_arrays(m, &A);
+        const bool ok = owner_len == A.num_particles;
+        g.mesh_close(m);
+        if (!ok) return throw_err(env, "vertOwner must hold one partition index per particle of the file");
+    }
     tetsim_handle h = nullptr;
     const int rc = g.create_from_file(path, &o, &h);
     if (rc != TETSIM_OK) return check(env, rc, nullptr);
-    tetsim_handle* hp = new tetsim_handle(h);
-    napi_value ext;
-    napi_create_external(env, hp, finalize_handle, nullptr, &ext);
-    return ext;
+    return wrap_handle(env, h);
 }
 // readMesh(path) -> { vertices: Float32Array, tetIds: Int32Array, tetEdgeIds, visVerts, visTriIds, tetColour, vertOwner, partCount }
 // (copies out of the mapping: the JS arrays outlive it; absent sections are null)
@@ -248,8 +298,15 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, a)) return nullptr;
     void* p = nullptr;
     if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
-        tetsim_handle* hp = static_cast<tetsim_handle*>(p);
-        if (*hp) { g.destroy(*hp); *hp = nullptr; }
+        Box* b = static_cast<Box*>(p);
+        for (napi_ref* r : {&b->pos_ab, &b->quat_ab}) {   // the pinned memory goes away with the handle: detach what wraps it
+            if (!*r) continue;
+            napi_value ab;
+            if (napi_get_reference_value(env, *r, &ab) == napi_ok && ab) napi_detach_arraybuffer(env, ab);
+            napi_delete_reference(env, *r);
+            *r = nullptr;
+        }
+        if (b->h) { g.destroy(b->h); b->h = nullptr; }
     }
     napi_value u; napi_get_undefined(env, &u); return u;
 }
@@ -259,7 +316,8 @@ napi_value Step(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 3, a)) return nullptr;
     tetsim_handle h = handle_of(env, a[0]);
     if (!h) return nullptr;
-    double dt; napi_get_value_double(env, a[1], &dt);
+    double dt;
+    if (!num_arg(env, a[1], &dt, "dt")) return nullptr;
     TetSimParams p; params_of(env, a[2], &p);
     return check(env, g.step(h, dt, &p), h);
 }
@@ -268,8 +326,10 @@ napi_value StepN(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 4, a)) return nullptr;
     tetsim_handle h = handle_of(env, a[0]);
     if (!h) return nullptr;
-    uint32_t n; napi_get_value_uint32(env, a[1], &n);
-    double dt; napi_get_value_double(env, a[2], &dt);
+    double nd, dt;
+    if (!num_arg(env, a[1], &nd, "n") || !num_arg(env, a[2], &dt, "dt")) return nullptr;
+    if (!(nd >= 0.0) || nd > 4294967295.0 || nd != static_cast<double>(static_cast<uint32_t>(nd))) return throw_err(env, "n must be a non-negative integer");
+    const uint32_t n = static_cast<uint32_t>(nd);
     TetSimParams p; params_of(env, a[3], &p);
     return check(env, g.step_n(h, n, dt, &p), h);
 }
@@ -293,31 +353,80 @@ napi_value ReadF32(napi_env env, napi_callback_info info) {
     if (n < need) return throw_err(env, "output array too small");
     return check(env, (g.*Fn)(h, out), h);
 }
-// mapPositions(handle) -> Float32Array over the handle's PINNED host buffer (zero copy); the view stays
-// valid until destroy(handle); refreshPositions(handle) re-fills it (device pack kernel + one DMA).
-napi_value MapPositions(napi_env env, napi_callback_info info) {
+// mapPositions(handle) / mapQuats(handle) -> Float32Array over the handle's PINNED host buffer (zero copy);
+// refreshPositions / refreshQuats re-fill it (one DMA).  destroy(handle) detaches the buffer (the view reads as empty
+// afterwards); a view that outlives an undestroyed body keeps the handle alive until it is collected itself.
+template <int (*Api::*Fn)(tetsim_handle, const float**), napi_ref Box::*Slot, int Per, bool Tets>
+napi_value MapPinned(napi_env env, napi_callback_info info) {
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return nullptr;
-    tetsim_handle h = handle_of(env, a[0]);
-    if (!h) return nullptr;
+    Box* b = box_of(env, a[0]);
+    if (!b) return nullptr;
     const float* p = nullptr;
-    const int rc = g.read_positions_pinned(h, &p);
-    if (rc) return check(env, rc, h);
+    const int rc = (g.*Fn)(b->h, &p);
+    if (rc) return check(env, rc, b->h);
     TetSimInfo inf;
-    g.get_info(h, &inf);
+    g.get_info(b->h, &inf);
+    const size_t count = static_cast<size_t>(Per) * (Tets ? inf.local_elems : inf.owned_particles);
     napi_value ab, ta;
-    if (napi_create_external_arraybuffer(env, const_cast<float*>(p), sizeof(float) * 3 * inf.owned_particles, nullptr, nullptr, &ab) != napi_ok ||
-        napi_create_typedarray(env, napi_float32_array, 3 * inf.owned_particles, ab, 0, &ta) != napi_ok)
-        return throw_err(env, "cannot wrap the pinned buffer");
+    if (b->*Slot) {   // mapped before: hand out a view of the same ArrayBuffer
+        if (napi_get_reference_value(env, b->*Slot, &ab) != napi_ok || !ab) return throw_err(env, "the mapped buffer is gone");
+    } else {
+        if (napi_create_external_arraybuffer(env, const_cast<float*>(p), sizeof(float) * count, finalize_mapped, b, &ab) != napi_ok)
+            return throw_err(env, "cannot wrap the pinned buffer");
+        b->refs++;   // released by finalize_mapped
+        if (napi_create_reference(env, ab, 1, &(b->*Slot)) != napi_ok) return throw_err(env, "cannot reference the pinned buffer");
+    }
+    if (napi_create_typedarray(env, napi_float32_array, count, ab, 0, &ta) != napi_ok) return throw_err(env, "cannot wrap the pinned buffer");
     return ta;
 }
-napi_value RefreshPositions(napi_env env, napi_callback_info info) {
+template <int (*Api::*Fn)(tetsim_handle, const float**)>
+napi_value RefreshPinned(napi_env env, napi_callback_info info) {
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return nullptr;
     tetsim_handle h = handle_of(env, a[0]);
     if (!h) return nullptr;
     const float* p = nullptr;
-    return check(env, g.read_positions_pinned(h, &p), h);
+    return check(env, (g.*Fn)(h, &p), h);
+}
+// saveState(handle) -> Uint8Array (complete solver state)  /  loadState(handle, Uint8Array)
+napi_value SaveState(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    uint64_t n = 0;
+    int rc = g.state_size(h, &n);
+    if (rc) return check(env, rc, h);
+    void* data = nullptr; napi_value ab, out;
+    if (napi_create_arraybuffer(env, n, &data, &ab) != napi_ok) return throw_err(env, "cannot allocate the state buffer");
+    rc = g.save_state(h, data, n);
+    if (rc) return check(env, rc, h);
+    napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &out);
+    return out;
+}
+napi_value LoadState(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    uint8_t* blob; size_t n;
+    if (!typed_array(env, a[1], napi_uint8_array, &blob, &n)) return throw_err(env, "state must be the Uint8Array saveState() returned");
+    return check(env, g.load_state(h, blob, n), h);
+}
+// libraryInfo() -> { abi, ablation, sourceSha, kernelSha, debugEnv }
+napi_value LibraryInfo(napi_env env, napi_callback_info) {
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    TetSimLibraryInfo li;
+    const int rc = g.library_info(&li);
+    if (rc) return check(env, rc, nullptr);
+    napi_value o, v; napi_create_object(env, &o);
+    napi_create_int32(env, li.abi, &v); napi_set_named_property(env, o, "abi", v);
+    napi_get_boolean(env, li.ablation != 0, &v); napi_set_named_property(env, o, "ablation", v);
+    napi_create_string_utf8(env, li.source_sha, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "sourceSha", v);
+    napi_create_string_utf8(env, li.kernel_sha, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "kernelSha", v);
+    napi_create_uint32(env, li.debug_env, &v); napi_set_named_property(env, o, "debugEnv", v);
+    return o;
 }
 napi_value ReadVolError(napi_env env, napi_callback_info info) {
     napi_value a[1];
@@ -348,8 +457,12 @@ napi_value ReadVisualMesh(napi_env env, napi_callback_info info) {
     if (!h) return nullptr;
     float *po, *no = nullptr; size_t np = 0, nn = 0;
     if (!typed_array(env, a[1], napi_float32_array, &po, &np)) return throw_err(env, "positions output must be a Float32Array");
-    typed_array(env, a[2], napi_float32_array, &no, &nn);
-    return check(env, g.read_visual_mesh(h, po, nn ? no : nullptr), h);
+    const bool want_normals = typed_array(env, a[2], napi_float32_array, &no, &nn);
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    if (np < 3ull * inf.num_vis_verts) return throw_err(env, "positions output array too small (3 floats per visual vertex)");
+    if (want_normals && nn < 3ull * inf.num_vis_verts) return throw_err(env, "normals output array too small (3 floats per visual vertex)");
+    return check(env, g.read_visual_mesh(h, po, want_normals ? no : nullptr), h);
 }
 // setVisualTriangles(handle, Int32Array visTriIds)
 napi_value SetVisualTriangles(napi_env env, napi_callback_info info) {
@@ -369,6 +482,9 @@ napi_value ReadVisualVertexNormals(napi_env env, napi_callback_info info) {
     if (!h) return nullptr;
     float* no; size_t nn;
     if (!typed_array(env, a[1], napi_float32_array, &no, &nn)) return throw_err(env, "normals output must be a Float32Array");
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    if (nn < 3ull * inf.num_vis_verts) return throw_err(env, "normals output array too small (3 floats per visual vertex)");
     return check(env, g.read_visual_vertex_normals(h, no), h);
 }
 // setGrab(handle, id, x, y, z)
@@ -377,8 +493,10 @@ napi_value SetGrab(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 5, a)) return nullptr;
     tetsim_handle h = handle_of(env, a[0]);
     if (!h) return nullptr;
-    int32_t id; napi_get_value_int32(env, a[1], &id);
-    double x, y, z; napi_get_value_double(env, a[2], &x); napi_get_value_double(env, a[3], &y); napi_get_value_double(env, a[4], &z);
+    double idd, x, y, z;
+    if (!num_arg(env, a[1], &idd, "id") || !num_arg(env, a[2], &x, "x") || !num_arg(env, a[3], &y, "y") || !num_arg(env, a[4], &z, "z")) return nullptr;
+    if (!(idd >= -1.0) || idd > 2147483647.0 || idd != static_cast<double>(static_cast<int32_t>(idd))) return throw_err(env, "id must be a particle index or -1");
+    const int32_t id = static_cast<int32_t>(idd);
     const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
     return check(env, g.set_grab(h, id, p), h);
 }
@@ -388,7 +506,8 @@ napi_value StartGrab(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 4, a)) return nullptr;
     tetsim_handle h = handle_of(env, a[0]);
     if (!h) return nullptr;
-    double x, y, z; napi_get_value_double(env, a[1], &x); napi_get_value_double(env, a[2], &y); napi_get_value_double(env, a[3], &z);
+    double x, y, z;
+    if (!num_arg(env, a[1], &x, "x") || !num_arg(env, a[2], &y, "y") || !num_arg(env, a[3], &z, "z")) return nullptr;
     const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
     int32_t id = -1;
     const int rc = g.start_grab(h, p, &id);
@@ -414,7 +533,7 @@ napi_value CommInit(napi_env env, napi_callback_info info) {
     uint8_t* id; size_t n;
     if (!typed_array(env, a[1], napi_uint8_array, &id, &n) || n < 128) return throw_err(env, "id must be the Uint8Array(128) of commUniqueId()");
     double rank, nranks;
-    napi_get_value_double(env, a[2], &rank); napi_get_value_double(env, a[3], &nranks);
+    if (!num_arg(env, a[2], &rank, "rank") || !num_arg(env, a[3], &nranks, "nranks")) return nullptr;
     return check(env, g.comm_init(h, id, static_cast<int32_t>(rank), static_cast<int32_t>(nranks)), h);
 }
 // ownedIds(handle) -> Int32Array: global particle id of every row readPositions returns (partitioned bodies)
@@ -446,7 +565,7 @@ napi_value Info(napi_env env, napi_callback_info info) {
     set("localElems", inf.local_elems); set("numLevels", inf.num_levels); set("maxValence", inf.max_valence);
     set("droppedSlots", inf.dropped_slots); set("deviceBytes", static_cast<double>(inf.device_bytes));
     set("solver", inf.solver); set("precision", inf.precision); set("localParticles", inf.local_particles);
-    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours);
+    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours); set("numVisVerts", inf.num_vis_verts);
     return o;
 }
 
@@ -466,8 +585,13 @@ napi_value Init(napi_env env, napi_value exports) {
         {"readPositions", nullptr, ReadF32<&Api::read_positions, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVelocities", nullptr, ReadF32<&Api::read_velocities, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readQuats", nullptr, ReadF32<&Api::read_quats, 4, true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
-        {"mapPositions", nullptr, MapPositions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
-        {"refreshPositions", nullptr, RefreshPositions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"mapPositions", nullptr, MapPinned<&Api::read_positions_pinned, &Box::pos_ab, 3, false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"refreshPositions", nullptr, RefreshPinned<&Api::read_positions_pinned>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"mapQuats", nullptr, MapPinned<&Api::read_quats_pinned, &Box::quat_ab, 4, true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"refreshQuats", nullptr, RefreshPinned<&Api::read_quats_pinned>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"saveState", nullptr, SaveState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"loadState", nullptr, LoadState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"libraryInfo", nullptr, LibraryInfo, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

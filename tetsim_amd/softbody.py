@@ -111,7 +111,7 @@ class SoftBodyHIP:
         capi.check(L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
         self._L = L
         self.numVisVerts = 0
-        if visVerts is not None and len(visVerts):   # Softbody.js:46-47: rows (tetNr, b0, b1, b2)
+        if visVerts is not None and len(visVerts) and part_count <= 1:   # Softbody.js:46-47: rows (tetNr, b0, b1, b2); unpartitioned bodies only
             if mesh_file is not None:   # tetsim_create_from_file attached the stored visual mesh already
                 self.numVisVerts, self._has_normals = len(np.asarray(visVerts).reshape(-1)) // 4, False
             else:
@@ -361,6 +361,15 @@ def comm_unique_id():
 
 def comm_init(body, uid, rank, nranks):
     capi.check(capi.lib().tetsim_comm_init(body._h, bytes(uid), int(rank), int(nranks)), body._h)
+
+
+def comm_info(body):
+    """What RCCL reports for this body's communicator + the halo volume of this partition (include/tetsim.h TetSimCommInfo)."""
+    ci = capi.TetSimCommInfo()
+    capi.check(capi.lib().tetsim_comm_info(body._h, C.byref(ci)), body._h)
+    return {"rccl_ranks": ci.rccl_ranks, "rccl_rank": ci.rccl_rank, "neighbours": ci.neighbours,
+            "send_bytes_per_substep": ci.send_bytes_per_substep, "recv_bytes_per_substep": ci.recv_bytes_per_substep,
+            "max_message_bytes": ci.max_message_bytes, "loopback": bool(ci.loopback)}
 
 
 def comm_selftest(body):
