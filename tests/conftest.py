@@ -49,15 +49,36 @@ def case_dt(case):
     return (case["timeScale"] * case["timeStep"]) / case["numSubsteps"]  # f64, as main.js:79
 
 
+_TOL_TABLE = None
+
+
+def _tol_table():
+    global _TOL_TABLE
+    if _TOL_TABLE is None:
+        try:
+            with open(os.path.join(GOLDEN, "tolerances.json")) as f:
+                _TOL_TABLE = json.load(f)["checks"]
+        except FileNotFoundError:
+            _TOL_TABLE = {}
+    return _TOL_TABLE
+
+
 def within(label, err, tol):
-    """`err <= tol` with the observed and the allowed value in the failure message.  The rule for every tolerance in this
-    suite: allowed <= 3 x the error observed on MI355X when the tolerance was set (bit-exact cases excepted).
+    """`err <= allowed`, with the observed and the allowed value in the failure message.
+
+    The rule of this suite: allowed <= 3 x the error observed on MI355X when the check was calibrated.  `tol` is the bound
+    the test states (the horizon's worst case); tests/golden/tolerances.json holds, per label, the error observed in the
+    calibration run and 3 x that value -- the smaller of the two applies.  (Checks whose calibrated error is exactly 0 --
+    PRECISE against the oracle -- keep the stated bound: a few ulps of libm feedback, the most another libm could do.)
     TETSIM_RECORD_ERRORS=<file> turns a run into a calibration run: every check appends {"label", "observed", "allowed"} as a
-    JSON line and does not fail (tools/tolerance_report.py prints the table)."""
+    JSON line and does not fail; tools/tolerance_report.py prints the table and writes tolerances.json."""
     err, tol = float(err), float(tol)
     rec = os.environ.get("TETSIM_RECORD_ERRORS")
     if rec:
         with open(rec, "a") as f:
             f.write(json.dumps({"label": label, "observed": err, "allowed": tol}) + "\n")
         return
-    assert err <= tol, "%s: observed %.3g, allowed %.3g (%.1fx)" % (label, err, tol, err / tol if tol else float("inf"))
+    cal = _tol_table().get(label)
+    allowed = min(tol, cal["allowed"]) if cal and cal["allowed"] > 0 else tol
+    assert err <= allowed, "%s: observed %.3g, allowed %.3g (stated bound %.3g%s)" % (
+        label, err, allowed, tol, ", calibrated at %.3g" % cal["observed"] if cal else "")

@@ -52,7 +52,7 @@ def oracle_1m_polar(lattice_1m):
     return out
 
 
-@pytest.mark.parametrize("mode,tol1,tol20", [("precise", 1e-6, 5e-6), ("fast", 2e-6, 5e-5), ("fast-gather", 2e-6, 5e-5)])
+@pytest.mark.parametrize("mode,tol1,tol20", [("precise", 2.5e-7, 1e-6), ("fast", 4e-6, 2e-4), ("fast-gather", 4e-6, 5e-5)])
 def test_lattice_1m_polar_vs_oracle(mode, tol1, tol20, lattice_1m, oracle_1m_polar):
     """BASELINE config 3: free fall from 0.5 m (substeps 1 and 20), through tetsim_step and tetsim_step_n."""
     _, t = lattice_1m
@@ -66,11 +66,11 @@ def test_lattice_1m_polar_vs_oracle(mode, tol1, tol20, lattice_1m, oracle_1m_pol
     q = body.quats
     qq = np.empty_like(q)
     qq[body.localTets] = q
-    within("polar %s 1M lattice vs oracle @20 (quat)" % mode, np.abs(qq - ref[20][1]).max(), 1e-4)
+    within("polar %s 1M lattice vs oracle @20 (quat)" % mode, np.abs(qq - ref[20][1]).max(), 2.5e-7 if mode == "precise" else 1e-3)
     assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-5
 
 
-@pytest.mark.parametrize("mode,tol", [("precise", 1e-5), ("fast", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("precise", 1e-6), ("fast", 1e-4)])
 def test_lattice_1m_polar_floor_contact_vs_oracle(mode, tol, lattice_1m, oracle_1m_polar):
     """The same body dropped 0.5 mm onto the floor: 20 substeps with the bottom face in contact (clamp + friction branch of
     the particle pass on 3,136 particles, deformation in the tiles above it)."""
@@ -101,9 +101,15 @@ def test_lattice_1m_neohookean_bit_exact(order, lattice_1m):
             assert body.volError == orc.volError, (order, s)
     assert np.array_equal(body.vel.view(np.uint32), orc.vel.view(np.uint32))
     assert body.pos[:, 1].min() == 0.0
-    fast = SoftBodyHIP(vv, t, None, dict(PP), solver="neohookean", precision="fast", order=order)
+    # FAST (f32 + FMA + v_rcp / v_rsq) against the same oracle, in free fall: the floor branch (`y < 0` -> clamp + friction jump,
+    # Softbody.js:218-226) is a discontinuity that turns a last-ulp difference into a 1e-4 m one and would measure nothing
+    del orc
+    fast = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order=order)
+    orc = OracleNH(v, t[fast.tetOrder], PP)
     fast.simulateSubsteps(5, DT20, PP)
-    within("neo-hookean fast %s 1M lattice vs oracle @5" % order, np.abs(fast.pos - orc.pos).max(), 2e-5)
+    for _ in range(5):
+        orc.simulate(DT20, PP)
+    within("neo-hookean fast %s 1M lattice vs oracle @5 (free fall)" % order, np.abs(fast.pos - orc.pos).max(), 2e-5)
 
 
 def test_lattice_8m_polar_vs_oracle():
@@ -121,4 +127,4 @@ def test_lattice_8m_polar_vs_oracle():
         set_threads(1)
     body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
     body.simulateSubsteps(2, DT20, PP)
-    within("polar fast 8M lattice vs oracle @2", np.abs(body.pos - ref).max(), 2e-6)
+    within("polar fast 8M lattice vs oracle @2", np.abs(body.pos - ref).max(), 1e-5)

@@ -120,5 +120,14 @@ def build(force=False, verbose=False, ablation=False):
     return lib
 
 
+def build_variant(name, defines, force=False, verbose=False):
+    """Development: libtetsim_hip_<name>.so with extra -D flags (kernel experiments, A/B through TETSIM_HIP_LIB; tools/ab_lib.py)."""
+    return _build_one(os.path.join(HERE, "libtetsim_hip_%s.so" % name), os.path.join(CSRC, "obj_" + name), list(defines), force, verbose)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))
+    if "--variant" in sys.argv:   # python -m tetsim_amd.build --variant t128 -DTETSIM_TILE=128
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

@@ -97,7 +97,8 @@ struct tetsim_body {
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
     uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
-    uint32_t halo_seq = 0;              // substep sequence number of the flag-synchronised path
+    bool queues_probed = false, queues_independent = false;   // flag path: do the two streams run on independent hardware queues?
+    std::map<uint32_t, std::pair<hipGraphExec_t, hipGraphExec_t>> flag_graphs;   // n substeps -> (main chain, halo chain), replayed side by side
     uint32_t* d_sync = nullptr;         // device counters of the flag-synchronised halo path: G done/taken, V done/taken, error
     bool flag_sync = false;             // this body steps through the flag-synchronised path (blocked + transport)
     bool halo_graph_broken = false;
@@ -236,5 +237,7 @@ bool has_transport(const tetsim_body* h);
 bool uses_flag_sync(const tetsim_body* h);
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr);  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
 int enqueue_phase_b(tetsim_body* h);                            // halo start
+int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
+int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains
 
 }  // namespace tetsim

@@ -58,7 +58,8 @@ struct PJBlk {
     float4* quat = nullptr;                  // [nt]
     const uint32_t* lc_range = nullptr;      // per tile slot: first | end << 16 into the tile's entry list
     const uint2* lc_ent = nullptr;           // [nt] 4 x u16 per tet position: (tetLocal*4 + corner), grouped by slot
-    float4* partial = nullptr;               // per tile slot: (sum V*goal, sum V)
+    float4* partial = nullptr;               // per tile slot: sum V*goal over the slot's entries (w unused)
+    const float* wsum = nullptr;             // per owned particle: sum of V over all its entries -- constant, summed on the host in the device's order
     const uint32_t* vp_ell = nullptr;        // ELL [vp_cols][nv_pad]: partial-sum indices of each owned particle,
     uint32_t vp_cols = 0, nv_pad = 0;        //   ascending tile, 0xffffffff = none
     float4* pos_pred = nullptr;
@@ -111,17 +112,16 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
                     hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
-// Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `wait` / `signal` are device words holding the sequence number of
-// the last finished producer launch, `seq` = this substep.
+// Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores
+// 1 behind the producer kernel, wait spins until it is non-zero in front of the consumer kernel and clears it.  No per-launch
+// argument changes: the kernels can be replayed from a captured graph.
 struct PJSync {
-    const uint32_t* wait = nullptr;
-    uint32_t* signal = nullptr;
+    uint32_t* flag = nullptr;
     uint32_t* error = nullptr;
-    uint32_t seq = 0;
     uint32_t timeout_ms = 0;   // 0 = unbounded
 };
-void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await
-void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: publish seq
+void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await + clear
+void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: set
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_predict_fast(hipStream_t s, const NHDev& d);

@@ -367,7 +367,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
                   const Incidence& inc, BlockPlan* out) {
     BlockPlan& B = *out;
     B = BlockPlan();
-    constexpr uint32_t kMaxTets = 256, kMaxVerts = 256;
+    constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
     // 1. Morton order of rest centroids (quantised to 10 bits per axis over the bounding box)
     const Quantiser Q(verts, nv);
     std::vector<uint64_t> key(nt);
@@ -462,7 +462,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
             for (int k = 0; k < 4; k++)
                 if (live[4ull * B.tet_perm[t0 + j] + k]) {
                     const uint32_t u = B.tet_lidx[4ull * (t0 + j) + k];
-                    B.lc_ent[4ull * t0 + fillp[u]++] = static_cast<uint16_t>(256 * k + j);  // word offset into the [corner][tet] goal planes
+                    B.lc_ent[4ull * t0 + fillp[u]++] = static_cast<uint16_t>(kMaxTets * k + j);  // word offset into the [corner][tet] goal planes
                 }
         for (uint32_t u = 0; u < nu; u++) {
             const int32_t v = touched[u];

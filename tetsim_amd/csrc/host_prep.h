@@ -83,6 +83,10 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 // Workgroup tiling for the blocked POLAR_JACOBI formulation (DESIGN.md "Blocked formulation").
 // Tets are sorted along a Morton curve of their rest centroids and cut into tiles of <= 256 tets that touch
 // <= 256 distinct vertices, so a tile's vertex set fits an LDS tile addressed by 8-bit local indices.
+#ifndef TETSIM_TILE
+#define TETSIM_TILE 256
+#endif
+constexpr uint32_t kBlockTile = TETSIM_TILE;   // tets per workgroup tile of the blocked polar kernel (pj_blocked.hip kTile)
 struct BlockPlan {
     uint32_t num_blocks = 0;
     std::vector<int32_t> tet_perm;       // new tet position -> input tet index

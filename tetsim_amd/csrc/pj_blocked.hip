@@ -35,6 +35,7 @@
 
 #include "dev_common.h"
 #include "dev_store.h"
+#include "host_prep.h"
 
 namespace tetsim {
 namespace {
@@ -49,9 +50,9 @@ namespace {
 
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd) { return (b & 7u) * tiles_per_xcd + (b >> 3); }
 
-constexpr uint32_t kTile = 256;
+constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
-// LDS per workgroup is kept at 19 KB (4 + 12 + 1 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
+// LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
 // exist only in the separate development build (-DTETSIM_ABLATION -> libtetsim_hip_ablation.so, tools/ab_iters.py): there the
@@ -74,11 +75,14 @@ constexpr uint32_t kTile = 256;
 // cost the default path 12 register moves per tet at the join of the two variants.
 template <bool kLean>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+#ifdef TETSIM_VAR_POS_PLANES
+    __shared__ float s_px[kTile], s_py[kTile], s_pz[kTile];   // staged particle positions, one plane per component
+#else
     __shared__ float4 s_pos[kTile];        // staged particle positions
+#endif
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
     __shared__ float s_gz[4 * kTile];
-    __shared__ float s_v[kTile];           // V per tet
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
     const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
@@ -98,7 +102,12 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     // 1. stage the tile's particles; every global load of this lane is issued before the barrier
     uint32_t range = 0;
     if (tid < nu) {
-        s_pos[tid] = d.pos_pred[d.blk_verts[v0 + tid]];
+        const float4 p = d.pos_pred[d.blk_verts[v0 + tid]];
+#ifdef TETSIM_VAR_POS_PLANES
+        s_px[tid] = p.x; s_py[tid] = p.y; s_pz[tid] = p.z;
+#else
+        s_pos[tid] = p;
+#endif
         range = d.lc_range[v0 + tid];
     }
     const bool has_tet = tid < ntb;
@@ -125,7 +134,12 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     // 2. solve
     if (has_tet) {
         f3 cur[4], rest[4], goal[4];
+#ifdef TETSIM_VAR_POS_PLANES
+        cur[0] = F3(s_px[li.x], s_py[li.x], s_pz[li.x]); cur[1] = F3(s_px[li.y], s_py[li.y], s_pz[li.y]);
+        cur[2] = F3(s_px[li.z], s_py[li.z], s_pz[li.z]); cur[3] = F3(s_px[li.w], s_py[li.w], s_pz[li.w]);
+#else
         cur[0] = xyz(s_pos[li.x]); cur[1] = xyz(s_pos[li.y]); cur[2] = xyz(s_pos[li.z]); cur[3] = xyz(s_pos[li.w]);
+#endif
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
         float4 q_new;
@@ -143,7 +157,6 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             s_gy[k * kTile + tid] = fmaf(goal[k].y, V, vcc.y);
             s_gz[k * kTile + tid] = fmaf(goal[k].z, V, vcc.z);
         }
-        s_v[tid] = V;
         store_wt(d.quat, e, q_new);
         if (!kLean && TETSIM_DBG_STORE_REST) {  // constant-rest-shape bodies never write the shape back
             store_wt(d.rest_a, e, make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
@@ -165,24 +178,24 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         // dependent LDS round trips: 4.9k cycles per tile in the s_memtime trace); whole groups of 4 run unmasked, the
         // 0-3 left over one by one.  Accumulation order stays entry order, i.e. deterministic.
         auto plane = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+        // The weight sum of a particle (sum of V over its entries, then over its tiles) never changes -- rest volumes are
+        // constants -- so it is not reduced here at all: the host adds it up once, in this very order (tetsim_create.hip ->
+        // PJBlk::wsum), and the particle pass reads it.  Three planes per entry instead of four.
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint32_t i = first;
         for (; i + 4u <= last; i += 4u) {
             uint32_t o[4];
-            float gx[4], gy[4], gz[4], gv[4];
+            float gx[4], gy[4], gz[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4u; j++) o[j] = static_cast<uint32_t>(ent[i + j]) << 2;
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
-                gx[j] = plane(s_gx, o[j]); gy[j] = plane(s_gy, o[j]); gz[j] = plane(s_gz, o[j]);
-                gv[j] = plane(s_v, o[j] & (4u * kTile - 4u));
-            }
+            for (uint32_t j = 0; j < 4u; j++) { gx[j] = plane(s_gx, o[j]); gy[j] = plane(s_gy, o[j]); gz[j] = plane(s_gz, o[j]); }
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; acc.w += gv[j]; }
+            for (uint32_t j = 0; j < 4u; j++) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; }
         }
         for (; i < last; i++) {
             const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
-            acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o); acc.w += plane(s_v, o & (4u * kTile - 4u));
+            acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
         }
         store_wt(d.partial, v0 + tid, acc);
     }
@@ -190,11 +203,11 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 #undef TETSIM_STAMP
 }
 
-__global__ __launch_bounds__(256, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                         uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
-__global__ __launch_bounds__(256, 2) void pjb_tet_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
@@ -206,22 +219,28 @@ __global__ __launch_bounds__(256, 2) void pjb_tet_kernel_constant_rest(PJBlk d, 
 // has two of them.  Here the producer queue runs a ONE-WAVE signal kernel behind its kernel (in-order queue: the kernel and
 // its agent-scope release are complete) and the consumer queue a one-wave wait kernel in front of the dependent kernel (whose
 // own start then performs the agent-scope acquire): ~5 us each under load, nothing else in either queue is delayed.
-// `seq` = the substep's sequence number, so a word is never reset.  The wait is bounded (timeout_ms, 30 s by default; then *error is raised and it
-// carries on): a wedged peer must not wedge this GPU.  The host submits every signal before the matching wait, so even a
-// single shared hardware queue stays live.
+// The word is a BINARY SEMAPHORE: signal stores 1, wait spins until it reads non-zero and stores 0 again.  That needs no
+// sequence number -- the dependency cycle itself makes producer and consumer alternate strictly (the next signal of a word is
+// behind the completion of the wait that consumed the previous one) -- so both kernels take CONSTANT arguments and the two
+// queues' chains can be replayed from captured graphs (tetsim_step_n; a per-launch sequence number was what kept this path
+// eager, and a counter kept in device memory cost two more memory round trips per hand-over).
+// The wait is bounded (timeout_ms, 30 s by default; then *error is raised and it carries on): a wedged peer must not wedge
+// this GPU.  The host submits every signal before the matching wait, so even a single shared hardware queue stays live in
+// eager mode (graph replay is only used when a probe at set-up found the two streams on independent hardware queues).
 // Tried and dropped: the hand-over inside the compute kernels (last-workgroup detection / every workgroup polling on entry).
 // Any per-workgroup device-scope atomic -- read-modify-write or load, one word or 64 words a cache line apart -- costs
 // ~20 ns and serialises: the 2,744-workgroup particle pass went from 7 us to 60-400 us.
 __device__ __forceinline__ void await_done(const PJSync& y) {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64(), limit = 100000ll * y.timeout_ms;   // 100 MHz ticks
-        while (static_cast<int32_t>(__hip_atomic_load(y.wait, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - y.seq) < 0) {
+        while (__hip_atomic_load(y.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(4);
             if (limit && wall_clock64() - t0 > limit) {
                 __hip_atomic_store(y.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
+                return;
             }
         }
+        __hip_atomic_store(y.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed
     }
 }
 
@@ -247,10 +266,11 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w; }
+        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
         if (__all(idx[7] == 0xffffffffu)) break;  // lists are front-packed: nobody in this wave has a ninth partial
     }
-    const float rw = __builtin_amdgcn_rcpf(acc.w);
+    // sum of the rest volumes of the particle's (live) corners: a constant, added up on the host in the tiles' entry order
+    const float rw = __builtin_amdgcn_rcpf(d.wsum[v]);
     f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
 
     // P6, :340-355
@@ -279,7 +299,7 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
 __global__ void pjb_wait_kernel(PJSync y) { await_done(y); }
-__global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.signal, y.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -310,8 +330,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     if (tile_count == 0) return;
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
-    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(256), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }

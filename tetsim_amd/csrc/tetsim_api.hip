@@ -160,7 +160,7 @@ int ensure_prediction(tetsim_body* h, double dt) {
         if (has_transport(h)) {
             if (h->flag_sync) {  // the halo stream continues only after the new predictions exist: publish / await one more sequence number
                 PJSync y;
-                y.wait = h->d_sync + 2; y.signal = h->d_sync + 2; y.error = h->d_sync + 4; y.seq = ++h->halo_seq; y.timeout_ms = halo_timeout_ms();
+                y.flag = h->d_sync + 2; y.error = h->d_sync + 4; y.timeout_ms = halo_timeout_ms();
                 pjb_launch_signal(h->stream, y);
                 pjb_launch_wait(h->comm_stream, y);
             }
@@ -346,6 +346,8 @@ void tetsim_destroy(tetsim_handle h) {
     // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
+    for (auto& kv : h->flag_graphs) { (void)hipGraphExecDestroy(kv.second.first); (void)hipGraphExecDestroy(kv.second.second); }
+    h->flag_graphs.clear();
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -390,7 +392,20 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
         // critical path.  TETSIM_HALO_GRAPH=0 keeps everything eager.
         static const bool use_graph = [] { const char* e = getenv("TETSIM_HALO_GRAPH"); return !(e && e[0] == '0'); }();
-        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {  // (the flag path is eager by design)
+        if (h->comm && use_graph && h->halo_warm && !h->halo_graph_broken && uses_flag_sync(h)) {
+            // flag path: the two streams' chains as two captured linear graphs, replayed side by side -- if the streams are served
+            // by independent hardware queues (probed once) and the chains can be captured (else: eager for good, loudly)
+            if ((rc = probe_queue_independence(h))) return rc;
+            if (h->queues_independent) {
+                rc = step_n_flag_graphs(h, n);
+                if (!rc) return 0;
+                fprintf(stderr, "[tetsim] halo graph capture failed (%s); falling back to eager halo stepping\n", h->err.c_str());
+                h->halo_graph_broken = true;
+                (void)hipGetLastError();
+                rc = 0;
+            }
+        }
+        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {
             for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
             h->halo_warm = true;
             return rc;

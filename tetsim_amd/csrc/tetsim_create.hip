@@ -140,6 +140,34 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const uint16_t* en = &B.lc_ent[4ull * i];
             lceh[i] = make_uint2(en[0] | (static_cast<uint32_t>(en[1]) << 16), en[2] | (static_cast<uint32_t>(en[3]) << 16));
         }
+        // Weight sums (PJBlk::wsum): rest volumes are constants, so the denominator of the volume-weighted average
+        // (SoftbodyGPU.js:306-319) is added up HERE, once, in exactly the order the kernels add the numerator: a tile slot's
+        // entries in entry order, then the particle's tile partial sums in ascending tile order, f32 throughout.
+        std::vector<float> wsum(std::max<size_t>(B.nv_pad, 1), 0.0f);
+        {
+            std::vector<float> slot_w(nslots, 0.0f);
+            for (uint32_t b = 0; b < B.num_blocks; b++) {
+                const uint32_t t0 = B.blk_tet_off[b], v0 = B.blk_vert_off[b], nu = B.blk_vert_off[b + 1] - v0;
+                for (uint32_t u = 0; u < nu; u++) {
+                    const uint32_t first = B.lc_range[v0 + u] & 0xffffu, last = B.lc_range[v0 + u] >> 16;
+                    float w = 0.0f;
+                    for (uint32_t i = first; i < last; i++) w += volh[t0 + (B.lc_ent[4ull * t0 + i] % kBlockTile)];
+                    slot_w[v0 + u] = w;
+                }
+            }
+            for (uint32_t v = 0; v < nvo; v++) {
+                float w = 0.0f;
+                for (uint32_t j = 0; j < B.max_partials; j++) {
+                    const uint32_t idx = B.vp_ell[static_cast<size_t>(j) * B.nv_pad + v];
+                    if (idx != 0xffffffffu) w += slot_w[idx];
+                }
+                wsum[v] = w;
+            }
+        }
+        float* dws;
+        if ((rc = dev_alloc(h, &dws, wsum.size()))) return rc;
+        if ((rc = upload(h, dws, wsum))) return rc;
+        k.wsum = dws;
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
         if ((rc = upload(h, bv, B.blk_verts))) return rc;

@@ -135,10 +135,9 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 HIPCHK(h, hipDeviceSynchronize());   // once: the halo stream must also see everything create() uploaded
             }
             h->flag_sync = true;
-            const uint32_t seq = ++h->halo_seq;
-            PJSync yg, yv;   // word 0: "G tiles of substep seq are done"; word 2: "particles of substep seq are done"
-            yg.wait = yg.signal = h->d_sync + 0; yg.error = h->d_sync + 4; yg.seq = seq; yg.timeout_ms = halo_timeout_ms();
-            yv.wait = yv.signal = h->d_sync + 2; yv.error = h->d_sync + 4; yv.seq = seq; yv.timeout_ms = yg.timeout_ms;
+            PJSync yg, yv;   // word 0: "the G tiles of this substep are done"; word 2: "the particles of this substep are done"
+            yg.flag = h->d_sync + 0; yg.error = h->d_sync + 4; yg.timeout_ms = halo_timeout_ms();
+            yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = yg.timeout_ms;
             int rc = halo_wait(h, h->comm_stream);   // in-process groups: the neighbours' transfers of the previous substep (events)
             if (rc) return rc;
             { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
@@ -192,6 +191,65 @@ int enqueue_phase_b(tetsim_body* h) {  // halo start
     int rc = halo_start(h);
     if (rc) return rc;
     h->halo_parity ^= 1u;
+    return 0;
+}
+
+// The flag path's two chains wait for each other through device words, so replaying them from graphs is only live if the two
+// streams are served by independent hardware queues (a wait kernel at the head of one queue must not block the signal kernel
+// that sits in the other).  Probe it once: a bounded wait on the halo stream, submitted BEFORE its signal on the main stream.
+int probe_queue_independence(tetsim_body* h) {
+    if (h->queues_probed) return 0;
+    h->queues_probed = true;
+    if (!h->d_sync || !h->comm_stream) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    PJSync y;
+    y.flag = h->d_sync + 6; y.error = h->d_sync + 7; y.timeout_ms = 200;
+    HIPCHK(h, hipMemset(h->d_sync + 6, 0, 2 * sizeof(uint32_t)));
+    pjb_launch_wait(h->comm_stream, y);
+    pjb_launch_signal(h->stream, y);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    uint32_t w[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(w, h->d_sync + 6, sizeof w, hipMemcpyDeviceToHost));
+    h->queues_independent = w[1] == 0u;
+    if (!h->queues_independent) {
+        fprintf(stderr, "[tetsim] the halo stream and the main stream share a hardware queue: the halo path stays eager (no graph replay)\n");
+        HIPCHK(h, hipMemset(h->d_sync + 6, 0, 2 * sizeof(uint32_t)));
+    }
+    return 0;
+}
+
+// n substeps of an RCCL body on the flag path as TWO captured linear chains, one per stream, replayed side by side:
+//   main:  [interior tiles -> wait G -> particles -> signal V] x n          halo:  [G tiles -> signal G -> wait V -> transfer] x n
+// No fork/join edge exists between them (those cost ~6 us each inside a graph on this stack): the chains meet only through the
+// binary-semaphore words, whose kernels take constant arguments.  Inside a chain a kernel boundary costs 1.6 us instead of the
+// 2.7 us of an eager launch, and the host enqueues two graph launches per call instead of 9 operations per substep.
+int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
+    auto it = h->flag_graphs.find(n);
+    if (it == h->flag_graphs.end()) {
+        hipGraph_t gm = nullptr, gh = nullptr;
+        hipGraphExec_t em = nullptr, eh = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipStreamBeginCapture(h->comm_stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { (void)hipStreamEndCapture(h->stream, &gm); if (gm) (void)hipGraphDestroy(gm); return fail(h, TETSIM_EHIP, std::string("begin capture (halo stream): ") + hipGetErrorString(e)); }
+        int rc = 0;
+        for (uint32_t i = 0; i < n && !rc; i++) {
+            rc = enqueue_phase_a(h);
+            if (!rc) rc = enqueue_phase_b(h);
+        }
+        const hipError_t e1 = hipStreamEndCapture(h->stream, &gm), e2 = hipStreamEndCapture(h->comm_stream, &gh);
+        if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(h, TETSIM_EHIP, std::string("end capture: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        if (!rc && hipGraphInstantiate(&em, gm, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "graph instantiate (main chain) failed");
+        if (!rc && hipGraphInstantiate(&eh, gh, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "graph instantiate (halo chain) failed");
+        if (gm) (void)hipGraphDestroy(gm);
+        if (gh) (void)hipGraphDestroy(gh);
+        if (rc) { if (em) (void)hipGraphExecDestroy(em); if (eh) (void)hipGraphExecDestroy(eh); return rc; }
+        it = h->flag_graphs.emplace(n, std::make_pair(em, eh)).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second.second, h->comm_stream));
+    HIPCHK(h, hipGraphLaunch(it->second.first, h->stream));
+    h->halo_pending = true;
     return 0;
 }
 

@@ -1,9 +1,23 @@
-"""In-session A/B of two builds of libtetsim_hip.so through bench.py (alternating runs):  python tools/ab_lib.py libA.so libB.so"""
-import json, os, subprocess, sys
-libs = sys.argv[1:3]
+"""In-session A/B of several builds of libtetsim_hip.so through bench.py (alternating runs, 3 rounds):
+    python tools/ab_lib.py libA.so libB.so [libC.so ...] [-- extra bench args]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:]
+extra = args[args.index("--") + 1:] if "--" in args else []
+libs = args[:args.index("--")] if "--" in args else args
 for rep in range(3):
     for lib in libs:
-        env = dict(os.environ); env["TETSIM_HIP_LIB"] = os.path.abspath(lib)
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True).stdout
-        d = json.loads(out.strip().splitlines()[-1])
-        print("%-28s value %.1f  ms/frame %.4f  tet %.2f us  vertex %.2f us  frac %.3f" % (os.path.basename(lib), d["value"], d["ms_per_step"], d["roofline"]["kernel_us"], d["roofline"]["vertex_kernel_us"], d["roofline"]["frac"]), flush=True)
+        env = dict(os.environ, TETSIM_HIP_LIB=os.path.abspath(lib))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"] + extra,
+                             env=env, capture_output=True, text=True)
+        try:
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            print("%-32s FAILED: %s" % (os.path.basename(lib), out.stderr[-300:]), flush=True)
+            continue
+        r = d["roofline"]
+        print("%-32s value %.1f  ms/frame %.4f  tet %.2f us  vertex %.2f us  frac %.3f" % (os.path.basename(lib), d["value"], d["ms_per_step"], r["kernel_us"], r["vertex_kernel_us"], r["frac"]), flush=True)

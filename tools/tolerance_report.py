@@ -1,33 +1,46 @@
 #!/usr/bin/env python3
-"""Table of a tolerance-calibration run:  TETSIM_RECORD_ERRORS=f.jsonl python -m pytest tests -m gpu ; python tools/tolerance_report.py f.jsonl
+"""Table of a tolerance-calibration run, and the committed calibration file.
 
-Per label: the largest observed error, the allowed value, their ratio, and the tolerance the <= 3 x rule suggests (observed x 3
-rounded up to 1 / 2 / 5 x 10^k).  Labels whose allowed value exceeds 3 x the observed one are marked LOOSE."""
+    TETSIM_RECORD_ERRORS=$PWD/errors.jsonl python -m pytest tests -m gpu     (on the GPU box: checks record instead of failing)
+    python tools/tolerance_report.py errors.jsonl [--write tests/golden/tolerances.json]
+
+Per label: the largest observed error, the bound the test states, and 3 x observed (rounded UP to two significant digits) --
+the value tests/conftest.py:within() enforces once written.  Labels whose observed error exceeds the stated bound are marked FAIL."""
 import json
 import math
 import sys
 from collections import OrderedDict
 
-rows = OrderedDict()
-for line in open(sys.argv[1]):
-    r = json.loads(line)
-    k = r["label"]
-    if k not in rows or r["observed"] > rows[k]["observed"]:
-        rows[k] = r
 
-
-def nice(x):
+def three_times(x):
     if x <= 0:
         return 0.0
-    e = math.floor(math.log10(x))
-    for m in (1, 2, 5, 10):
-        if m * 10 ** e >= x * (1 - 1e-12):
-            return m * 10 ** e
+    y = 3.0 * x
+    e = math.floor(math.log10(y)) - 1
+    return float("%.6g" % (math.ceil(y / 10 ** e - 1e-9) * 10 ** e))
 
 
-print("%-78s %10s %10s %7s %10s" % ("check", "observed", "allowed", "ratio", "3x rule"))
-for k, r in rows.items():
-    o, a = r["observed"], r["allowed"]
-    ratio = a / o if o > 0 else float("inf")
-    flag = "" if o == 0 or ratio <= 3.0 + 1e-9 else "  LOOSE" if o <= a else "  FAIL"
-    print("%-78s %10.3g %10.3g %7.1f %10.3g%s" % (k[:78], o, a, ratio, nice(3 * o), flag))
+def main():
+    rows = OrderedDict()
+    for line in open(sys.argv[1]):
+        r = json.loads(line)
+        k = r["label"]
+        if k not in rows or r["observed"] > rows[k]["observed"]:
+            rows[k] = r
+    print("%-84s %10s %10s %10s" % ("check", "observed", "stated", "3x observed"))
+    for k, r in rows.items():
+        o, a = r["observed"], r["allowed"]
+        print("%-84s %10.3g %10.3g %10.3g%s" % (k[:84], o, a, three_times(o), "  FAIL (above the stated bound)" if o > a else ""))
+    if "--write" in sys.argv:
+        path = sys.argv[sys.argv.index("--write") + 1]
+        out = {"_how": "tools/tolerance_report.py from a TETSIM_RECORD_ERRORS calibration run of `pytest -m gpu` on MI355X; "
+                       "allowed = 3 x observed rounded up to 2 digits, capped by the bound the test states; observed 0 keeps the stated bound",
+               "checks": OrderedDict((k, {"observed": r["observed"], "allowed": min(three_times(r["observed"]), r["allowed"]) if r["observed"] > 0 else 0.0,
+                                          "stated": r["allowed"]}) for k, r in rows.items())}
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote", path, "(%d checks)" % len(rows))
+
+
+if __name__ == "__main__":
+    main()
