@@ -31,7 +31,7 @@
 namespace tetsim {
 
 constexpr int kRing = 64;  // pinned parameter slots in flight
-// device words of the flag-synchronised halo path: [0] G flag, [2] V flag, [4] error
+// device words of the flag-synchronised halo path (binary semaphores): [0] G, [2] V, [3] re-prediction after a dt change, [4] error, [6] [7] queue probe
 constexpr uint32_t kSyncWords = 8;
 
 // ---- RCCL, resolved at run time so single-GPU hosts (and the N-API addon) do not need librccl ----------

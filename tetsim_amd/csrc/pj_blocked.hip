@@ -16,6 +16,9 @@
 //   pjb_vertex_kernel  one lane per particle: adds the 1..9 (2.9 on average) partial sums of the tiles that touch
 //        it instead of gathering ~23 goals, then collides / integrates exactly like the gather formulation.
 //
+// Tried and dropped in round 2 (profiles/r02b_kernel_variants.txt): the staged positions as three f32 planes instead of float4
+// (12 ds_read_b32 instead of 4 ds_read_b128 per tet: 29.5 vs 29.0 us), and 128-tet tiles (-DTETSIM_TILE=128: 16 workgroups per
+// CU, tet kernel 28.3-30.5 us against 29.0, but 15% more partial sums: particle pass 6.5 vs 5.8 us, no gain overall).
 // Tried and dropped (measured on the 1 M-tet lattice): (a) a persistent variant prefetching tile i+1
 // during tile i's solve, with scalar tile headers, a 3-deep index pipeline, a peeled first trip and counted
 // vmcnt waits: 49 us vs 42-44 us, its 0-iteration base is already slower (32.5 vs 28.5 us); (b) having the particle
@@ -75,11 +78,7 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 // cost the default path 12 register moves per tet at the join of the two variants.
 template <bool kLean>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-#ifdef TETSIM_VAR_POS_PLANES
-    __shared__ float s_px[kTile], s_py[kTile], s_pz[kTile];   // staged particle positions, one plane per component
-#else
     __shared__ float4 s_pos[kTile];        // staged particle positions
-#endif
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
     __shared__ float s_gz[4 * kTile];
@@ -102,12 +101,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     // 1. stage the tile's particles; every global load of this lane is issued before the barrier
     uint32_t range = 0;
     if (tid < nu) {
-        const float4 p = d.pos_pred[d.blk_verts[v0 + tid]];
-#ifdef TETSIM_VAR_POS_PLANES
-        s_px[tid] = p.x; s_py[tid] = p.y; s_pz[tid] = p.z;
-#else
-        s_pos[tid] = p;
-#endif
+        s_pos[tid] = d.pos_pred[d.blk_verts[v0 + tid]];
         range = d.lc_range[v0 + tid];
     }
     const bool has_tet = tid < ntb;
@@ -134,12 +128,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     // 2. solve
     if (has_tet) {
         f3 cur[4], rest[4], goal[4];
-#ifdef TETSIM_VAR_POS_PLANES
-        cur[0] = F3(s_px[li.x], s_py[li.x], s_pz[li.x]); cur[1] = F3(s_px[li.y], s_py[li.y], s_pz[li.y]);
-        cur[2] = F3(s_px[li.z], s_py[li.z], s_pz[li.z]); cur[3] = F3(s_px[li.w], s_py[li.w], s_pz[li.w]);
-#else
         cur[0] = xyz(s_pos[li.x]); cur[1] = xyz(s_pos[li.y]); cur[2] = xyz(s_pos[li.z]); cur[3] = xyz(s_pos[li.w]);
-#endif
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
         float4 q_new;

@@ -158,9 +158,14 @@ int ensure_prediction(tetsim_body* h, double dt) {
         // same dt change, so every rank does this).  RCCL bodies do it here; an in-process group does it for all its members
         // in tetsim_group_step_n (a copy waits for the RECEIVER's event, so all records must precede all copies).
         if (has_transport(h)) {
-            if (h->flag_sync) {  // the halo stream continues only after the new predictions exist: publish / await one more sequence number
+            if (h->flag_sync) {
+                // the halo stream continues only after the new predictions exist: one more hand-over, through a word of its OWN.
+                // (The regular V word is a binary semaphore whose producer and consumer alternate because the substep's dependency
+                // cycle forces them to; this extra signal has no such back-edge -- it could land on a V that the halo stream has
+                // not consumed yet, and the two would collapse into one.  Between two uses of this word lies at least one whole
+                // substep, whose G hand-over orders them.)
                 PJSync y;
-                y.flag = h->d_sync + 2; y.error = h->d_sync + 4; y.timeout_ms = halo_timeout_ms();
+                y.flag = h->d_sync + 3; y.error = h->d_sync + 4; y.timeout_ms = halo_timeout_ms();
                 pjb_launch_signal(h->stream, y);
                 pjb_launch_wait(h->comm_stream, y);
             }
