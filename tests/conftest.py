@@ -69,7 +69,8 @@ def within(label, err, tol):
     The rule of this suite: allowed <= 3 x the error observed on MI355X when the check was calibrated.  `tol` is the bound
     the test states (the horizon's worst case); tests/golden/tolerances.json holds, per label, the error observed in the
     calibration run and 3 x that value -- the smaller of the two applies.  (Checks whose calibrated error is exactly 0 --
-    PRECISE against the oracle -- keep the stated bound: a few ulps of libm feedback, the most another libm could do.)
+    results bit-identical to the oracle or to the reference's own output -- get an ulp-level bound instead: 1.2e-7 for unit
+    quaternions, 2.5e-7 for positions, 1e-6 for velocities; tools/tolerance_report.py.)
     TETSIM_RECORD_ERRORS=<file> turns a run into a calibration run: every check appends {"label", "observed", "allowed"} as a
     JSON line and does not fail; tools/tolerance_report.py prints the table and writes tolerances.json."""
     err, tol = float(err), float(tol)

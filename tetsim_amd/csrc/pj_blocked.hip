@@ -98,24 +98,27 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
 
-    // 1. stage the tile's particles; every global load of this lane is issued before the barrier
-    uint32_t range = 0;
-    if (tid < nu) {
-        s_pos[tid] = d.pos_pred[d.blk_verts[v0 + tid]];
-        range = d.lc_range[v0 + tid];
-    }
-    const bool has_tet = tid < ntb;
-    const uint32_t e = t0 + (has_tet ? tid : 0u);
-    uchar4 li = make_uchar4(0, 0, 0, 0);
-    float4 ra, rb, rc, q_old;
-    float V = 0.0f;
-    if (has_tet) {
-        li = d.tet_lidx[e];
-        ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e];
-        q_old = d.quat[e];
-        V = d.vol[e];
-        s_ent[tid] = d.lc_ent[e];
-    }
+    // 1. stage the tile's particles.  Order of ISSUE matters: the particle gather is a dependent pair (slot -> particle id ->
+    // position) and the tet record is independent of it, so the ids are requested first, then the whole tet record, and only
+    // then the positions (which wait for the ids alone: vmcnt is in order, the tet loads stay in flight) -- two memory round
+    // trips per tile.  Written in source order "gather, then tet record" the compiler has to finish the gather (its LDS store
+    // needs the data) before it may issue the tet loads: three round trips, the load phase being a third of a tile's life.
+    // All of it is issued UNCONDITIONALLY, lanes without a slot / without a tet re-reading element 0 of the tile (one
+    // request per wave, results unused): with the loads inside `if`s the wait-count pass sees paths with different numbers of
+    // loads in flight and, at the join, waits for the position gather's operand with the most conservative count -- which
+    // lets (almost) the whole tet record land first, i.e. serialises the round trips again.
+    const bool has_slot = tid < nu, has_tet = tid < ntb;
+    const uint32_t slot = v0 + (has_slot ? tid : 0u), e = t0 + (has_tet ? tid : 0u);
+    const uint32_t vid = static_cast<uint32_t>(d.blk_verts[slot]);   // (unsigned: no sign extension right behind the load)
+    const uint32_t range = has_slot ? d.lc_range[slot] : 0u;
+    const uchar4 li = d.tet_lidx[e];
+    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
+    const float4 q_old = d.quat[e];
+    const float V = d.vol[e];
+    const uint2 ent_row = d.lc_ent[e];
+    const float4 pos_stage = d.pos_pred[vid];
+    if (has_slot) s_pos[tid] = pos_stage;
+    if (has_tet) s_ent[tid] = ent_row;
     TETSIM_STAMP(1);  // loads issued (and landed, for this wave)
     // Every load above has been consumed by now on the path that has tets; say so for ALL paths.  Without this, the
     // wait-count model keeps "load into v[..] pending" alive through the path that skips the solve, and protects the reuse
