@@ -138,6 +138,7 @@ typedef struct TetSimInfo {
     int32_t solver, precision, order, device;
     uint32_t flags;
     uint32_t num_vis_verts;      /* visual vertices attached by tetsim_set_visual_mesh / a .tetsim file (0 = none); since ABI 3 */
+    uint32_t num_bodies;         /* independent bodies behind this handle (tetsim_create_batch), 1 otherwise; since ABI 3 */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
@@ -164,6 +165,18 @@ void tetsim_default_params(TetSimParams *p);
  * data / tables on the host, uploads.  verts = [3*nv] xyz, tets = [4*nt] vertex ids. */
 int tetsim_create(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt,
                   const TetSimOptions *opts, tetsim_handle *out);
+/* Several INDEPENDENT bodies behind one handle (the reference steps `softBodies[]` one after the other, main.js:80-84): body b is
+ * (verts[b], nv[b], tets[b], nt[b]); the handle's particles / tets are their concatenation (tetsim_get_batch_layout gives the
+ * ranges) and every other entry point works on that concatenation -- one tetsim_step_n steps all bodies with ONE launch per
+ * kernel: a Dragon-sized body alone fills 15 of the chip's 2,048 workgroup slots, sixty-four of them 960.  All bodies share
+ * physicsParams; tetsim_set_grab addresses a particle of the concatenation.  Each body's results equal its solo run BIT FOR BIT
+ * (both solvers, both precisions): tiles never span two bodies and are cut per body exactly as for a body alone, the
+ * reference's slot-table quirk applies to every body's own first tet, Gauss-Seidel schedules of disjoint bodies are independent
+ * (tetsim_get_tet_order then refers to the concatenation).  Unpartitioned only. */
+int tetsim_create_batch(const float *const *verts, const uint32_t *nv, const int32_t *const *tets, const uint32_t *nt,
+                        uint32_t count, const TetSimOptions *opts, tetsim_handle *out);
+/* first_particle / first_elem [num_bodies + 1]: body b owns particles [first_particle[b], first_particle[b+1]) of the handle. */
+int tetsim_get_batch_layout(tetsim_handle h, uint32_t *first_particle, uint32_t *first_elem);
 void tetsim_destroy(tetsim_handle h);
 
 /* Text of the last error on this handle (h == NULL: last error of a failed create on this thread). */

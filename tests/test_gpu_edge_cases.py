@@ -248,3 +248,59 @@ def test_partitioned_body_ignores_the_visual_mesh(tmp_path):
     assert part2.info.num_vis_verts == 0 and np.isfinite(part2.pos).all()
     whole = SoftBodyHIP.fromFile(path, dict(PP), solver="polar", precision="fast")
     assert whole.info.num_vis_verts == len(vis) // 4
+
+
+@pytest.mark.parametrize("kw", [dict(solver="polar", precision="precise"), dict(solver="polar", precision="fast"),
+                                dict(solver="polar", precision="fast", gather=True), dict(solver="polar", precision="fast", constant_rest_shape=True),
+                                dict(solver="neohookean", precision="precise", order="original"), dict(solver="neohookean", precision="precise", order="coloured"),
+                                dict(solver="neohookean", precision="precise", order="clustered"), dict(solver="neohookean", precision="fast", order="clustered")])
+def test_batch_of_bodies_equals_solo_runs_bit_for_bit(kw):
+    """tetsim_create_batch: several independent bodies behind one handle, one launch per kernel for all of them.  Each body's
+    positions and velocities must equal its solo run bit for bit -- different meshes in one batch, floor contact included,
+    through tetsim_step and tetsim_step_n."""
+    meshes = []
+    for name, dy in (("dragon", 0.0), ("lat4", 0.0), ("hub", -0.35), ("dragon", -0.8), ("lat4", 0.3)):
+        v, t = load_mesh(name)
+        v = v.copy()
+        v[:, 1] += np.float32(dy)       # the second dragon starts closer to the floor: contact within the run
+        meshes.append((v, t))
+    dt = DT if kw["solver"] == "polar" else DT * 2
+    batch = SoftBodyHIP.batch(meshes, dict(PP), **kw)
+    assert batch.info.num_bodies == len(meshes) and batch.info.num_particles == sum(len(v) for v, _ in meshes)
+    solos = [SoftBodyHIP(v, t, None, dict(PP), **kw) for v, t in meshes]
+    for body in [batch] + solos:
+        body.simulateSubsteps(40, dt, PP)
+        for _ in range(5):
+            body.simulate(dt, PP)
+        body.simulateSubsteps(40, dt, PP)
+    pos, vel = batch.pos, batch.vel
+    ranges = batch.bodyRanges
+    assert [r[0][1] - r[0][0] for r in ranges] == [len(v) for v, _ in meshes] and [r[1][1] - r[1][0] for r in ranges] == [len(t) for _, t in meshes]
+    for (prange, _), solo in zip(ranges, solos):
+        assert np.array_equal(pos[prange[0]:prange[1]].view(np.uint32), solo.pos.view(np.uint32))
+        assert np.array_equal(vel[prange[0]:prange[1]].view(np.uint32), solo.vel.view(np.uint32))
+    assert pos[:, 1].min() == 0.0          # somebody is on the floor
+    if kw["solver"] == "polar":
+        assert batch.info.dropped_slots == sum(s.info.dropped_slots for s in solos)   # the slot-table quirk, once per body
+    with pytest.raises(TetSimError, match="partitioned"):
+        SoftBodyHIP.batch(meshes, dict(PP), part_count=2, part_index=0, **kw)
+
+
+def test_batch_of_dragons_throughput():
+    """Config 2's body is launch-bound alone (15 tiles on a chip with 2,048 workgroup slots): 64 of them in one batch must step at
+    >= 20x the tet-solves/s of a single one."""
+    import time
+    v, t = load_mesh("dragon")
+
+    def rate(body, frames):
+        body.simulateSubsteps(20, DT, PP); body.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            body.simulateSubsteps(20, DT, PP)
+        body.sync()
+        return body.info.num_elems * 20 * frames / (time.perf_counter() - t0)
+
+    one = rate(SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast"), 200)
+    many = rate(SoftBodyHIP.batch([(v, t)] * 64, dict(PP), solver="polar", precision="fast"), 200)
+    print("single Dragon %.1f M tet-solves/s, 64 Dragons in one batch %.1f M (%.1fx)" % (one / 1e6, many / 1e6, many / one))
+    assert many >= 20.0 * one, (one, many)

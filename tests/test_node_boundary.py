@@ -28,7 +28,7 @@ def test_addon_loads_and_fails_loudly_without_gpu():
           "catch(e){console.log('THROWN '+e.message);}") % (os.path.join(NODE_DIR, "tetsim_napi.node"),
                                                          os.path.join(ROOT, "tetsim_amd", "libtetsim_hip.so"))
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120).stdout
-    assert ("KEYS commInit,commUniqueId,create,createFromFile,destroy,info,libraryInfo,load,loadState,mapPositions,mapQuats,ownedIds,readMesh,"
+    assert ("KEYS batchLayout,commInit,commUniqueId,create,createBatch,createFromFile,destroy,info,libraryInfo,load,loadState,mapPositions,mapQuats,ownedIds,readMesh,"
             "readPositions,readQuats,readVelocities,readVisualMesh,readVisualVertexNormals,readVolError,refreshPositions,refreshQuats,saveState,"
             "setGrab,setVisualMesh,setVisualTriangles,startGrab,step,stepN,sync") in out
     assert "ABI 3" in out

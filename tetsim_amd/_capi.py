@@ -42,7 +42,7 @@ class TetSimInfo(C.Structure):
                 ("num_levels", C.c_uint32), ("max_valence", C.c_uint32), ("dropped_slots", C.c_uint32),
                 ("num_neighbours", C.c_uint32), ("device_bytes", C.c_uint64), ("solver", C.c_int32),
                 ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("num_vis_verts", C.c_uint32)]
+                ("num_vis_verts", C.c_uint32), ("num_bodies", C.c_uint32)]
 
 
 class TetSimProfile(C.Structure):
@@ -77,7 +77,7 @@ class TetSimError(RuntimeError):
 
 # every symbol include/tetsim.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "tetsim_abi_version", "tetsim_default_options", "tetsim_default_params", "tetsim_create", "tetsim_destroy",
+    "tetsim_abi_version", "tetsim_default_options", "tetsim_default_params", "tetsim_create", "tetsim_create_batch", "tetsim_get_batch_layout", "tetsim_destroy",
     "tetsim_last_error", "tetsim_get_info", "tetsim_step", "tetsim_step_n", "tetsim_sync",
     "tetsim_library_info", "tetsim_read_quats_pinned", "tetsim_state_size", "tetsim_save_state", "tetsim_load_state",
     "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
@@ -113,6 +113,8 @@ def lib():
     L.tetsim_default_params.argtypes = [PP]
     L.tetsim_default_params.restype = None
     L.tetsim_create.argtypes = [fp, u32, ip, u32, C.POINTER(TetSimOptions), C.POINTER(H)]
+    L.tetsim_create_batch.argtypes = [C.POINTER(fp), C.POINTER(u32), C.POINTER(ip), C.POINTER(u32), u32, C.POINTER(TetSimOptions), C.POINTER(H)]
+    L.tetsim_get_batch_layout.argtypes = [H, C.POINTER(u32), C.POINTER(u32)]
     L.tetsim_destroy.argtypes = [H]
     L.tetsim_destroy.restype = None
     L.tetsim_comm_probe.argtypes = [H, C.c_uint64, u32, i32, u32, dp, dp]

@@ -124,6 +124,8 @@ struct tetsim_body {
     std::vector<void*> allocs;
     std::vector<float> h_verts;
     std::vector<int32_t> h_tets;
+    // tetsim_create_batch: first particle / first tet of every body in the concatenation, [bodies + 1]; empty = a single body
+    std::vector<uint32_t> batch_first_vert, batch_first_tet;
     bool fast = false;
 
     // POLAR_JACOBI

@@ -364,22 +364,28 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 }
 
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
-                  const Incidence& inc, BlockPlan* out) {
+                  const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet, const uint32_t* body_first_vert, uint32_t bodies) {
     BlockPlan& B = *out;
     B = BlockPlan();
     constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
-    // 1. Morton order of rest centroids (quantised to 10 bits per axis over the bounding box)
-    const Quantiser Q(verts, nv);
+    const uint32_t one_t[2] = {0u, nt}, one_v[2] = {0u, nv};
+    if (!body_first_tet || !body_first_vert || bodies == 0) { body_first_tet = one_t; body_first_vert = one_v; bodies = 1; }
+    // 1. Morton order of rest centroids (quantised to 10 bits per axis over the body's bounding box), body after body
     std::vector<uint64_t> key(nt);
-    for (uint32_t e = 0; e < nt; e++) {
-        float m[3] = {0.0f, 0.0f, 0.0f};
-        for (int k = 0; k < 4; k++)
-            for (int c = 0; c < 3; c++) m[c] += verts[3 * tets[4 * e + k] + c];
-        key[e] = (static_cast<uint64_t>(Q.code(0.25f * m[0], 0.25f * m[1], 0.25f * m[2])) << 32) | e;  // ties keep the caller's order
-    }
-    std::sort(key.begin(), key.end());
+    std::vector<uint32_t> body_of_pos(nt);   // body of the tet at each sorted position
     B.tet_perm.resize(nt);
-    for (uint32_t i = 0; i < nt; i++) B.tet_perm[i] = static_cast<int32_t>(key[i] & 0xffffffffu);
+    for (uint32_t b = 0; b < bodies; b++) {
+        const uint32_t tb = body_first_tet[b], te = body_first_tet[b + 1], vb = body_first_vert[b], ve = body_first_vert[b + 1];
+        const Quantiser Q(verts + 3ull * vb, ve - vb);
+        for (uint32_t e = tb; e < te; e++) {
+            float m[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 4; k++)
+                for (int c = 0; c < 3; c++) m[c] += verts[3 * tets[4 * e + k] + c];
+            key[e] = (static_cast<uint64_t>(Q.code(0.25f * m[0], 0.25f * m[1], 0.25f * m[2])) << 32) | (e - tb);  // ties keep the caller's order
+        }
+        std::sort(key.begin() + tb, key.begin() + te);
+        for (uint32_t i = tb; i < te; i++) { B.tet_perm[i] = static_cast<int32_t>(tb + (key[i] & 0xffffffffu)); body_of_pos[i] = b; }
+    }
 
     // which (tet,corner) contributions are live (the incidence table may drop some: reference quirk / cap)
     std::vector<uint8_t> live(4ull * nt, 0);
@@ -396,7 +402,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
             const uint32_t t0 = i;
             touched.clear();
             bool ghost = false;
-            while (i < nt && i - t0 < kMaxTets) {
+            while (i < nt && i - t0 < kMaxTets && body_of_pos[i] == body_of_pos[t0]) {   // a tile never spans two bodies
                 const int32_t* t = &tets[4 * B.tet_perm[i]];
                 uint32_t fresh = 0;
                 for (int k = 0; k < 4; k++) {

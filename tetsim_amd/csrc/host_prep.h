@@ -105,8 +105,12 @@ struct BlockPlan {
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
 // it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).
+// Batches (tetsim_create_batch: several independent bodies behind one handle): body_first_tet / body_first_vert [bodies + 1]
+// give each body's tet and vertex range; tiles never span two bodies and every body is tiled exactly as it would be alone
+// (its own bounding box for the Morton codes), so that each body's results equal its solo run bit for bit.  NULL = one body.
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
-                  const Incidence& inc, BlockPlan* out);
+                  const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet = nullptr,
+                  const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1);
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 

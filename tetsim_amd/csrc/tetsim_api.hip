@@ -280,7 +280,10 @@ void tetsim_default_params(TetSimParams* p) {  // main.js:22-36
 
 const char* tetsim_last_error(tetsim_handle h) { return h ? h->err.c_str() : create_error(); }
 
-int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, const TetSimOptions* opts, tetsim_handle* out) {
+namespace {
+// batch_first_vert / batch_first_tet: [bodies + 1] ranges of a concatenation of independent bodies (tetsim_create_batch), or empty
+int create_common(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, const TetSimOptions* opts, tetsim_handle* out,
+                  const std::vector<uint32_t>& batch_first_vert, const std::vector<uint32_t>& batch_first_tet) {
     if (!out) return fail(nullptr, TETSIM_EINVAL, "out handle pointer is null");
     *out = nullptr;
     TetSimOptions o;
@@ -312,6 +315,9 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     h->info.solver = o.solver; h->info.precision = o.precision; h->info.order = o.order; h->info.device = o.device; h->info.flags = o.flags;
     h->h_verts.assign(verts, verts + 3ull * nv);
     h->h_tets.assign(tets, tets + 4ull * nt);
+    h->batch_first_vert = batch_first_vert;
+    h->batch_first_tet = batch_first_tet;
+    h->info.num_bodies = batch_first_vert.empty() ? 1u : static_cast<uint32_t>(batch_first_vert.size() - 1);
 
     auto bail = [&](int rc) { g_create_error = h->err; tetsim_destroy(h); return rc; };
     auto hipok = [&](hipError_t er, const char* what) { if (er != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(er); return false; } return true; };
@@ -336,6 +342,47 @@ int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     if (!hipok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return bail(TETSIM_EHIP);
     *out = h;
     return TETSIM_OK;
+}
+}  // namespace
+
+int tetsim_create(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, const TetSimOptions* opts, tetsim_handle* out) {
+    return create_common(verts, nv, tets, nt, opts, out, {}, {});
+}
+
+int tetsim_create_batch(const float* const* verts, const uint32_t* nv, const int32_t* const* tets, const uint32_t* nt, uint32_t count,
+                        const TetSimOptions* opts, tetsim_handle* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "out handle pointer is null");
+    *out = nullptr;
+    if (!verts || !nv || !tets || !nt || count == 0) return fail(nullptr, TETSIM_EINVAL, "tetsim_create_batch: null argument or empty batch");
+    if (opts && opts->part_count > 1) return fail(nullptr, TETSIM_EINVAL, "a batch cannot be partitioned (partition the bodies over handles instead)");
+    if (opts && opts->tet_colour) return fail(nullptr, TETSIM_EINVAL, "tet_colour is not supported for batches");
+    std::vector<uint32_t> fv(count + 1, 0), ft(count + 1, 0);
+    for (uint32_t b = 0; b < count; b++) {
+        const std::string merr = validate_mesh(verts[b], nv[b], tets[b], nt[b], opts && opts->solver == TETSIM_SOLVER_NEOHOOKEAN_GS);
+        if (!merr.empty()) return fail(nullptr, TETSIM_EINVAL, "body " + std::to_string(b) + ": " + merr);
+        const uint64_t v = static_cast<uint64_t>(fv[b]) + nv[b], t = static_cast<uint64_t>(ft[b]) + nt[b];
+        if (v > 0x3fffffffull || t > 0x1fffffffull) return fail(nullptr, TETSIM_EINVAL, "batch too large for one handle");
+        fv[b + 1] = static_cast<uint32_t>(v); ft[b + 1] = static_cast<uint32_t>(t);
+    }
+    std::vector<float> av(3ull * fv[count]);
+    std::vector<int32_t> at(4ull * ft[count]);
+    for (uint32_t b = 0; b < count; b++) {
+        std::copy(verts[b], verts[b] + 3ull * nv[b], av.begin() + 3ull * fv[b]);
+        for (uint64_t i = 0; i < 4ull * nt[b]; i++) at[4ull * ft[b] + i] = tets[b][i] + static_cast<int32_t>(fv[b]);
+    }
+    return create_common(av.data(), fv[count], at.data(), ft[count], opts, out, fv, ft);
+}
+
+int tetsim_get_batch_layout(tetsim_handle h, uint32_t* first_particle, uint32_t* first_elem) {
+    if (!h || !first_particle || !first_elem) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->batch_first_vert.empty()) {
+        first_particle[0] = 0; first_particle[1] = h->info.num_particles;
+        first_elem[0] = 0; first_elem[1] = h->info.num_elems;
+        return 0;
+    }
+    std::copy(h->batch_first_vert.begin(), h->batch_first_vert.end(), first_particle);
+    std::copy(h->batch_first_tet.begin(), h->batch_first_tet.end(), first_elem);
+    return 0;
 }
 
 void tetsim_destroy(tetsim_handle h) {

@@ -30,20 +30,49 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         h->info.owned_elems = nt;
     }
     // device numbering: Morton order inside the interior segment [nvb, nvo); boundary (halo sends stay contiguous
-    // runs) and ghosts (receive ranges) keep the plan's order
+    // runs) and ghosts (receive ranges) keep the plan's order.  Batches: every body's segment on its own (as it would be alone).
+    const bool batch = !h->batch_first_vert.empty();
+    const uint32_t bodies = batch ? static_cast<uint32_t>(h->batch_first_vert.size() - 1) : 1u;
     {
         std::vector<float> lv(3ull * nvl);
         for (uint32_t i = 0; i < nvl; i++) {
             const uint32_t g = h->partitioned ? static_cast<uint32_t>(l2g_v[i]) : i;
             lv[3 * i] = verts[3 * g]; lv[3 * i + 1] = verts[3 * g + 1]; lv[3 * i + 2] = verts[3 * g + 2];
         }
-        h->dev2api = morton_vertex_order(lv.data(), nvl, nvb, nvo - nvb);
+        if (!batch) h->dev2api = morton_vertex_order(lv.data(), nvl, nvb, nvo - nvb);
+        else {
+            h->dev2api.resize(nvl);
+            for (uint32_t b = 0; b < bodies; b++) {
+                const uint32_t vb = h->batch_first_vert[b], n = h->batch_first_vert[b + 1] - vb;
+                const std::vector<uint32_t> ord = morton_vertex_order(lv.data() + 3ull * vb, n, 0, n);
+                for (uint32_t i = 0; i < n; i++) h->dev2api[vb + i] = vb + ord[i];
+            }
+        }
         h->api2dev.resize(nvl);
         for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
         for (auto& id : ltets) id = static_cast<int32_t>(h->api2dev[id]);
     }
-    const bool quirk_here = ref_table && ntl > 0 && (!h->partitioned || l2g_t[0] == 0);
-    Incidence inc = build_incidence(ltets.data(), ntl, nvl, quirk_here, ref_table);
+    // incidence (which (tet, corner) contributions each particle sums).  The reference's `<= 0.0` quirk drops the contribution of
+    // ITS tet 0 / corner 0: in a batch that is every body's own first tet, so the table is built body by body.
+    Incidence inc;
+    if (!batch) {
+        const bool quirk_here = ref_table && ntl > 0 && (!h->partitioned || l2g_t[0] == 0);
+        inc = build_incidence(ltets.data(), ntl, nvl, quirk_here, ref_table);
+    } else {
+        inc.offset.assign(nvl + 1, 0);
+        for (uint32_t b = 0; b < bodies; b++) {
+            const uint32_t vb = h->batch_first_vert[b], nvb_ = h->batch_first_vert[b + 1] - vb;
+            const uint32_t tb = h->batch_first_tet[b], ntb_ = h->batch_first_tet[b + 1] - tb;
+            std::vector<int32_t> bt(ltets.begin() + 4ull * tb, ltets.begin() + 4ull * (tb + ntb_));
+            for (auto& id : bt) id -= static_cast<int32_t>(vb);   // a body's particles occupy [vb, vb + nvb_) in device numbering too
+            const Incidence bi = build_incidence(bt.data(), ntb_, nvb_, ref_table && ntb_ > 0, ref_table);
+            const uint32_t base = static_cast<uint32_t>(inc.slot.size());
+            for (uint32_t v = 0; v < nvb_; v++) inc.offset[vb + v + 1] = base + bi.offset[v + 1];
+            for (int32_t enc : bi.slot) inc.slot.push_back(enc + static_cast<int32_t>(4u * tb));
+            inc.max_valence = std::max(inc.max_valence, bi.max_valence);
+            inc.dropped += bi.dropped;
+        }
+    }
     // Only owned vertices are averaged here; the table rows of ghosts are never read.
     uint32_t maxv = 0;
     for (uint32_t v = 0; v < nvo; v++) maxv = std::max(maxv, inc.offset[v + 1] - inc.offset[v]);
@@ -89,7 +118,8 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
     if (h->blocked) {
         BlockPlan B;
-        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B);
+        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
+                     batch ? h->batch_first_vert.data() : nullptr, bodies);
         h->tet_perm = B.tet_perm;
         PJBlk& k = h->blk;
         h->interior_tets = B.blk_tet_off[B.num_interior_blocks];

@@ -56,8 +56,13 @@ class SoftBodyHIP {
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
         };
         if (opt.vertOwner) createOptions.vertOwner = opt.vertOwner instanceof Int32Array ? opt.vertOwner : Int32Array.from(opt.vertOwner);
-        // fromFile: the library maps the .tetsim container itself (and picks up a stored colouring / visual mesh)
-        this._h = _meshFile ? api.createFromFile(_meshFile, createOptions) : api.create(verts32, tets32, createOptions);
+        // fromFile: the library maps the .tetsim container itself (and picks up a stored colouring / visual mesh);
+        // batch: `_meshFile` carries the list of bodies, vertices / tetIds are their concatenation
+        if (_meshFile && _meshFile.batch) {
+            this._h = api.createBatch(_meshFile.batch.map(b => b.vertices instanceof Float32Array ? b.vertices : Float32Array.from(b.vertices)),
+                                      _meshFile.batch.map(b => b.tetIds instanceof Int32Array ? b.tetIds : Int32Array.from(b.tetIds)), createOptions);
+            _meshFile = null;
+        } else this._h = _meshFile ? api.createFromFile(_meshFile, createOptions) : api.create(verts32, tets32, createOptions);
         this._dirty = false;
         this._visOnDevice = false;
 
@@ -106,6 +111,23 @@ class SoftBodyHIP {
         return new SoftBodyHIP(m.vertices, m.tetIds, m.tetEdgeIds || [], physicsParams, m.visVerts || new Float32Array(0),
                                m.visTriIds || [], visMaterial, world, path);
     }
+
+    // Several INDEPENDENT bodies [{vertices, tetIds}, ...] behind one handle: main.js:80-84 steps softBodies[] one after the other,
+    // here ONE simulate() steps them all with one launch per kernel (a Dragon alone fills 15 of the chip's 2,048 workgroup
+    // slots).  `.pos` is the concatenation; bodyRanges() gives each body's particle / tet range.  Every body's result equals
+    // its solo run bit for bit.  Physics only (no display meshes).
+    static batch(bodies, physicsParams) {
+        const nv = bodies.reduce((s, b) => s + b.vertices.length, 0), nt = bodies.reduce((s, b) => s + b.tetIds.length, 0);
+        const vertices = new Float32Array(nv), tetIds = new Int32Array(nt);
+        let ov = 0, ot = 0;
+        for (const b of bodies) {
+            vertices.set(b.vertices, ov);
+            for (let i = 0; i < b.tetIds.length; i++) tetIds[ot + i] = b.tetIds[i] + ov / 3;
+            ov += b.vertices.length; ot += b.tetIds.length;
+        }
+        return new SoftBodyHIP(vertices, tetIds, [], physicsParams, new Float32Array(0), [], null, null, { batch: bodies });
+    }
+    bodyRanges() { return this._api.batchLayout(this._h); }
 
     // ---- multi-GPU: one Node process per GPU, this body = partition partIndex of partCount (INTEGRATION.md §4) -------------
     // rank 0: id = SoftBodyHIP.commUniqueId(); ship the 128 bytes to every process (any channel); all: body.commInit(id, rank, n).

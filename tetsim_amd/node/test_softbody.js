@@ -252,4 +252,17 @@ if (process.env.TETSIM_TEST_MESH) {   // a partitioned body from a file that car
     b.dispose();
     console.log('refStartGrab: searches the edge-mesh copy (stale until updateEdgeMesh), like SoftbodyGPU.js:692-704');
 }
+// 8. a batch of independent bodies behind one handle: each equals its solo run bit for bit (Neo-Hookean PRECISE == Softbody.js goldens)
+{
+    const p12 = Object.assign({}, pp, { numSubsteps: 10, tetsim: { solver: 'neohookean', precision: 'precise' } });
+    const lv = f32('lat4_verts.f32'), lt = i32('lat4_tets.i32');
+    const batch = SoftBodyHIP.batch([{ vertices: verts, tetIds: tets }, { vertices: lv, tetIds: lt }, { vertices: verts, tetIds: tets }], p12);
+    assert.strictEqual(batch.info().numBodies, 3); assert.strictEqual(batch.numParticles, 2 * 1234 + lv.length / 3);
+    for (let step = 1; step <= 10; step++) batch.simulate(dt, p12);
+    batch.endFrame();
+    const r = batch.bodyRanges().firstParticle, want = f32('dragon_pos_10.f32');
+    for (const b of [0, 2]) assert.strictEqual(bitsEqual(batch.pos.subarray(3 * r[b], 3 * r[b + 1]), want), -1, `batched Dragon ${b} differs from Softbody.js at substep 10`);
+    batch.dispose();
+    console.log('batch: 2 Dragons + a lattice behind one handle, both Dragons bit-exact vs Softbody.js goldens');
+}
 console.log('node boundary ok');

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/tetsim.h"
 
@@ -23,6 +24,8 @@ struct Api {
     decltype(&tetsim_default_options) default_options = nullptr;
     decltype(&tetsim_default_params) default_params = nullptr;
     decltype(&tetsim_create) create = nullptr;
+    decltype(&tetsim_create_batch) create_batch = nullptr;
+    decltype(&tetsim_get_batch_layout) get_batch_layout = nullptr;
     decltype(&tetsim_destroy) destroy = nullptr;
     decltype(&tetsim_last_error) last_error = nullptr;
     decltype(&tetsim_get_info) get_info = nullptr;
@@ -71,6 +74,7 @@ bool load_lib(const std::string& hint) {
     SYM(get_local_tets, "tetsim_get_local_tets") SYM(set_grab, "tetsim_set_grab") SYM(start_grab, "tetsim_start_grab")
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(set_visual_triangles, "tetsim_set_visual_triangles") SYM(read_visual_vertex_normals, "tetsim_read_visual_vertex_normals")
+    SYM(create_batch, "tetsim_create_batch") SYM(get_batch_layout, "tetsim_get_batch_layout")
     SYM(abi_version, "tetsim_abi_version") SYM(read_quats_pinned, "tetsim_read_quats_pinned") SYM(state_size, "tetsim_state_size")
     SYM(save_state, "tetsim_save_state") SYM(load_state, "tetsim_load_state") SYM(library_info, "tetsim_library_info")
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
@@ -210,6 +214,58 @@ napi_value Create(napi_env env, napi_callback_info info) {
     const int rc = g.create(verts, static_cast<uint32_t>(nvf / 3), tets, static_cast<uint32_t>(ntf / 4), &o, &h);
     if (rc != TETSIM_OK) return check(env, rc, nullptr);
     return wrap_handle(env, h);
+}
+// createBatch(Float32Array[] verts, Int32Array[] tets, options) -> handle of the concatenation (tetsim_create_batch)
+napi_value CreateBatch(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    bool isv = false, ist = false;
+    uint32_t n = 0, nt_ = 0;
+    if (napi_is_array(env, a[0], &isv) != napi_ok || !isv || napi_is_array(env, a[1], &ist) != napi_ok || !ist ||
+        napi_get_array_length(env, a[0], &n) != napi_ok || napi_get_array_length(env, a[1], &nt_) != napi_ok || n == 0 || n != nt_)
+        return throw_err(env, "createBatch(verts[], tets[], options): two arrays of equal, non-zero length");
+    std::vector<const float*> vp(n);
+    std::vector<const int32_t*> tp(n);
+    std::vector<uint32_t> nv(n), nt(n);
+    for (uint32_t b = 0; b < n; b++) {
+        napi_value ev, et;
+        float* v; int32_t* t; size_t lv, lt;
+        if (napi_get_element(env, a[0], b, &ev) != napi_ok || !typed_array(env, ev, napi_float32_array, &v, &lv) || lv % 3)
+            return throw_err(env, "every vertices entry must be a Float32Array of xyz triples");
+        if (napi_get_element(env, a[1], b, &et) != napi_ok || !typed_array(env, et, napi_int32_array, &t, &lt) || lt % 4)
+            return throw_err(env, "every tetIds entry must be an Int32Array of 4 ids per tet");
+        vp[b] = v; tp[b] = t; nv[b] = static_cast<uint32_t>(lv / 3); nt[b] = static_cast<uint32_t>(lt / 4);
+    }
+    TetSimOptions o;
+    size_t owner_len = 0;
+    options_of(env, a[2], &o, &owner_len);
+    o.vert_owner = nullptr;
+    tetsim_handle h = nullptr;
+    const int rc = g.create_batch(vp.data(), nv.data(), tp.data(), nt.data(), n, &o, &h);
+    if (rc != TETSIM_OK) return check(env, rc, nullptr);
+    return wrap_handle(env, h);
+}
+// batchLayout(handle) -> { firstParticle: Uint32Array[bodies+1], firstElem: Uint32Array[bodies+1] }
+napi_value BatchLayout(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    const size_t n = static_cast<size_t>(inf.num_bodies) + 1;
+    void *dp = nullptr, *de = nullptr; napi_value abp, abe, tp_, te_, o;
+    napi_create_arraybuffer(env, 4 * n, &dp, &abp);
+    napi_create_arraybuffer(env, 4 * n, &de, &abe);
+    const int rc = g.get_batch_layout(h, static_cast<uint32_t*>(dp), static_cast<uint32_t*>(de));
+    if (rc) return check(env, rc, h);
+    napi_create_typedarray(env, napi_uint32_array, n, abp, 0, &tp_);
+    napi_create_typedarray(env, napi_uint32_array, n, abe, 0, &te_);
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "firstParticle", tp_);
+    napi_set_named_property(env, o, "firstElem", te_);
+    return o;
 }
 // options object -> TetSimOptions (shared by create / createFromFile)
 void options_of(napi_env env, napi_value obj, TetSimOptions* o, size_t* owner_len) {
@@ -565,7 +621,7 @@ napi_value Info(napi_env env, napi_callback_info info) {
     set("localElems", inf.local_elems); set("numLevels", inf.num_levels); set("maxValence", inf.max_valence);
     set("droppedSlots", inf.dropped_slots); set("deviceBytes", static_cast<double>(inf.device_bytes));
     set("solver", inf.solver); set("precision", inf.precision); set("localParticles", inf.local_particles);
-    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours); set("numVisVerts", inf.num_vis_verts);
+    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours); set("numVisVerts", inf.num_vis_verts); set("numBodies", inf.num_bodies);
     return o;
 }
 
@@ -574,6 +630,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"load", nullptr, Load, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"createFromFile", nullptr, CreateFromFile, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"createBatch", nullptr, CreateBatch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"batchLayout", nullptr, BatchLayout, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readMesh", nullptr, ReadMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -57,9 +57,15 @@ class SoftBodyHIP:
     def __init__(self, vertices, tetIds, tetEdgeIds=None, physicsParams=None, visVerts=None, visTriIds=None,
                  visMaterial=None, world=None, *, solver="polar", precision="precise", order="original",
                  ref_slot_table=True, ref_fixed_bounds=True, gather=False, constant_rest_shape=False, ref_grab_texel=False,
-                 device=0, part_count=1, part_index=0, vert_owner=None, tet_colour=None, mesh_file=None):
+                 device=0, part_count=1, part_index=0, vert_owner=None, tet_colour=None, mesh_file=None, batch=None):
         L = capi.lib()
         self.physicsParams = physicsParams if physicsParams is not None else {}
+        self._batch = None
+        if batch is not None:   # SoftBodyHIP.batch: several independent bodies behind one handle (tetsim_create_batch)
+            self._batch = [(_f32(v).reshape(-1), np.ascontiguousarray(np.asarray(t).reshape(-1), dtype=np.int32)) for v, t in batch]
+            offs = np.concatenate([[0], np.cumsum([len(v) // 3 for v, _ in self._batch])])
+            vertices = np.concatenate([v for v, _ in self._batch])
+            tetIds = np.concatenate([t + int(offs[i]) for i, (_, t) in enumerate(self._batch)])
         if mesh_file is not None:   # SoftBodyHIP.fromFile: arrays come from the .tetsim container
             from .meshfile import MeshFile
             with MeshFile(mesh_file) as mf:
@@ -104,6 +110,13 @@ class SoftBodyHIP:
         self._h = C.c_void_p()
         if mesh_file is not None:   # the library maps the file itself and picks up a stored colouring / partition map
             capi.check(L.tetsim_create_from_file(str(mesh_file).encode(), C.byref(o), C.byref(self._h)))
+        elif self._batch is not None:
+            n = len(self._batch)
+            vp = (C.POINTER(C.c_float) * n)(*[_fp(v) for v, _ in self._batch])
+            tp = (C.POINTER(C.c_int32) * n)(*[_ip(t) for _, t in self._batch])
+            nvs = (C.c_uint32 * n)(*[len(v) // 3 for v, _ in self._batch])
+            nts = (C.c_uint32 * n)(*[len(t) // 4 for _, t in self._batch])
+            capi.check(L.tetsim_create_batch(vp, nvs, tp, nts, n, C.byref(o), C.byref(self._h)))
         else:
             capi.check(L.tetsim_create(_fp(self._verts), self.numParticles, _ip(self._tets), self.numElems,
                                        C.byref(o), C.byref(self._h)))
@@ -118,6 +131,20 @@ class SoftBodyHIP:
                 self.setVisualMesh(visVerts)
             if visTriIds is not None and len(visTriIds):   # Softbody.js:48-50: enables visualVertexNormals()
                 self.setVisualTriangles(visTriIds)
+
+    @classmethod
+    def batch(cls, bodies, physicsParams=None, **kw):
+        """Several INDEPENDENT bodies `[(vertices, tetIds), ...]` behind one handle: one launch per kernel steps them all (the
+        reference steps softBodies[] one after the other, main.js:80-84).  `.pos` etc. are the concatenation; `bodyRanges` gives
+        each body's particle / tet range.  Every body's results equal its solo run bit for bit."""
+        return cls(None, None, None, physicsParams, batch=list(bodies), **kw)
+
+    @property
+    def bodyRanges(self):
+        n = self.info.num_bodies
+        fp_, fe = (C.c_uint32 * (n + 1))(), (C.c_uint32 * (n + 1))()
+        capi.check(self._L.tetsim_get_batch_layout(self._h, fp_, fe), self._h)
+        return [((fp_[b], fp_[b + 1]), (fe[b], fe[b + 1])) for b in range(n)]
 
     @classmethod
     def fromFile(cls, path, physicsParams=None, visMaterial=None, world=None, **kw):
