@@ -259,10 +259,11 @@ def test_batch_of_bodies_equals_solo_runs_bit_for_bit(kw):
     positions and velocities must equal its solo run bit for bit -- different meshes in one batch, floor contact included,
     through tetsim_step and tetsim_step_n."""
     meshes = []
-    for name, dy in (("dragon", 0.0), ("lat4", 0.0), ("hub", -0.35), ("dragon", -0.8), ("lat4", 0.3)):
+    for name, y_min in (("dragon", None), ("lat4", None), ("hub", 0.25), ("dragon", 0.004), ("lat4", 0.8)):
         v, t = load_mesh(name)
         v = v.copy()
-        v[:, 1] += np.float32(dy)       # the second dragon starts closer to the floor: contact within the run
+        if y_min is not None:
+            v[:, 1] += np.float32(y_min) - v[:, 1].min()   # the second dragon starts 4 mm above the floor: contact within the run
         meshes.append((v, t))
     dt = DT if kw["solver"] == "polar" else DT * 2
     batch = SoftBodyHIP.batch(meshes, dict(PP), **kw)
