@@ -581,6 +581,8 @@ def run(args, rank, world, local_rank, ranks):
         units = pr["tets_per_tet_launch"]
         achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
+        if body.info.fused_particle_pass:   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
+            kname, tet_bytes = "pjb_tet_fused_kernel", tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
         traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
         out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

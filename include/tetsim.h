@@ -139,6 +139,8 @@ typedef struct TetSimInfo {
     uint32_t flags;
     uint32_t num_vis_verts;      /* visual vertices attached by tetsim_set_visual_mesh / a .tetsim file (0 = none); since ABI 3 */
     uint32_t num_bodies;         /* independent bodies behind this handle (tetsim_create_batch), 1 otherwise; since ABI 3 */
+    uint32_t fused_particle_pass; /* 1: tetsim_step_n runs ONE kernel per substep (particle update fused into the tet kernel's staging,
+                                     DESIGN.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
@@ -279,7 +281,9 @@ int tetsim_nearest_particle(tetsim_handle h, const float xyz[3], int32_t *global
 /* --- measurement ----------------------------------------------------------------------------- */
 
 /* Run n substeps eagerly on the handle's own stream; every POLAR_JACOBI kernel carries its own begin/end HIP
- * events (hipExtLaunchKernelGGL), so kernel_ms[] sums the kernels' own durations in the real launch sequence. */
+ * events (hipExtLaunchKernelGGL), so kernel_ms[] sums the kernels' own durations in the real launch sequence.  Bodies with
+ * TetSimInfo.fused_particle_pass run the sequence of tetsim_step_n (tet | fused x (n-1) | particle): TETSIM_K_TET then holds the
+ * n-1 fused kernels, TETSIM_K_VERTEX the one particle kernel that ends the call. */
 int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params, TetSimProfile *out);
 /* Kernel-only timing: `reps` back-to-back launches of the per-tet kernel(s) of one substep inside ONE HIP-event
  * pair on the handle's stream, then the same for the per-particle kernel(s); kernel_ms[] = total / reps.  No event

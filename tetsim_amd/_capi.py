@@ -42,7 +42,7 @@ class TetSimInfo(C.Structure):
                 ("num_levels", C.c_uint32), ("max_valence", C.c_uint32), ("dropped_slots", C.c_uint32),
                 ("num_neighbours", C.c_uint32), ("device_bytes", C.c_uint64), ("solver", C.c_int32),
                 ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("num_vis_verts", C.c_uint32), ("num_bodies", C.c_uint32)]
+                ("num_vis_verts", C.c_uint32), ("num_bodies", C.c_uint32), ("fused_particle_pass", C.c_uint32)]
 
 
 class TetSimProfile(C.Structure):

@@ -132,6 +132,12 @@ struct tetsim_body {
     PJDev pj;
     PJBlk blk;             // blocked formulation (FAST unless TETSIM_FLAG_GATHER_FORMULATION)
     bool blocked = false;
+    // fused particle pass (unpartitioned blocked bodies): tetsim_step_n runs  tet | fused x (n-1) | particle  instead of n x (tet | particle)
+    bool fused = false;
+    float4* partial_b = nullptr;      // second buffer of the tile partial sums
+    float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
+    uint32_t fuse_step = 0;           // substep index inside the current run (enqueue_substep)
+    bool fin_in_b = false;            // the latest end-of-substep positions are in pos_final_b (only between the kernels of one call)
     std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
     // Particles are renumbered on the device (Morton order inside the interior segment) for locality; the API keeps
     // the caller's / the partition plan's numbering.  api2dev[a] = device index of API-local particle a.

@@ -65,6 +65,17 @@ struct PJBlk {
     float4* pos_pred = nullptr;
     float4* pos_final = nullptr;
     float4* vel = nullptr;
+    // Fused particle pass (pjb_tet_fused_kernel): the staging of substep s+1 performs the particle update of substep s for the
+    // tile's own particles instead of reading predictions a separate kernel wrote.  Inputs of that update are the PREVIOUS tet
+    // pass's partial sums and end-of-substep positions, which other tiles of the same launch still read while this launch writes
+    // the new ones: both are double buffered (the launcher fills these four per launch; the particle kernel uses fin_in / fin_out
+    // too -- a lane only touches its own particle there, so they may be the same array).
+    const float4* partial_prev = nullptr;    // fused staging input: the partial sums of the previous tet pass
+    const float4* fin_in = nullptr;          // end-of-substep positions to read (prevPos of the update)
+    float4* fin_out = nullptr;               // ... and to write
+    const uint32_t* slot_src = nullptr;      // ELL [vp_cols][ns_pad]: per tile slot, the partial sums of its particle
+    const uint32_t* blk_maxsrc = nullptr;    // [nb] longest such list in the tile
+    uint32_t ns_pad = 0;
     const DevParams* params = nullptr;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
@@ -110,6 +121,8 @@ void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLau
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr);
+// the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)
+void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores

@@ -492,6 +492,22 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     B.vp_ell.assign(static_cast<size_t>(std::max(B.max_partials, 1u)) * B.nv_pad, 0xffffffffu);
     for (uint32_t v = 0; v < nv_sum; v++)
         for (size_t j = 0; j < vert_partials[v].size(); j++) B.vp_ell[j * B.nv_pad + v] = vert_partials[v][j];
+    // fused particle pass: every tile slot carries its particle's list of partial sums; the list's first slot is the owner
+    const uint32_t ns = static_cast<uint32_t>(B.blk_verts.size());
+    B.ns_pad = (ns + 63u) & ~63u;
+    B.slot_src.assign(static_cast<size_t>(std::max(B.max_partials, 1u)) * B.ns_pad, 0xffffffffu);
+    B.blk_maxsrc.assign(B.num_blocks, 0);
+    for (uint32_t v = 0; v < nv_sum; v++)
+        if (vert_partials[v].empty()) B.every_owned_particle_has_a_partial = false;
+    for (uint32_t b = 0; b < B.num_blocks; b++)
+        for (uint32_t g = B.blk_vert_off[b]; g < B.blk_vert_off[b + 1]; g++) {
+            const uint32_t v = static_cast<uint32_t>(B.blk_verts[g]);
+            if (v >= nv_sum) continue;   // ghosts are not integrated here
+            const std::vector<uint32_t>& list = vert_partials[v];
+            for (size_t j = 0; j < list.size(); j++) B.slot_src[j * B.ns_pad + g] = list[j];
+            B.blk_maxsrc[b] = std::max<uint32_t>(B.blk_maxsrc[b], static_cast<uint32_t>(list.size()));
+            if (!list.empty() && list[0] == g) B.lc_range[g] |= 1u << 15;
+        }
 }
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats) {

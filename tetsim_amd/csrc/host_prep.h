@@ -94,11 +94,18 @@ struct BlockPlan {
     std::vector<uint32_t> blk_vert_off;  // [num_blocks+1] into blk_verts / partial sums
     std::vector<int32_t> blk_verts;      // vertex ids of each tile's LDS slots
     std::vector<uint8_t> tet_lidx;       // [4*nt] LDS slot of every corner (new tet order)
-    std::vector<uint32_t> lc_range;      // per tile vertex: first | (last+1) << 16 into the tile's lc_ent
+    std::vector<uint32_t> lc_range;      // per tile vertex: first | owner << 15 | (last+1) << 16 into the tile's lc_ent (first, last+1 <= 1024);
+                                         //   owner = this slot is the FIRST of its particle's partial sums (the fused kernel's one writer)
     std::vector<uint16_t> lc_ent;        // [4*nt] per tile: corner*256 + tetLocal (word offset into the goal planes) grouped by LDS slot, tet order inside
     std::vector<uint32_t> vp_off;        // [nv_sum+1] per summed vertex: range into vp_idx
     std::vector<uint32_t> vp_idx;        // indices into the partial-sum array, ascending tile
     std::vector<uint32_t> vp_ell;        // the same lists as ELL [max_partials][nv_pad], 0xffffffff = none
+    // fused particle pass (pj_blocked.hip): per tile slot, the partial sums of ITS particle (= the particle's vp list) as ELL
+    // [max_partials][ns_pad], 0xffffffff = none; per tile, the longest such list among its slots
+    std::vector<uint32_t> slot_src;
+    std::vector<uint32_t> blk_maxsrc;    // [num_blocks]
+    uint32_t ns_pad = 0;
+    bool every_owned_particle_has_a_partial = true;   // else some particle is summed by no tile: the fused pass cannot serve it
     uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
     uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no particle >= nv_sum (no ghost)

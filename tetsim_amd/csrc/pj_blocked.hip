@@ -53,6 +53,35 @@ namespace {
 
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd) { return (b & 7u) * tiles_per_xcd + (b >> 3); }
 
+// P5's division + P6 + P7 (+ P1, P2 of the next substep) for one particle, shared by the particle kernel and by the fused
+// staging of the tet kernel (same function, same contraction: the two must agree bit for bit -- tetsim_step runs the former,
+// tetsim_step_n the latter).  acc = sum of V*goal, wsum = sum of V (a constant), prev = end of the previous substep.
+struct VertexOut { f3 p, vel, pred; };
+__device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 prev, const DevParams& P, uint32_t v) {
+    const float rw = __builtin_amdgcn_rcpf(wsum);
+    f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
+    // P6, SoftbodyGPU.js:340-355
+    if (static_cast<int32_t>(v) == P.grab_local || static_cast<int32_t>(v) == P.grab_local2) p = F3(P.grab[0], P.grab[1], P.grab[2]);
+    p.x = fminf(fmaxf(p.x, P.lo[0]), P.hi[0]);
+    p.y = fminf(fmaxf(p.y, P.lo[1]), P.hi[1]);
+    p.z = fminf(fmaxf(p.z, P.lo[2]), P.hi[2]);
+    if (p.y < 0.0f) {
+        p.y = 0.0f;
+        const f3 F = prev - p;
+        const float fr = fminf(1.0f, P.dt * P.friction);
+        p.x += F.x * fr;
+        p.z += F.z * fr;
+    }
+    // P7, :364-372, then P1 + P2 of the next substep
+    const float dt = P.dt;
+    const float rdt = __builtin_amdgcn_rcpf(dt);
+    VertexOut o;
+    o.p = p;
+    o.vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * dt;
+    o.pred = p + o.vel * dt;
+    return o;
+}
+
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
@@ -76,7 +105,7 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 #endif
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
-template <bool kLean>
+template <bool kLean, bool kFused>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
@@ -111,12 +140,52 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     const uint32_t slot = v0 + (has_slot ? tid : 0u), e = t0 + (has_tet ? tid : 0u);
     const uint32_t vid = static_cast<uint32_t>(d.blk_verts[slot]);   // (unsigned: no sign extension right behind the load)
     const uint32_t range = has_slot ? d.lc_range[slot] : 0u;
+    // kFused: the particle update of the PREVIOUS substep happens here, for this tile's own particles (a particle in k tiles is
+    // updated k times, identically; the tile holding the first of its partial sums -- `owner` -- writes the result back): the
+    // slot's list of partial sums is requested together with its particle id (round trip 1), then the sums themselves, the
+    // particle's previous position and weight together with the tet record (round trip 2).  One kernel per substep instead of
+    // two: the particle kernel's launch, its 30 MB and a second dependency bubble per substep are gone, for one more gather
+    // level here.  Partial sums and positions are double buffered (other tiles still read the old ones).
+    uint32_t src[8];
+    uint32_t src8 = 0xffffffffu;
+    [[maybe_unused]] uint32_t maxsrc = 0;
+    if constexpr (kFused) {
+        maxsrc = d.blk_maxsrc[b];
+        const uint32_t* col = d.slot_src + slot;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) src[j] = (j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;   // (uniform)
+        if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
+    }
     const uchar4 li = d.tet_lidx[e];
     const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
     const float4 q_old = d.quat[e];
     const float V = d.vol[e];
     const uint2 ent_row = d.lc_ent[e];
-    const float4 pos_stage = d.pos_pred[vid];
+    float4 pos_stage;
+    if constexpr (kFused) {
+        // (a ghost would keep its received prediction; fused bodies have none)
+        f3 g[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {   // ascending tile order, absent = +0: the particle kernel's order of additions
+            const float4 t = d.partial_prev[src[j] == 0xffffffffu ? 0u : src[j]];
+            g[j] = src[j] == 0xffffffffu ? F3(0.0f, 0.0f, 0.0f) : xyz(t);
+        }
+        const float4 t8 = d.partial_prev[src8 == 0xffffffffu ? 0u : src8];
+        const float4 prev4 = d.fin_in[vid];
+        const float wsum = d.wsum[vid];
+        f3 acc = F3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
+        if (src8 != 0xffffffffu) { acc.x += t8.x; acc.y += t8.y; acc.z += t8.z; }
+        const VertexOut o = pjb_vertex_update(acc, wsum, xyz(prev4), *d.params, vid);
+        pos_stage = make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f);
+        if (has_slot && ((range >> 15) & 1u)) {   // one writer per particle
+            store_wt(d.fin_out, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
+            store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+        }
+    } else {
+        pos_stage = d.pos_pred[vid];
+    }
     if (has_slot) s_pos[tid] = pos_stage;
     if (has_tet) s_ent[tid] = ent_row;
     TETSIM_STAMP(1);  // loads issued (and landed, for this wave)
@@ -162,7 +231,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 
     // 3. one lane per tile particle: fixed-order sum of its corner goals -> one partial per (tile, particle)
     if (tid < nu) {
-        const uint32_t first = range & 0xffffu, last = range >> 16;
+        const uint32_t first = range & 0x7ffu, last = range >> 16;   // (bit 15: owner flag)
         const uint16_t* ent = reinterpret_cast<const uint16_t*>(s_ent);
         // An entry is the word offset corner * kTile + tet of a corner goal in the planes (host_prep.cpp), so its byte offset
         // and the byte offset of its tet's weight are one shift and one mask.  4 entries per trip: the 4 index reads, then
@@ -197,11 +266,20 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                         uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+// ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                               uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                                             uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<true, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 
 // ---- cross-queue hand-over of partitioned bodies ----------------------------------------------------------
@@ -242,7 +320,6 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = first + i;
-    const DevParams& P = *d.params;
 
     // P5 (SoftbodyGPU.js:302-320) from tile partial sums, ascending tile order.  The index lists are ELL
     // (column-major, coalesced, no offset lookup first), fetched 8 columns at a time: the kernel is two dependent memory
@@ -261,32 +338,11 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
         for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
         if (__all(idx[7] == 0xffffffffu)) break;  // lists are front-packed: nobody in this wave has a ninth partial
     }
-    // sum of the rest volumes of the particle's (live) corners: a constant, added up on the host in the tiles' entry order
-    const float rw = __builtin_amdgcn_rcpf(d.wsum[v]);
-    f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
-
-    // P6, :340-355
-    const f3 prev = xyz(d.pos_final[v]);
-    if (static_cast<int32_t>(v) == P.grab_local || static_cast<int32_t>(v) == P.grab_local2) p = F3(P.grab[0], P.grab[1], P.grab[2]);
-    p.x = fminf(fmaxf(p.x, P.lo[0]), P.hi[0]);
-    p.y = fminf(fmaxf(p.y, P.lo[1]), P.hi[1]);
-    p.z = fminf(fmaxf(p.z, P.lo[2]), P.hi[2]);
-    if (p.y < 0.0f) {
-        p.y = 0.0f;
-        const f3 F = prev - p;
-        const float fr = fminf(1.0f, P.dt * P.friction);
-        p.x += F.x * fr;
-        p.z += F.z * fr;
-    }
-    // P7, :364-372, then P1 + P2 of the next substep (everything computed before the first store: a parameter re-read
-    // behind a store would wait for that store's trip to HBM)
-    const float dt = P.dt;
-    const float rdt = __builtin_amdgcn_rcpf(dt);
-    const f3 vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * dt;
-    const f3 pred = p + vel * dt;
-    store_wt(d.pos_final, v, make_float4(p.x, p.y, p.z, 0.0f));
-    store_wt(d.vel, v, make_float4(vel.x, vel.y, vel.z, 0.0f));
-    store_wt(d.pos_pred, v, make_float4(pred.x, pred.y, pred.z, 0.0f));
+    // (the weight: sum of the rest volumes of the particle's live corners -- a constant, added up on the host in the tiles' entry order)
+    const VertexOut o = pjb_vertex_update(xyz(acc), d.wsum[v], xyz(d.fin_in[v]), *d.params, v);
+    store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
+    store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+    store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
@@ -324,6 +380,13 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+}
+void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
+    if (d.nb == 0) return;
+    const uint32_t per_xcd = (d.nb + 7u) / 8u;
+    auto* kernel = d.lean ? pjb_tet_fused_kernel_constant_rest : pjb_tet_fused_kernel;
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }

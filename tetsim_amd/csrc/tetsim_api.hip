@@ -101,6 +101,33 @@ void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0, hi
     if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
     else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count, e0, e1) : pj_launch_vertex_precise(h->stream, h->pj, first, count, e0, e1);
 }
+// One substep of a fused body inside a run of substeps with one dt:
+//   first substep:  plain tet kernel (predictions of the previous call's particle kernel)          -> partial sums A
+//   substep s >= 1: fused kernel = particle update of s-1 (partial sums of s-1, positions in/out double buffered) + tet pass s
+//   last substep:   ... followed by the particle kernel, which always leaves the positions in pj.pos_final
+// e[0..3]: begin / end events of the tet (or fused) kernel and of the particle kernel (tetsim_profile)
+void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e) {
+    PJBlk k = h->blk;
+    if (first) { h->fuse_step = 0; h->fin_in_b = false; }
+    const uint32_t s = h->fuse_step++;
+    float4* const pbuf[2] = {h->blk.partial, h->partial_b};
+    float4* const fbuf[2] = {h->pj.pos_final, h->pos_final_b};
+    k.partial = pbuf[s & 1u];
+    if (s == 0) pjb_launch_tet(h->stream, k, 0, k.nb, e ? e[0] : nullptr, e ? e[1] : nullptr);
+    else {
+        k.partial_prev = pbuf[(s - 1u) & 1u];
+        k.fin_in = fbuf[h->fin_in_b ? 1 : 0];
+        k.fin_out = fbuf[h->fin_in_b ? 0 : 1];
+        pjb_launch_tet_fused(h->stream, k, e ? e[0] : nullptr, e ? e[1] : nullptr);
+        h->fin_in_b = !h->fin_in_b;
+    }
+    if (last) {
+        k.fin_in = fbuf[h->fin_in_b ? 1 : 0];
+        k.fin_out = h->pj.pos_final;
+        pjb_launch_vertex(h->stream, k, 0, h->pj.nv_owned, e ? e[2] : nullptr, e ? e[3] : nullptr);
+        h->fin_in_b = false;
+    }
+}
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
     else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
@@ -129,6 +156,8 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
             int rc = enqueue_phase_a(h);
             if (!rc) rc = enqueue_phase_b(h);
             if (rc) return rc;
+        } else if (h->fused) {
+            pj_fused_substep(h, first, last, nullptr);
         } else {
             pj_tet(h);
             pj_vertex(h, 0, h->pj.nv_owned);
@@ -953,6 +982,8 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     for (uint32_t i = 0; i < n; i++) {
         if (pjs && halo) {
             if ((rc = enqueue_phase_a(h, &ev[4 * i])) || (rc = enqueue_phase_b(h))) break;
+        } else if (pjs && h->fused) {   // tet | fused x (n-1) | particle: what tetsim_step_n runs
+            pj_fused_substep(h, i == 0, i + 1 == n, &ev[4 * i]);
         } else if (pjs) {
             pj_tet(h, ev[4 * i], ev[4 * i + 1]);
             pj_vertex(h, 0, h->pj.nv_owned, ev[4 * i + 2], ev[4 * i + 3]);
@@ -973,7 +1004,12 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
     float ms = 0.0f;
     for (uint32_t i = 0; i < n; i++) {
         float a = 0, b = 0, c = 0;
-        if (pjs) {
+        if (pjs && h->fused && !halo) {
+            // TETSIM_K_TET = the FUSED kernels (substeps 1..n-1: particle update + tet pass; the plain first tet kernel of the call is
+            // not counted), TETSIM_K_VERTEX = the one particle kernel that ends the call
+            if (i > 0) { HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1])); out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET]++; }
+            if (i + 1 == n) { HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3])); out->kernel_ms[TETSIM_K_VERTEX] += b; out->launches[TETSIM_K_VERTEX]++; }
+        } else if (pjs) {
             HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
             HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
             out->kernel_ms[TETSIM_K_TET] += a; out->kernel_ms[TETSIM_K_VERTEX] += b;

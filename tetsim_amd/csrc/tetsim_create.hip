@@ -179,7 +179,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             for (uint32_t b = 0; b < B.num_blocks; b++) {
                 const uint32_t t0 = B.blk_tet_off[b], v0 = B.blk_vert_off[b], nu = B.blk_vert_off[b + 1] - v0;
                 for (uint32_t u = 0; u < nu; u++) {
-                    const uint32_t first = B.lc_range[v0 + u] & 0xffffu, last = B.lc_range[v0 + u] >> 16;
+                    const uint32_t first = B.lc_range[v0 + u] & 0x7ffu, last = B.lc_range[v0 + u] >> 16;   // (bit 15: owner flag)
                     float w = 0.0f;
                     for (uint32_t i = first; i < last; i++) w += volh[t0 + (B.lc_ent[4ull * t0 + i] % kBlockTile)];
                     slot_w[v0 + u] = w;
@@ -198,6 +198,31 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = dev_alloc(h, &dws, wsum.size()))) return rc;
         if ((rc = upload(h, dws, wsum))) return rc;
         k.wsum = dws;
+        // fused particle pass: unpartitioned bodies whose every particle is summed by some tile, lists of at most 9 partial sums
+        // (8 in one trip + 1), TETSIM_FUSED_PARTICLE_PASS=0 keeps the two-kernel substep (development A/B)
+        static const bool allow_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return !(e && e[0] == '0'); }();
+        // ... and only where it pays: a body of fewer tiles than the chip has workgroup slots (2,048) is bound by launches and
+        // dependency bubbles, and one kernel per substep instead of two is worth +21% on the Dragon (15 tiles; profiles/r02h_*); the
+        // 1 M-tet lattice (3,900 tiles) gains nothing -- the fused kernel costs what the particle kernel and its bubble cost
+        // (32.0 us against 25.6 + 5.8), needs 74 registers instead of 49 (6 waves per SIMD instead of 8) and reads lower on the
+        // roofline -- and keeps the two-kernel substep.  TETSIM_FUSED_PARTICLE_PASS=1 forces it on (A/B).
+        static const bool force_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return e && e[0] == '1'; }();
+        h->fused = allow_fused && !h->partitioned && nvo == nvl && B.every_owned_particle_has_a_partial && B.max_partials <= 9 && ntl > 0 &&
+                   (B.num_blocks < 2048u || force_fused);
+        k.fin_in = d.pos_final; k.fin_out = d.pos_final;
+        h->info.fused_particle_pass = h->fused ? 1u : 0u;
+        if (h->fused) {
+            uint32_t *dsrc, *dmax;
+            if ((rc = dev_alloc(h, &dsrc, B.slot_src.size()))) return rc;
+            if ((rc = dev_alloc(h, &dmax, B.blk_maxsrc.size()))) return rc;
+            if ((rc = dev_alloc(h, &h->partial_b, nslots))) return rc;
+            if ((rc = dev_alloc(h, &h->pos_final_b, nvl))) return rc;
+            if ((rc = upload(h, dsrc, B.slot_src))) return rc;
+            if ((rc = upload(h, dmax, B.blk_maxsrc))) return rc;
+            HIPCHK(h, hipMemset(h->partial_b, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
+            if ((rc = upload(h, h->pos_final_b, pos))) return rc;
+            k.slot_src = dsrc; k.blk_maxsrc = dmax; k.ns_pad = B.ns_pad;
+        }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
         if ((rc = upload(h, bv, B.blk_verts))) return rc;
