@@ -19,6 +19,11 @@
 // Tried and dropped in round 2 (profiles/r02b_kernel_variants.txt): the staged positions as three f32 planes instead of float4
 // (12 ds_read_b32 instead of 4 ds_read_b128 per tet: 29.5 vs 29.0 us), and 128-tet tiles (-DTETSIM_TILE=128: 16 workgroups per
 // CU, tet kernel 28.3-30.5 us against 29.0, but 15% more partial sums: particle pass 6.5 vs 5.8 us, no gain overall).
+// ... and a second attempt at a persistent, software-pipelined kernel (commit 645542b: workgroups resident over several tiles, the next
+// tile's record AND position gather in flight during the solve -- ids two tiles ahead, headers through scalar loads, partial sums
+// leaving one tile late so that the one drain point per tile finds everything landed; correct, 86 registers, 5 waves per SIMD):
+// 33.4-35.0 us against 28.3-29.2 (profiles/r02j_pipelined_kernel_ab.txt).  What eight independent workgroups per CU overlap for
+// free, one pipelined workgroup pays for in registers, occupancy and rotation moves.
 // Tried and dropped (measured on the 1 M-tet lattice): (a) a persistent variant prefetching tile i+1
 // during tile i's solve, with scalar tile headers, a 3-deep index pipeline, a peeled first trip and counted
 // vmcnt waits: 49 us vs 42-44 us, its 0-iteration base is already slower (32.5 vs 28.5 us); (b) having the particle
@@ -264,152 +269,6 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 #undef TETSIM_STAMP
 }
 
-// ---- persistent, software-pipelined variant (experiment of round 2; TETSIM_TET_PIPELINE=1) ----------------------------------
-// pjb_tet_kernel behaves like a synchronous two-phase machine: the 2,048 workgroups of a round issue their loads together
-// (memory busy, nobody computes), then compute together (memory idle) -- DESIGN.md 5.3.  Here a workgroup stays resident and
-// walks over several tiles of its XCD's range; while it solves tile i its loads for tile i+1 -- the tet record AND the
-// position gather, whose particle ids were fetched one tile earlier still -- are in flight, and the partial sums of tile i
-// leave at the start of tile i+1, so that the one point per tile where the wave drains its memory counter (gfx9: one
-// in-order counter for loads and stores) finds everything landed long ago.  Staging buffers alternate by tile parity: two
-// barriers per tile, as before.
-struct PipeRec { uint32_t li; float4 ra, rb, rc, q; float V; uint2 ent; };   // li: the 4 corner slots, kept packed (unpacked where used:
-                                                                             // an unpack at the load would wait for the load)
-__device__ __forceinline__ PipeRec pipe_load_rec(const PJBlk& d, uint32_t e) {
-    PipeRec r;
-    r.li = reinterpret_cast<const uint32_t*>(d.tet_lidx)[e]; r.ra = d.rest_a[e]; r.rb = d.rest_b[e]; r.rc = d.rest_c[e]; r.q = d.quat[e]; r.V = d.vol[e]; r.ent = d.lc_ent[e];
-    return r;
-}
-template <bool kLean>
-__device__ __forceinline__ void pjb_tet_pipe_body(const PJBlk& d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t wgs_per_xcd) {
-    __shared__ float4 s_pos[2][kTile];
-    __shared__ uint2 s_ent[2][kTile];
-    __shared__ float s_gx[4 * kTile];
-    __shared__ float s_gy[4 * kTile];
-    __shared__ float s_gz[4 * kTile];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t xb = (blockIdx.x & 7u) * tiles_per_xcd, xe = min(xb + tiles_per_xcd, tile_count);
-    uint32_t b = xb + (blockIdx.x >> 3);
-    if (b >= xe) return;
-    // prologue: tile b completely, the particle ids of tile b + stride, the header of tile b + 2 stride (headers are fetched
-    // two tiles ahead, so that no request of an iteration depends on another request of the same iteration).
-    struct Hdr { uint32_t t0, ntb, v0, nu; };
-    // (read through the CONSTANT address space: these tables are never written by a kernel, and only that makes the compiler
-    // use scalar loads for them inside the loop -- with global pointers it falls back to vector loads, whose results it
-    // immediately needs in scalar registers: a full drain of the memory counter right behind the prefetch)
-    typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;
-    const const_u32_t bto = (const_u32_t)d.blk_tet_off, bvo = (const_u32_t)d.blk_vert_off;
-    auto header = [&](uint32_t t) { Hdr h; h.t0 = bto[t]; h.ntb = bto[t + 1] - h.t0; h.v0 = bvo[t]; h.nu = bvo[t + 1] - h.v0; return h; };
-    const Hdr none = {0u, 0u, 0u, 0u};
-    Hdr hc = header(b);
-    uint32_t slot = hc.v0 + (tid < hc.nu ? tid : 0u);
-    uint32_t vid_c = static_cast<uint32_t>(d.blk_verts[slot]);
-    uint32_t range_c = d.lc_range[slot];
-    PipeRec rec_c = pipe_load_rec(d, hc.t0 + (tid < hc.ntb ? tid : 0u));
-    float4 pos_c = d.pos_pred[vid_c];
-    uint32_t bn = b + wgs_per_xcd;            // next tile, bn + stride = the one after, ...
-    Hdr hn = bn < xe ? header(bn) : none;
-    Hdr hn2 = bn + wgs_per_xcd < xe ? header(bn + wgs_per_xcd) : none;
-    uint32_t vid_n = 0, range_n = 0;
-    if (bn < xe) {
-        const uint32_t sn = hn.v0 + (tid < hn.nu ? tid : 0u);
-        vid_n = static_cast<uint32_t>(d.blk_verts[sn]);
-        range_n = d.lc_range[sn];
-    }
-    float4 out_prev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t out_slot = 0;
-    bool out_valid = false;
-    uint32_t par = 0;
-    for (;;) {
-        const bool has_next = bn < xe;
-        const uint32_t t0 = hc.t0, ntb = hc.ntb, v0 = hc.v0, nu = hc.nu;
-        // 1. the drain point: everything requested for this tile one tile ago has landed (the compiler waits here)
-        if (out_valid) store_wt(d.partial, out_slot, out_prev);
-        const bool has_slot = tid < nu, has_tet = tid < ntb;
-        if (has_slot) s_pos[par][tid] = pos_c;
-        if (has_tet) s_ent[par][tid] = rec_c.ent;
-        // 2. requests for the next tile (in flight during the solve), the ids of the one after it, the header of the third
-        PipeRec rec_n = rec_c;
-        float4 pos_n = pos_c;
-        uint32_t vid_n2 = 0, range_n2 = 0;
-        Hdr hn3 = none;
-        if (has_next) {
-            rec_n = pipe_load_rec(d, hn.t0 + (tid < hn.ntb ? tid : 0u));
-            pos_n = d.pos_pred[vid_n];
-            const uint32_t bn2 = bn + wgs_per_xcd;
-            if (bn2 < xe) {
-                const uint32_t s2 = hn2.v0 + (tid < hn2.nu ? tid : 0u);
-                vid_n2 = static_cast<uint32_t>(d.blk_verts[s2]);
-                range_n2 = d.lc_range[s2];
-                if (bn2 + wgs_per_xcd < xe) hn3 = header(bn2 + wgs_per_xcd);
-            }
-        }
-        __syncthreads();
-        // 3. solve (as pjb_tet_body)
-        if (has_tet) {
-            const uint32_t li = rec_c.li;
-            f3 cur[4], rest[4], goal[4];
-            cur[0] = xyz(s_pos[par][li & 0xffu]); cur[1] = xyz(s_pos[par][(li >> 8) & 0xffu]);
-            cur[2] = xyz(s_pos[par][(li >> 16) & 0xffu]); cur[3] = xyz(s_pos[par][li >> 24]);
-            rest[0] = F3(rec_c.ra.x, rec_c.ra.y, rec_c.ra.z); rest[1] = F3(rec_c.ra.w, rec_c.rb.x, rec_c.rb.y);
-            rest[2] = F3(rec_c.rb.z, rec_c.rb.w, rec_c.rc.x); rest[3] = F3(rec_c.rc.y, rec_c.rc.z, rec_c.rc.w);
-            float4 q_new;
-            f3 cc;
-            pj_solve_tet(cur, rest, rec_c.q, q_new, goal, 9, true, kLean, !kLean, &cc);
-            const float V = rec_c.V;
-            const f3 vcc = cc * V;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                s_gx[k * kTile + tid] = fmaf(goal[k].x, V, vcc.x);
-                s_gy[k * kTile + tid] = fmaf(goal[k].y, V, vcc.y);
-                s_gz[k * kTile + tid] = fmaf(goal[k].z, V, vcc.z);
-            }
-            const uint32_t e = t0 + tid;
-            store_wt(d.quat, e, q_new);
-            if (!kLean) {
-                store_wt(d.rest_a, e, make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
-                store_wt(d.rest_b, e, make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
-                store_wt(d.rest_c, e, make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
-            }
-        }
-        __syncthreads();
-        // 4. reduction (as pjb_tet_body); the partial sum leaves at the start of the next tile
-        out_valid = has_slot;
-        out_slot = v0 + tid;
-        if (has_slot) {
-            const uint32_t first = range_c & 0x7ffu, last = range_c >> 16;
-            const uint16_t* ent = reinterpret_cast<const uint16_t*>(s_ent[par]);
-            auto plane = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
-            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            uint32_t i = first;
-            for (; i + 4u <= last; i += 4u) {
-                uint32_t o[4];
-                float gx[4], gy[4], gz[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) o[j] = static_cast<uint32_t>(ent[i + j]) << 2;
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) { gx[j] = plane(s_gx, o[j]); gy[j] = plane(s_gy, o[j]); gz[j] = plane(s_gz, o[j]); }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; }
-            }
-            for (; i < last; i++) {
-                const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
-                acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
-            }
-            out_prev = acc;
-        }
-        if (!has_next) break;
-        // 5. rotate
-        hc = hn; hn = hn2; hn2 = hn3;
-        rec_c = rec_n; pos_c = pos_n; range_c = range_n;
-        bn += wgs_per_xcd; vid_n = vid_n2; range_n = range_n2;
-        par ^= 1u;
-    }
-    if (out_valid) store_wt(d.partial, out_slot, out_prev);
-}
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_pipe_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t wgs_per_xcd) {
-    pjb_tet_pipe_body<false>(d, tile_count, tiles_per_xcd, wgs_per_xcd);
-}
-
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                         uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
@@ -523,13 +382,6 @@ static uint32_t tet_mode() {
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
     if (tile_count == 0) return;
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    static const int pipe_wgs = [] { const char* e = getenv("TETSIM_TET_PIPELINE"); return e ? atoi(e) : 0; }();   // workgroups per CU of the persistent variant (experiment)
-    if (pipe_wgs > 0 && !d.lean && tile_first == 0 && tile_count > 32u * 8u * static_cast<uint32_t>(pipe_wgs)) {
-        const uint32_t wgs_per_xcd = 32u * static_cast<uint32_t>(pipe_wgs);
-        if (e0) hipExtLaunchKernelGGL(pjb_tet_pipe_kernel, dim3(wgs_per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_count, per_xcd, wgs_per_xcd);
-        else hipLaunchKernelGGL(pjb_tet_pipe_kernel, dim3(wgs_per_xcd * 8u), dim3(kTile), 0, s, d, tile_count, per_xcd, wgs_per_xcd);
-        return;
-    }
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
