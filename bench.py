@@ -437,27 +437,39 @@ def slab_owner(nverts, cells, nz, world):
     return np.minimum((np.arange(nverts) // plane) // layers, world - 1).astype(np.int32)
 
 
-def make_body(args, cells, scaling, rank, world, local_rank, ranks):
-    """This rank's body of the cells^2 x (cells [x world when weak]) lattice (+ communicator when ranks is not None)."""
+def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False):
+    """This rank's body of the cells^2 x (cells [x world when weak]) lattice (+ communicator when ranks is not None).
+    vote=True: creation (local, may fail on one rank alone: memory, ...) is followed by a vote of all ranks BEFORE the collective
+    communicator set-up; if any rank failed, every rank returns (None, ..., error text) instead of hanging in the broadcast."""
     from tetsim_amd import SoftBodyHIP, make_lattice
     nz = cells * world if scaling == "weak" else cells
-    verts, tets = make_lattice(cells, nz=nz)
     pp = dict(PP)
-    kw = {}
-    if ranks is not None:
-        # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
-        # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
-        zext = 0.5 * (nz / cells) + 2.0
-        pp["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
-        kw = dict(part_count=world, part_index=rank, vert_owner=slab_owner(len(verts), cells, nz, world), ref_fixed_bounds=False)
-    if args.constant_rest_shape:
-        kw["constant_rest_shape"] = True
-    body = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision=args.precision, device=local_rank, **kw)
+    body, verts, tets, err = None, None, None, None
+    try:
+        verts, tets = make_lattice(cells, nz=nz)
+        kw = {}
+        if ranks is not None:
+            # the stacked lattice is `world` metres long in z: the reference's hard-coded +-2.5 m clamp (SoftbodyGPU.js:347)
+            # would squash it, so N > 1 runs honour physicsParams.worldBounds, widened along z
+            zext = 0.5 * (nz / cells) + 2.0
+            pp["worldBounds"] = [-2.5, -1.0, -zext, 2.5, 10.0, zext]
+            kw = dict(part_count=world, part_index=rank, vert_owner=slab_owner(len(verts), cells, nz, world), ref_fixed_bounds=False)
+        if args.constant_rest_shape:
+            kw["constant_rest_shape"] = True
+        body = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision=args.precision, device=local_rank, **kw)
+    except Exception as e:  # noqa: BLE001
+        if not vote:
+            raise
+        err = "rank %d: %r" % (rank, e)
+    if vote and ranks is not None and ranks.min_float(0.0 if err else 1.0) < 1.0:
+        if body is not None:
+            body.close()
+        return None, verts, tets, pp, nz, err or "another rank failed to create its partition"
     if ranks is not None:
         from tetsim_amd import comm_init, comm_unique_id
         uid = ranks.broadcast_bytes(comm_unique_id() if rank == 0 else None, 128)
         comm_init(body, uid, rank, world)
-    return body, verts, tets, pp, nz
+    return body, verts, tets, pp, nz, None
 
 
 def timed_frames(body, pp, steps, warmup, ranks):
@@ -528,7 +540,7 @@ def run(args, rank, world, local_rank, ranks):
         out, body = run_neohookean(args, verts, tets, local_rank)
         out["library"] = library_info()
         return out, body
-    body, verts, tets, pp, nz = make_body(args, cells, args.scaling, rank, world, local_rank, ranks)
+    body, verts, tets, pp, nz, _ = make_body(args, cells, args.scaling, rank, world, local_rank, ranks)
     nt_global = len(tets)
 
     # ---- timed region --------------------------------------------------------------------------------
@@ -603,22 +615,27 @@ def run(args, rank, world, local_rank, ranks):
                            "substep_alg_bytes_per_tet": round(b_alg, 1)}
     # ---- BASELINE config 5, literally: the 110^3-cell lattice (7,986,000 tets) cut into N slabs -- strong scaling -----------
     if use_dist and (args.config5 == "on" or (args.config5 == "auto" and world == 8)) and not (args.scaling == "strong" and cells == args.config5_cells):
-        c5 = None
-        body.close()
-        body, v5, t5, pp5, _ = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks)
-        steps5 = max(1, min(args.steps, 10))
-        e5_local, h5_local = timed_frames(body, pp5, steps5, min(args.warmup, 2), ranks)
-        e5 = ranks.max_float(e5_local)
-        finite = ranks.min_float(1.0 if np.isfinite(body.pos).all() else 0.0)
-        mg5 = multi_gpu_report(body, world, e5_local, h5_local, steps5, ranks)
-        if rank == 0:
-            v = len(t5) * SUBSTEPS * steps5 / e5 / 1e6
-            c5 = {"workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles) cut into %d z-slabs, %d-particle interface planes, "
-                              "polar-decomposition Jacobi, %d substeps/frame" % (args.config5_cells, len(t5), len(v5), world, (args.config5_cells + 1) ** 2, SUBSTEPS),
-                  "scaling": "strong", "value": round(v, 1), "unit": "M tet-solves/s", "steps": steps5, "ms_per_step": round(e5 / steps5 * 1e3, 4),
-                  "finite": bool(finite), "multi_gpu": mg5,
-                  "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
-            out["config5_strong"] = c5
+        # (the headline body stays alive: if this second body cannot be built on some rank, the line above is still reported)
+        body5, v5, t5, pp5, _, err5 = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks, vote=True)
+        if body5 is None:
+            if rank == 0:
+                out["config5_strong"] = {"error": err5}
+        else:
+            body.close()
+            body = body5
+            steps5 = max(1, min(args.steps, 10))
+            e5_local, h5_local = timed_frames(body, pp5, steps5, min(args.warmup, 2), ranks)
+            e5 = ranks.max_float(e5_local)
+            finite = ranks.min_float(1.0 if np.isfinite(body.pos).all() else 0.0)
+            mg5 = multi_gpu_report(body, world, e5_local, h5_local, steps5, ranks)
+            if rank == 0:
+                v = len(t5) * SUBSTEPS * steps5 / e5 / 1e6
+                out["config5_strong"] = {
+                    "workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles) cut into %d z-slabs, %d-particle interface planes, "
+                                "polar-decomposition Jacobi, %d substeps/frame" % (args.config5_cells, len(t5), len(v5), world, (args.config5_cells + 1) ** 2, SUBSTEPS),
+                    "scaling": "strong", "value": round(v, 1), "unit": "M tet-solves/s", "steps": steps5, "ms_per_step": round(e5 / steps5 * 1e3, 4),
+                    "finite": bool(finite), "multi_gpu": mg5,
+                    "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
     if world == 1:
         body.close()
         if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
