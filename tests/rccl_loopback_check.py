@@ -19,14 +19,16 @@ owner = np.minimum((np.arange(len(v)) // plane) // cells, 2).astype(np.int32)
 owner[(np.arange(len(v)) // plane) >= 2 * cells] = 2
 body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision, part_count=3, part_index=1, vert_owner=owner, ref_fixed_bounds=False)
 comm_init(body, comm_unique_id(), 0, 1)
-seq = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else "7,7,20,-1,7,20".split(","))]
-for n in seq:      # the first call is always eager; repeated sizes replay a cached graph; -1 = one eager tetsim_step in between
+seq = (sys.argv[3] if len(sys.argv) > 3 else "7,7,20,-1,7,20,7x2,7x2,20").split(",")
+for item in seq:   # the first call is always eager; repeated sizes replay cached graphs; -1 = one eager tetsim_step in between;
+    n, _, f = item.partition("x")   # "7x2" = 7 substeps with dt * 2: the re-prediction hand-over in front of a replayed graph
+    n, dt = int(n), DT * (float(f) if f else 1.0)
     if n < 0:
-        body.simulate(DT, PP)
+        body.simulate(dt, PP)
     else:
-        body.simulateSubsteps(n, DT, PP)
+        body.simulateSubsteps(n, dt, PP)
     if os.environ.get("LOOPBACK_VERBOSE"):
-        body.sync(); print("done", n, flush=True)
+        body.sync(); print("done", item, flush=True)
 pos = body.pos
 assert np.isfinite(pos).all()
 print("HASH", hashlib.sha256(np.ascontiguousarray(pos, dtype="<f4").tobytes()).hexdigest()[:16], "ymin %.4f" % float(pos[:, 1].min()), flush=True)
