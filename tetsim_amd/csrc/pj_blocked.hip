@@ -129,6 +129,14 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 #define TETSIM_STAMP(i) do { } while (0)
 #endif
     TETSIM_STAMP(0);
+#ifdef TETSIM_ABLATION
+    // TETSIM_DEBUG_STAGGER=<s_sleep units of 64 cycles>: workgroups of the first round delay their loads by (slot index) x that
+    // much, slot index guessed from the dispatch order in two ways (bit 16 of the mode word selects which)
+    if (const uint32_t st = (dbg >> 8) & 0xffu; st != 0u && blockIdx.x < 2048u) {
+        const uint32_t k = (dbg & 0x10000u) ? (blockIdx.x >> 3) & 7u : (blockIdx.x >> 8) & 7u;
+        for (uint32_t i = 0; i < k * st; i++) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
 
@@ -370,7 +378,10 @@ static uint32_t tet_mode() {
         const char* it = getenv("TETSIM_DEBUG_ITERS");
         const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
         const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
-        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((np && np[0] == '1') ? 64 : 0);
+        const char* sg = getenv("TETSIM_DEBUG_STAGGER");
+        const char* sm = getenv("TETSIM_DEBUG_STAGGER_MAP");
+        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((np && np[0] == '1') ? 64 : 0) | (sg ? ((atoi(sg) & 255) << 8) : 0) |
+              ((sm && sm[0] == '1') ? 0x10000 : 0);
         fprintf(stderr, "[tetsim] WARNING: ABLATION build of libtetsim_hip (mode 0x%x): timing experiments only, the results are NOT the solver's\n", dbg);
     }
     return static_cast<uint32_t>(dbg);
