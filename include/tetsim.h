@@ -354,6 +354,15 @@ int tetsim_prep_colours(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *
  * launch[a] < launch[b], or the same launch AND lane with step[a] < step[b]. */
 int tetsim_prep_clusters(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *order, int32_t *launch, int32_t *lane,
                          int32_t *step, uint32_t *num_launches, uint32_t *num_clusters);
+/* The tile plan of the blocked polar kernels for a mesh or a batch of meshes (body_first_tet / body_first_vert
+ * [bodies + 1] as tetsim_create_batch lays them out; NULL = one body): tets in tile order (tile_tets[i] = input tet at position
+ * i), tile offsets into it (tile_off [tiles + 1]; pass NULL arrays to query *num_tiles first: at most nt of them), and per
+ * position the tile-local particle slot of each corner (corner_slot [4 * nt], < 256).  Host only; what the property tests check:
+ * <= 256 tets and <= 256 particles per tile, every tet in exactly one tile, no tile spanning two bodies, a body tiled in a batch
+ * exactly as alone. */
+int tetsim_prep_tiles(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt, const uint32_t *body_first_tet,
+                      const uint32_t *body_first_vert, uint32_t bodies, int32_t *tile_tets, uint32_t *tile_off,
+                      uint8_t *corner_slot, uint32_t *num_tiles);
 /* Scatter table of SoftbodyGPU.js:563-577: slots[v*36 + s] = 4*tet + corner, -1 = empty.
  * ref_quirk != 0 reproduces the `<= 0.0` test.  Returns the number of dropped contributions. */
 int tetsim_prep_slot_table(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t ref_quirk,

@@ -93,3 +93,68 @@ def test_partition_plans_fit_together(m, parts, rnd):
             assert np.array_equal(pl.local_to_global_vert[nb.recv_start:nb.recv_start + nb.recv_count], nb.recv_global)
         received = np.concatenate([nb.recv_global for nb in pl.neighbours]) if pl.neighbours else np.zeros(0, np.int32)
         assert sorted(received.tolist()) == sorted(ghosts.tolist())       # every ghost is refreshed by exactly one neighbour
+
+
+def _tiles(verts, tets, first_tet=None, first_vert=None):
+    """tetsim_prep_tiles -> (tile_tets, tile_off, corner_slot)"""
+    L = capi.lib()
+    v = np.ascontiguousarray(verts, np.float32).ravel()
+    t = np.ascontiguousarray(tets, np.int32).ravel()
+    nt, nv = len(t) // 4, len(v) // 3
+    bodies = 0 if first_tet is None else len(first_tet) - 1
+    ft = None if first_tet is None else (C.c_uint32 * len(first_tet))(*first_tet)
+    fv = None if first_vert is None else (C.c_uint32 * len(first_vert))(*first_vert)
+    tile_tets, off, slot, n = np.empty(nt, np.int32), np.empty(nt + 1, np.uint32), np.empty(4 * nt, np.uint8), C.c_uint32()
+    rc = L.tetsim_prep_tiles(v.ctypes.data_as(C.POINTER(C.c_float)), nv, _ip(t), nt, ft, fv, bodies, _ip(tile_tets),
+                             off.ctypes.data_as(C.POINTER(C.c_uint32)), slot.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n))
+    assert rc == 0, L.tetsim_last_error(None)
+    return tile_tets, off[:n.value + 1], slot.reshape(-1, 4)
+
+
+@st.composite
+def geometric_meshes(draw):
+    nv, t = draw(meshes())
+    seed = draw(st.integers(0, 2 ** 16))
+    verts = np.random.RandomState(seed).rand(nv, 3).astype(np.float32)
+    return verts, t
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(geometric_meshes(), min_size=1, max_size=4))
+def test_tile_plan_of_batches(bodies):
+    """The blocked kernels' tiles (tetsim_prep_tiles): a partition of the tets into runs of <= 256 tets over <= 256 particles,
+    with consistent tile-local corner slots; in a batch no tile spans two bodies and every body is tiled exactly as alone."""
+    fv = np.concatenate([[0], np.cumsum([len(v) for v, _ in bodies])])
+    ft = np.concatenate([[0], np.cumsum([len(t) for _, t in bodies])])
+    verts = np.concatenate([v for v, _ in bodies])
+    tets = np.concatenate([t + int(fv[i]) for i, (_, t) in enumerate(bodies)])
+    tile_tets, off, slot = _tiles(verts, tets, ft.tolist(), fv.tolist())
+    assert sorted(tile_tets.tolist()) == list(range(len(tets))) and off[0] == 0 and off[-1] == len(tets)
+    body_of = np.searchsorted(ft, tile_tets, side="right") - 1
+    for a, b in zip(off[:-1], off[1:]):
+        assert 0 < b - a <= 256
+        assert len(set(body_of[a:b].tolist())) == 1                      # one body per tile
+        corners = tets[tile_tets[a:b]]
+        ids = np.unique(corners)
+        assert len(ids) <= 256
+        assert np.array_equal(ids[slot[a:b]], corners)                   # slots = rank of the particle among the tile's particles
+    for i, (v, t) in enumerate(bodies):                                  # the same body alone: the same tiles
+        solo_tets, solo_off, solo_slot = _tiles(v, t)
+        mine = (body_of[off[:-1]] == i)
+        starts = off[:-1][mine]
+        assert np.array_equal(starts - ft[i], solo_off[:-1])
+        sel = slice(int(ft[i]), int(ft[i + 1]))
+        lo = int(starts[0]) if len(starts) else 0
+        assert np.array_equal(tile_tets[lo:lo + len(t)] - ft[i], solo_tets)
+        assert np.array_equal(slot[lo:lo + len(t)], solo_slot)
+
+
+def test_tile_plan_of_the_headline_lattice():
+    from tetsim_amd import make_lattice
+    v, t = make_lattice(20)
+    tile_tets, off, slot = _tiles(v, t)
+    sizes = np.diff(off)
+    assert sizes.max() <= 256 and sorted(tile_tets.tolist()) == list(range(len(t)))
+    assert len(sizes) <= -(-len(t) // 256) + len(t) // 2000          # the Morton runs fill their tiles (a few short ones at most)
+    with __import__("pytest").raises(AssertionError):
+        _tiles(v, t, [0, len(t)], [0, len(v) - 1])                    # body ranges must cover the mesh

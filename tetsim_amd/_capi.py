@@ -87,7 +87,7 @@ SYMBOLS = [
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
-    "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
+    "tetsim_prep_tiles", "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
     "tetsim_mesh_write", "tetsim_mesh_open", "tetsim_mesh_arrays", "tetsim_mesh_close", "tetsim_create_from_file",
 ]
@@ -164,6 +164,7 @@ def lib():
     L.tetsim_prep_levels.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_colours.argtypes = [ip, u32, u32, ip, C.POINTER(u32)]
     L.tetsim_prep_clusters.argtypes = [ip, u32, u32, ip, ip, ip, ip, C.POINTER(u32), C.POINTER(u32)]
+    L.tetsim_prep_tiles.argtypes = [fp, u32, ip, u32, C.POINTER(u32), C.POINTER(u32), u32, ip, C.POINTER(u32), C.POINTER(C.c_uint8), C.POINTER(u32)]
     L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
     L.tetsim_prep_ref_grab_texels.argtypes = [i32, u32, u32, ip]
     L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]

@@ -69,6 +69,31 @@ int tetsim_prep_clusters(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t*
     if (num_clusters) *num_clusters = P.num_clusters;
     return 0;
 }
+int tetsim_prep_tiles(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, const uint32_t* body_first_tet,
+                      const uint32_t* body_first_vert, uint32_t bodies, int32_t* tile_tets, uint32_t* tile_off, uint8_t* corner_slot,
+                      uint32_t* num_tiles) {
+    if (!num_tiles) return TETSIM_EINVAL;
+    std::string e = validate_mesh(verts, nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    if (body_first_tet && body_first_vert && bodies) {
+        if (body_first_tet[0] != 0 || body_first_vert[0] != 0 || body_first_tet[bodies] != nt || body_first_vert[bodies] != nv)
+            return fail(nullptr, TETSIM_EINVAL, "body ranges must cover the whole mesh");
+        for (uint32_t b = 0; b < bodies; b++) {
+            if (body_first_tet[b] > body_first_tet[b + 1] || body_first_vert[b] >= body_first_vert[b + 1]) return fail(nullptr, TETSIM_EINVAL, "body ranges must ascend");
+            for (uint64_t i = 4ull * body_first_tet[b]; i < 4ull * body_first_tet[b + 1]; i++)
+                if (static_cast<uint32_t>(tets[i]) < body_first_vert[b] || static_cast<uint32_t>(tets[i]) >= body_first_vert[b + 1])
+                    return fail(nullptr, TETSIM_EINVAL, "a tet references a particle of another body");
+        }
+    }
+    const Incidence inc = build_incidence(tets, nt, nv, false, false);
+    BlockPlan B;
+    build_blocks(verts, tets, nt, nv, nv, inc, &B, body_first_tet, body_first_vert, bodies);
+    *num_tiles = B.num_blocks;
+    if (tile_tets) std::copy(B.tet_perm.begin(), B.tet_perm.end(), tile_tets);
+    if (tile_off) std::copy(B.blk_tet_off.begin(), B.blk_tet_off.end(), tile_off);
+    if (corner_slot) std::copy(B.tet_lidx.begin(), B.tet_lidx.end(), corner_slot);
+    return 0;
+}
 int tetsim_prep_slot_table(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t ref_quirk, int32_t* slots, uint32_t* dropped) {
     if ((nt && !tets) || !slots) return TETSIM_EINVAL;
     std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv ? nv : 1, tets, nt, false);
