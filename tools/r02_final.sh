@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round-2 evidence batch (run ON the GPU box):  bash tools/r02_final.sh <tag>
 # 1. tolerance calibration of the whole GPU suite (TETSIM_RECORD_ERRORS) -> tolerances.json, 2. the suite again WITH the table,
-# 3. mutation check against the table, 4. bench line, 5. rocprofv3 kernel stats of the same command, 6. PMC passes (polar + NH).
+# 3. mutation check against the table, 4. PMC passes (polar + NH) -> pmc_traffic.json, 5. bench lines, 6. rocprofv3 kernel stats of the same command.
 set -u
 TAG=${1:-r02c}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -15,14 +15,15 @@ python tools/tolerance_report.py "$OUT/errors.jsonl" --write "$OUT/tolerances.js
 cp "$OUT/tolerances.json" tests/golden/tolerances.json
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -25 > "$OUT/pytest_with_table.log"
 timeout 900 bash tools/mutation_check.sh "$OUT/mutation" > "$OUT/mutation.txt" 2>&1
-timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
-( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/stats.log" 2>&1 )
-( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
 timeout 900 bash tools/pmc_run.sh $TAG/pmc > "$OUT/pmc.log" 2>&1
 BENCH_ARGS="--solver neohookean" timeout 900 bash tools/pmc_run.sh $TAG/pmc_nh > "$OUT/pmc_nh.log" 2>&1
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_counters.txt" 2>&1
 python tools/pmc_summary.py "$OUT/pmc_nh" > "$OUT/pmc_counters_nh.txt" 2>&1
 python tools/pmc_traffic.py "$OUT/pmc" "$OUT/pmc_traffic.json" > /dev/null 2>&1
+cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json   # keyed by kernel_sha: the bench lines below attach it to roofline.traffic
+timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
+( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/stats.log" 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
 find "$OUT" -name "*kernel_stats.csv" | head
 tail -3 "$OUT/pytest_calibration.log"; tail -6 "$OUT/pytest_with_table.log"; tail -12 "$OUT/mutation.txt"; head -c 600 "$OUT/bench.json"
