@@ -112,8 +112,11 @@ struct tetsim_body {
     hipEvent_t ev_boundary2[2] = {nullptr, nullptr}, ev_packed2[2] = {nullptr, nullptr}, ev_sent2[2] = {nullptr, nullptr};
     uint32_t halo_parity = 0;
     DevParams* d_params = nullptr;
+    DevParams* d_params_halo = nullptr;   // the same parameters, copied on the HALO stream (its boundary-particle pass reads them)
     DevParams* h_ring = nullptr;  // pinned [kRing]
     hipEvent_t ring_ev[kRing] = {};
+    hipEvent_t ring_ev_halo[kRing] = {};
+    bool ring_used_halo[kRing] = {};
     bool ring_used[kRing] = {};
     int ring_pos = 0;
     std::vector<int32_t> tet_colour;  // copy of TetSimOptions.tet_colour (create only)
@@ -136,6 +139,7 @@ struct tetsim_body {
     bool fused = false;
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
+    bool v_pending = false;           // flag path: the interior particles of the last enqueued substep are not signalled yet (flush_v)
     uint32_t fuse_step = 0;           // substep index inside the current run (enqueue_substep)
     bool fin_in_b = false;            // the latest end-of-substep positions are in pos_final_b (only between the kernels of one call)
     std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
@@ -244,6 +248,7 @@ uint32_t halo_timeout_ms();
 bool has_transport(const tetsim_body* h);
 bool uses_flag_sync(const tetsim_body* h);
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr);  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
+int flush_v(tetsim_body* h);                                    // flag path: the V hand-over that no following substep will carry
 int enqueue_phase_b(tetsim_body* h);                            // halo start
 int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
 int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains

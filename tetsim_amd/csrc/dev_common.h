@@ -119,11 +119,14 @@ void nh_launch_post_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
 void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
+// raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
+// in its queue is done" -- a signal kernel folded into its successor
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
-                    hipEvent_t e1 = nullptr);
+                    hipEvent_t e1 = nullptr, uint32_t* raise_word = nullptr);
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                       uint32_t* raise_word = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores
 // 1 behind the producer kernel, wait spins until it is non-zero in front of the consumer kernel and clears it.  No per-launch
@@ -167,6 +170,7 @@ void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map,
 void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, uint32_t n, double px, double py, double pz,
                          double* best_d2, uint32_t* best_id);
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n);
+void util_launch_delay(hipStream_t s, uint32_t us);   // loopback measurements: a stand-in for wire latency
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 
 

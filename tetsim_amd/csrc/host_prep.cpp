@@ -364,7 +364,8 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 }
 
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
-                  const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet, const uint32_t* body_first_vert, uint32_t bodies) {
+                  const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet, const uint32_t* body_first_vert, uint32_t bodies,
+                  uint32_t nv_boundary) {
     BlockPlan& B = *out;
     B = BlockPlan();
     constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
@@ -412,14 +413,17 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
                 }
                 if (touched.size() + fresh > kMaxVerts) break;
                 for (int k = 0; k < 4; k++)
-                    if (slot_of[t[k]] < 0) { slot_of[t[k]] = 0; touched.push_back(t[k]); ghost |= static_cast<uint32_t>(t[k]) >= nv_sum; }
+                    if (slot_of[t[k]] < 0) {
+                        slot_of[t[k]] = 0; touched.push_back(t[k]);
+                        ghost |= static_cast<uint32_t>(t[k]) >= nv_sum || static_cast<uint32_t>(t[k]) < nv_boundary;   // halo-side
+                    }
                 i++;
             }
             for (int32_t v : touched) slot_of[v] = -1;
             runs.push_back({t0, i, ghost});
         }
     }
-    // tiles that touch a ghost particle go last: a partitioned body solves the others while the halo is in flight
+    // tiles that touch a ghost or a boundary particle go last: a partitioned body solves the others while the halo is in flight
     std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.ghost < b.ghost; });
     {
         std::vector<int32_t> perm2(nt);

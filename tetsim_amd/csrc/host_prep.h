@@ -108,16 +108,20 @@ struct BlockPlan {
     bool every_owned_particle_has_a_partial = true;   // else some particle is summed by no tile: the fused pass cannot serve it
     uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
-    uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no particle >= nv_sum (no ghost)
+    uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no ghost (id >= nv_sum) and no boundary particle
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
 // it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).
 // Batches (tetsim_create_batch: several independent bodies behind one handle): body_first_tet / body_first_vert [bodies + 1]
 // give each body's tet and vertex range; tiles never span two bodies and every body is tiled exactly as it would be alone
 // (its own bounding box for the Morton codes), so that each body's results equal its solo run bit for bit.  NULL = one body.
+// nv_boundary: particles [0, nv_boundary) are the partition's BOUNDARY particles (the ones it sends to neighbours).  A tile is
+// "halo-side" -- ordered last, counted out of num_interior_blocks -- if it touches a ghost (id >= nv_sum) OR a boundary particle:
+// then every tile that contributes to a boundary particle is halo-side, and the halo queue can finish the boundary particles
+// and start the transfer without waiting for the interior tiles.
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet = nullptr,
-                  const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1);
+                  const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1, uint32_t nv_boundary = 0);
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 

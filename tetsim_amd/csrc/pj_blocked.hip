@@ -285,6 +285,22 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
+// ... raising a hand-over word as they START (partitioned bodies): a kernel starts only when everything in front
+// of it in its in-order queue is complete, so "the previous kernel of this queue is done" costs one store of one thread here
+// instead of a signal kernel of its own (~2.7 us of queue time each, and the two-queue substep had two of them)
+__device__ __forceinline__ void raise(uint32_t* sig) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                              uint32_t tiles_per_xcd, uint32_t* sig TETSIM_DBG_PARAM) {
+    raise(sig);
+    pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                                            uint32_t tiles_per_xcd, uint32_t* sig TETSIM_DBG_PARAM) {
+    raise(sig);
+    pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
@@ -296,12 +312,13 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(P
 }
 
 // ---- cross-queue hand-over of partitioned bodies ----------------------------------------------------------
-// A partitioned substep runs on two queues (ghost-touching tiles + transfer on the halo stream, everything else on the main
-// stream).  A dependency between the queues costs ~15 us as an event (eager) and ~6 us as a fork/join edge of a captured graph
-// on this stack (tools/micro/xq_latency.hip), and the cycle  particles(s) -> transfer(s) -> G tiles(s+1) -> particles(s+1)
-// has two of them.  Here the producer queue runs a ONE-WAVE signal kernel behind its kernel (in-order queue: the kernel and
-// its agent-scope release are complete) and the consumer queue a one-wave wait kernel in front of the dependent kernel (whose
-// own start then performs the agent-scope acquire): ~5 us each under load, nothing else in either queue is delayed.
+// A partitioned substep runs on two queues (halo-side tiles, boundary particles and the transfer on the halo stream, everything
+// else on the main stream; tetsim_halo.hip: enqueue_phase_a).  A dependency between the queues costs ~15 us as an event (eager) and ~6 us as a fork/join edge of a captured graph
+// on this stack (tools/micro/xq_latency.hip), and the cycle  particles(s) -> transfer(s) -> H tiles(s+1) -> particles(s+1)
+// has two of them.  Here the producer queue sets a word behind its kernel (in-order queue: the kernel and its agent-scope
+// release are complete) -- as the first store of the NEXT kernel of that queue (the *_raise kernels below), or from a one-wave
+// signal kernel where no kernel follows -- and the consumer queue runs a one-wave wait kernel in front of the dependent kernel
+// (whose own start then performs the agent-scope acquire): ~2.7 us of queue time per one-wave kernel, nothing else is delayed.
 // The word is a BINARY SEMAPHORE: signal stores 1, wait spins until it reads non-zero and stores 0 again.  That needs no
 // sequence number -- the dependency cycle itself makes producer and consumer alternate strictly (the next signal of a word is
 // behind the completion of the wait that consumed the previous one) -- so both kernels take CONSTANT arguments and the two
@@ -359,6 +376,10 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
+__global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t first, uint32_t count, uint32_t* sig) {
+    raise(sig);
+    pjb_vertex_body(d, first, count);
+}
 __global__ void pjb_wait_kernel(PJSync y) { await_done(y); }
 __global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -390,9 +411,15 @@ static uint32_t tet_mode() {
 #else
 #define TETSIM_DBG_LAUNCH
 #endif
-void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1) {
-    if (tile_count == 0) return;
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
+    if (tile_count == 0) return;   // (callers with a word to raise check this themselves)
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
+    if (raise_word) {
+        auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_raise : pjb_tet_kernel_raise;
+        if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, raise_word TETSIM_DBG_LAUNCH);
+        else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, raise_word TETSIM_DBG_LAUNCH);
+        return;
+    }
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
@@ -406,8 +433,13 @@ void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }
-void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
     if (count == 0) return;
+    if (raise_word) {
+        if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count, raise_word);
+        else hipLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, raise_word);
+        return;
+    }
     if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count);
     else hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count);
 }

@@ -83,10 +83,19 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     const int slot = h->ring_pos;
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
+    if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
+    if (h->comm_stream && h->d_params_halo) {
+        // the halo queue runs the boundary particles itself (enqueue_phase_a) and is ordered against the main queue only through
+        // the semaphore words: it gets its own copy of the parameters, in ITS stream order
+        if (!h->ring_ev_halo[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->ring_ev_halo[slot], hipEventDisableTiming));
+        HIPCHK(h, hipMemcpyAsync(h->d_params_halo, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->comm_stream));
+        HIPCHK(h, hipEventRecord(h->ring_ev_halo[slot], h->comm_stream));
+        h->ring_used_halo[slot] = true;
+    }
     h->fork_needed = true;  // whatever the caller did on the main stream since the last call must be visible to the boundary stream
     return 0;
 }
@@ -174,7 +183,6 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
 }
 
 // POLAR_JACOBI keeps x* = x + v*dt precomputed by the previous vertex kernel; redo it if dt changed.
-int enqueue_phase_b(tetsim_body* h);
 int ensure_prediction(tetsim_body* h, double dt) {
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return 0;
     const float fdt = static_cast<float>(dt);
@@ -182,6 +190,13 @@ int ensure_prediction(tetsim_body* h, double dt) {
         if (h->partitioned && !h->neigh.empty() && !has_transport(h))
             return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body without a transport (ghost predictions would be stale): "
                                           "exchange halos through tetsim_comm_init / tetsim_group_step_n, or keep dt fixed");
+        if (h->flag_sync && h->comm_stream) {
+            // the boundary particles of the last substep were finished by the HALO queue (enqueue_phase_a), and its last transfer
+            // still reads their predictions: the re-prediction on the main queue goes behind all of that (an eager cross-queue
+            // event, ~15 us -- only when dt changes)
+            HIPCHK(h, hipEventRecord(h->ev_bnd_tet, h->comm_stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_bnd_tet, 0));
+        }
         pj_repredict(h);
         // the neighbours' ghost copies of our interface predictions are stale now: one extra halo exchange (every rank sees the
         // same dt change, so every rank does this).  RCCL bodies do it here; an in-process group does it for all its members
@@ -435,6 +450,7 @@ void tetsim_destroy(tetsim_handle h) {
     if (h->pinned_pos) (void)hipHostFree(h->pinned_pos);
     if (h->pinned_quat) (void)hipHostFree(h->pinned_quat);
     for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+    for (int i = 0; i < kRing; i++) if (h->ring_ev_halo[i]) (void)hipEventDestroy(h->ring_ev_halo[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {h->ev_fork, h->ev_bnd_tet}) if (ev) (void)hipEventDestroy(ev);
@@ -456,7 +472,9 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
-    return enqueue_substep(h);
+    rc = enqueue_substep(h);
+    if (!rc) rc = flush_v(h);
+    return rc;
 }
 
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* params) {
@@ -488,6 +506,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         }
         if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {
             for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            if (!rc) rc = flush_v(h);
             h->halo_warm = true;
             return rc;
         }
@@ -507,6 +526,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
             (void)hipGetLastError();
             rc = 0;
             for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            if (!rc) rc = flush_v(h);
             return rc;
         }
         it = h->graphs.emplace(n, exec).first;
@@ -997,6 +1017,7 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             HIPCHK(h, hipEventRecord(ev[4 * i + 3], h->stream));
         }
     }
+    if (!rc) rc = flush_v(h);
     HIPCHK(h, hipEventRecord(last_ev, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));

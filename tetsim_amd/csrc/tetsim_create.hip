@@ -119,8 +119,15 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     if (h->blocked) {
         BlockPlan B;
         build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
-                     batch ? h->batch_first_vert.data() : nullptr, bodies);
+                     batch ? h->batch_first_vert.data() : nullptr, bodies, nvb);
         h->tet_perm = B.tet_perm;
+        // the two-queue halo path (tetsim_halo.hip) rests on this: an interior tile touches neither a ghost nor a boundary particle
+        for (uint32_t b = 0; b < B.num_interior_blocks; b++)
+            for (uint32_t e = B.blk_tet_off[b]; e < B.blk_tet_off[b + 1]; e++)
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t v = static_cast<uint32_t>(ltets[4ull * static_cast<uint32_t>(B.tet_perm[e]) + c]);
+                    if (v < nvb || v >= nvo) return fail(h, TETSIM_ESTATE, "internal error in the tile plan: an interior tile touches a boundary or a ghost particle");
+                }
         PJBlk& k = h->blk;
         h->interior_tets = B.blk_tet_off[B.num_interior_blocks];
         k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;

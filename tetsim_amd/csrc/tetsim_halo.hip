@@ -14,7 +14,8 @@ int create_halo_stream(tetsim_body* h) {
     HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_bnd_tet, hipEventDisableTiming));
-    return 0;
+    // the halo stream's own copy of the substep parameters (push_params fills it in THIS stream's order)
+    return dev_alloc(h, &h->d_params_halo, 1);
 }
 
 int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
@@ -34,7 +35,7 @@ int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
 //   our next boundary pass overwrites the very buffer our transfer reads
 int halo_start(tetsim_body* h) {
     const uint32_t p = h->halo_parity;
-    if (h->flag_sync) {  // the halo stream already waited for this substep's particle pass (wait V): stay in stream order
+    if (h->flag_sync) {  // the halo stream ran this substep's boundary particles itself: stay in stream order
         for (auto& nb : h->neigh)
             if (!nb.contiguous && nb.send_count) util_launch_gather4(h->comm_stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
     } else {
@@ -76,6 +77,10 @@ int halo_start(tetsim_body* h) {
             const float4* from = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
             { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
         }
+    }
+    if (h->loopback) {   // measurement only: how much wire latency the choreography hides (tools/loopback_rank.py)
+        static const uint32_t delay_us = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_DELAY_US"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 0u; }();
+        util_launch_delay(h->comm_stream, delay_us);
     }
     if (!(h->flag_sync && h->comm)) { HP("record sent"); HIPCHK(h, hipEventRecord(h->ev_sent2[p], h->comm_stream)); }  // (RCCL + flags: stream order is all there is)
     h->halo_pending = true;
@@ -121,12 +126,19 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
         static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();  // "events" = the older path
         if (nbnd && !one_stream && use_flags) {
-            // Two queues, synchronised through device counters instead of events (util_kernels.hip: a cross-stream event costs
-            // ~15 us eagerly and ~6 us as a graph edge here, and a substep has two on its critical path):
-            //   main stream:  interior tiles(s) -> wait G(s) -> particles(s) -> signal V(s)
-            //   halo stream:  ghost tiles G(s) -> signal G(s) -> wait V(s) -> transfer(s)              [transfer(s-1) precedes G(s)]
-            // signal / wait are one-wave kernels (pj_blocked.hip).  Host submission order follows the dependencies (G, signal G,
-            // interior, wait G, particles, signal V, wait V, transfer): every wait is submitted after its signal, so the path
+            // Two queues, synchronised through device words instead of events (a cross-stream event costs ~15 us eagerly and ~6 us
+            // as a graph edge here, and a substep has two hand-overs on its critical path):
+            //   main stream:  interior tiles(s) [raises V(s-1)] -> wait G(s) -> interior particles(s)
+            //   halo stream:  wait V(s-1) -> H tiles(s) -> boundary particles(s) [raises G(s)] -> transfer(s)     [enqueue_phase_b]
+            // H tiles = the tiles that touch a ghost OR a boundary particle (host_prep.cpp): every contribution to a boundary
+            // particle comes from an H tile, so the halo queue finishes the boundary particles itself and starts the transfer
+            // while the main queue is still in its tet kernel.  The H tiles wait for V: they also read interior particles.
+            // A wait is a one-wave kernel on a binary semaphore (pj_blocked.hip); a signal is ONE STORE at the start of the kernel
+            // that follows the producer in its queue (an in-order queue starts a kernel when its predecessor is complete):
+            // "H tiles done" is raised by the boundary-particle kernel, "interior particles done" by the next substep's interior tet
+            // kernel -- or by a signal kernel where no such kernel follows (end of a call: flush_v).  A kernel of its own costs
+            // ~2.7 us of queue time here, and the substep had a signal kernel on each of its two critical chains.
+            // Host submission order follows the dependencies, every wait behind the kernel that raises its word, so the eager path
             // stays live even if the runtime maps both streams onto one hardware queue (it then merely serialises).
             if (!h->d_sync) {
                 int rc = dev_alloc(h, &h->d_sync, kSyncWords);
@@ -135,19 +147,27 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 HIPCHK(h, hipDeviceSynchronize());   // once: the halo stream must also see everything create() uploaded
             }
             h->flag_sync = true;
-            PJSync yg, yv;   // word 0: "the G tiles of this substep are done"; word 2: "the particles of this substep are done"
+            PJSync yg, yv;   // word 0: "the H tiles of this substep are done"; word 2: "the interior particles of this substep are done"
             yg.flag = h->d_sync + 0; yg.error = h->d_sync + 4; yg.timeout_ms = halo_timeout_ms();
             yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = yg.timeout_ms;
-            int rc = halo_wait(h, h->comm_stream);   // in-process groups: the neighbours' transfers of the previous substep (events)
-            if (rc) return rc;
-            { HP("launch tet ghost"); pjb_launch_tet(h->comm_stream, h->blk, h->blk.nb_interior, nbnd); }
-            { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+            const uint32_t nvb = h->pj.nv_boundary;
+            int rc;
+            const bool v_open = h->v_pending;   // the previous substep's "interior particles done": raised here, consumed below
+            if (v_open && h->blk.nb_interior) h->v_pending = false;
+            else if ((rc = flush_v(h))) return rc;
+            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr,
+                                                       v_open && h->blk.nb_interior ? yv.flag : nullptr); }
+            if (v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            if ((rc = halo_wait(h, h->comm_stream))) return rc;   // in-process groups: the neighbours' transfers of the previous substep (events)
+            PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
+            if (h->d_params_halo) kb.params = h->d_params_halo;
+            { HP("launch tet halo-side"); pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
+            if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
             if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
-            { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr); }
+            if (nvb) { HP("launch vertex boundary"); pjb_launch_vertex(h->comm_stream, kb, 0, nvb, nullptr, nullptr, yg.flag); }
             { HP("wait G"); pjb_launch_wait(h->stream, yg); }
-            { HP("launch vertex"); pj_vertex(h, 0, h->pj.nv_owned, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
-            { HP("signal V"); pjb_launch_signal(h->stream, yv); }
-            { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            { HP("launch vertex interior"); pj_vertex(h, nvb, h->pj.nv_owned - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+            h->v_pending = true;
             return 0;
         }
         if (nbnd && !one_stream) {
@@ -186,6 +206,16 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
     if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->stream)); }  // group transport only
     return 0;
 }
+int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of its own: signal on the main queue, wait on the halo queue
+    if (!h->v_pending) return 0;
+    if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
+    PJSync yv;
+    yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms();
+    { HP("signal V"); pjb_launch_signal(h->stream, yv); }
+    { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+    h->v_pending = false;
+    return 0;
+}
 int enqueue_phase_b(tetsim_body* h) {  // halo start
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = halo_start(h);
@@ -221,7 +251,8 @@ int probe_queue_independence(tetsim_body* h) {
 }
 
 // n substeps of an RCCL body on the flag path as TWO captured linear chains, one per stream, replayed side by side:
-//   main:  [interior tiles -> wait G -> particles -> signal V] x n          halo:  [G tiles -> signal G -> wait V -> transfer] x n
+//   main:  [interior tiles (raise V) -> wait G -> interior particles] x n -> signal V
+//   halo:  [H tiles -> boundary particles (raise G) -> transfer -> wait V] x n          (enqueue_phase_a)
 // No fork/join edge exists between them (those cost ~6 us each inside a graph on this stack): the chains meet only through the
 // binary-semaphore words, whose kernels take constant arguments.  Inside a chain a kernel boundary costs 1.6 us instead of the
 // 2.7 us of an eager launch, and the host enqueues two graph launches per call instead of 9 operations per substep.
@@ -238,6 +269,8 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
             rc = enqueue_phase_a(h);
             if (!rc) rc = enqueue_phase_b(h);
         }
+        if (!rc) rc = flush_v(h);
+        h->v_pending = false;
         const hipError_t e1 = hipStreamEndCapture(h->stream, &gm), e2 = hipStreamEndCapture(h->comm_stream, &gh);
         if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(h, TETSIM_EHIP, std::string("end capture: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         if (!rc && hipGraphInstantiate(&em, gm, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "graph instantiate (main chain) failed");
@@ -514,6 +547,7 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
         for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
         if (dbg_sync) (void)hipDeviceSynchronize();
     }
+    for (uint32_t i = 0; i < count; i++) { int rc = flush_v(hs[i]); if (rc) return rc; }
     return 0;
 }
 

@@ -56,8 +56,17 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float4* __restrict__
     if (threadIdx.x == 0) { best_d2[blockIdx.x] = s_d[0]; best_id[blockIdx.x] = s_i[0]; }
 }
 
+// measurement aid of the loopback halo (TETSIM_DEBUG_LOOPBACK_DELAY_US): one wave that idles for `ticks` of the 100 MHz clock
+__global__ void delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 }  // namespace
 
+void util_launch_delay(hipStream_t s, uint32_t us) {
+    if (us) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, 100ll * us);
+}
 void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map, float* out, uint32_t n) {
     if (n == 0) return;
     hipLaunchKernelGGL(pack_xyz_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, map, out, n);

@@ -24,13 +24,18 @@ owner[(np.arange(len(v)) // plane) >= 2 * cells] = 2
 mid = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=3, part_index=1, vert_owner=owner, ref_fixed_bounds=False)
 comm_init(mid, comm_unique_id(), 0, 1)
 print("middle slab: %d owned particles, %d local tets (%d owned), %d neighbours" % (mid.info.owned_particles, mid.info.local_elems, mid.info.owned_elems, mid.info.num_neighbours))
+pr = mid.profile(2, DT, PP)
+print("interior tet kernel: %d of %d local tets (the rest, %.1f%%, are in halo-side tiles: they touch a ghost or a boundary particle)" % (
+    pr["tets_per_tet_launch"], mid.info.local_elems, 100.0 * (1 - pr["tets_per_tet_launch"] / mid.info.local_elems)), flush=True)
+CALLS, REPS = int(os.environ.get("LOOPBACK_CALLS", 50)), int(os.environ.get("LOOPBACK_REPS", 3))   # (small values: for a kernel trace)
 for name, body in (("monolithic", mono), ("middle rank, RCCL loopback halo", mid)):
+    if name == "monolithic" and os.environ.get("LOOPBACK_SKIP_MONO"): continue
     for _ in range(10): body.simulateSubsteps(20, DT, PP)
     body.sync()
-    for rep in range(3):
+    for rep in range(REPS):
         t0 = time.perf_counter()
-        for _ in range(50): body.simulateSubsteps(20, DT, PP)
+        for _ in range(CALLS): body.simulateSubsteps(20, DT, PP)
         th = time.perf_counter() - t0
         body.sync(); tt = time.perf_counter() - t0
-        print("%-34s host enqueue %.1f us, wall %.1f us per substep" % (name, th / 1000 * 1e6, tt / 1000 * 1e6), flush=True)
+        print("%-34s host enqueue %.1f us, wall %.1f us per substep" % (name, th / (20 * CALLS) * 1e6, tt / (20 * CALLS) * 1e6), flush=True)
     assert np.isfinite(body.pos).all()
