@@ -167,9 +167,6 @@ struct tetsim_body {
     // NEOHOOKEAN_GS
     NHDev nh;
     std::vector<NHClusterLaunch> cluster_launch;  // TETSIM_ORDER_CLUSTERED: one per cluster colour
-    NHChain chain;                                // ... or the whole sweep as one launch (chain.nblocks != 0)
-    NHClusterLaunch* d_chain_launches = nullptr;
-    uint32_t* d_chain_words = nullptr;            // [epoch | flags (nblocks)]
     int32_t* d_slot_vid = nullptr;
     std::vector<uint32_t> level_off;
     std::vector<int32_t> order;
@@ -232,7 +229,7 @@ struct HostProfScope {
 void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_repredict(tetsim_body* h);
-void nh_sweep(tetsim_body* h, bool allow_chain = true);
+void nh_sweep(tetsim_body* h);
 // first / last: position inside a run of substeps enqueued back to back with one dt
 int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
 int ensure_prediction(tetsim_body* h, double dt);

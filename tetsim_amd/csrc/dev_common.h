@@ -95,8 +95,6 @@ struct NHDev {
     int32_t* order = nullptr;  // [nt] solve position -> caller's tet id
     uint32_t* corner_slots = nullptr;  // [nt] TETSIM_ORDER_CLUSTERED: the corners' cluster-local vertex slots, a byte each
     const DevParams* params = nullptr;
-    uint32_t* sweep_epoch = nullptr;   // chained sweep (NHChain): the number the current sweep's workgroups publish; the per-particle
-                                       // pass that follows every sweep adds 1
 };
 // One launch of the clustered Gauss-Seidel schedule (host_prep.h ClusterPlan): lane = cluster, step j = tets first[j] + lane
 // for lanes < count[j] (count non-increasing), slot_vid = [kNHClusterVerts][clusters] vertex ids (-1 = unused).
@@ -105,17 +103,6 @@ struct NHClusterLaunch {
     uint32_t nsteps = 0, clusters = 0;
     uint32_t first[kNHClusterTets] = {}, count[kNHClusterTets] = {};
     const int32_t* slot_vid = nullptr;
-};
-
-// The whole clustered sweep as ONE persistent launch (nh_kernels.inc: nh_cluster_chain_kernel): `nblocks` co-resident one-wave
-// workgroups, each walking the colours in order -- its 64 clusters of colour c, then a grid barrier.  The barrier is one word per
-// workgroup, monotone: flags[b] = 32 * *epoch + (colours finished); nobody reads a particle of colour c before every word says c.
-struct NHChain {
-    const NHClusterLaunch* launches = nullptr;   // [ncolours], device
-    uint32_t ncolours = 0, nblocks = 0;          // nblocks = the largest colour's workgroup count
-    uint32_t* flags = nullptr;                   // [nblocks]
-    const uint32_t* epoch = nullptr;
-    unsigned long long* trace = nullptr;         // TETSIM_NH_CHAIN_TRACE=1: [ncolours][4] s_memtime stamps of workgroup 0 (tools/nh_chain_trace.py)
 };
 
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
@@ -132,8 +119,6 @@ void nh_launch_post_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
 void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
-void nh_launch_cluster_chain_precise(hipStream_t s, const NHDev& d, const NHChain& c);
-void nh_launch_cluster_chain_fast(hipStream_t s, const NHDev& d, const NHChain& c);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
 // in its queue is done" -- a signal kernel folded into its successor
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,

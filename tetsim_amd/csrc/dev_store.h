@@ -23,13 +23,4 @@ __device__ __forceinline__ void store_wt(float4* base, uint32_t index, const flo
     __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, static_cast<int>(index * 16u), 0, 0x11);  // aux: sc0 | sc1
 }
 
-// The matching load: served from the memory side (sc0 sc1), never from a line this XCD's L2 cached before another XCD's
-// write-through store replaced it -- what a reader needs when no kernel boundary (with its cache invalidation) lies between the
-// store and the load (nh_kernels.inc: the persistent sweep).  Same constraints as store_wt.
-__device__ __forceinline__ float4 load_coherent(const float4* base, uint32_t index) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, 0x7fffffff, 0x00020000);
-    const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(index * 16u), 0, 0x11);
-    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
-}
-
 }  // namespace tetsim

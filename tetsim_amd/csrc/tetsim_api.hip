@@ -145,11 +145,7 @@ void pj_repredict(tetsim_body* h) {
 // The halo stream carries the transfers AND the boundary tiles that consume them; high priority so that its few
 // workgroups are dispatched ahead of the interior kernel's backlog.
 // NEOHOOKEAN_GS: the Gauss-Seidel sweep over all tets (A3-A5), as dependency levels or as cluster colours
-void nh_sweep(tetsim_body* h, bool allow_chain) {
-    if (h->chain.nblocks && allow_chain) {   // (the chained launch relies on the per-particle pass behind every sweep: it advances the epoch)
-        h->fast ? nh_launch_cluster_chain_fast(h->stream, h->nh, h->chain) : nh_launch_cluster_chain_precise(h->stream, h->nh, h->chain);
-        return;
-    }
+void nh_sweep(tetsim_body* h) {
     if (!h->cluster_launch.empty()) {
         for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L) : nh_launch_cluster_precise(h->stream, h->nh, L);
         return;
@@ -442,13 +438,6 @@ void tetsim_destroy(tetsim_handle h) {
         std::vector<unsigned long long> tr(8ull * h->blk.nb);
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
-    }
-    if (h->chain.trace) {   // TETSIM_NH_CHAIN_TRACE=1: the persistent sweep's stamps of its last run, to stderr (cycles since the sweep began)
-        std::vector<unsigned long long> tr(4ull * h->chain.ncolours);
-        if (hipMemcpy(tr.data(), h->chain.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
-            for (uint32_t c = 0; c < h->chain.ncolours; c++)
-                fprintf(stderr, "[tetsim] chain colour %2u: entered %8llu  barrier passed %8llu  solved %8llu  written back %8llu\n", c,
-                        tr[4 * c] - tr[0], tr[4 * c + 1] - tr[0], tr[4 * c + 2] - tr[0], tr[4 * c + 3] - tr[0]);
     }
     // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -1071,7 +1060,7 @@ int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimP
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     auto tet_once = [&]() {
         if (pjs) { pj_tet(h); return 1u; }
-        nh_sweep(h, false);   // back-to-back sweeps: one launch per colour
+        nh_sweep(h);
         return static_cast<uint32_t>(h->level_off.size() - 1);
     };
     auto vert_once = [&]() {

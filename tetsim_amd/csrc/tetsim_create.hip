@@ -412,30 +412,6 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             L.slot_vid = h->d_slot_vid + plan.vid_off[l];
             h->cluster_launch.push_back(L);
         }
-        // the sweep as ONE persistent launch (nh_cluster_chain_kernel) when its workgroups -- as many as the largest colour has
-        // waves -- are certainly resident together (one wave + 8 KB of LDS each: 2,048 is 8 per CU); TETSIM_NH_CHAIN=0: one
-        // launch per colour (A/B)
-        static const bool use_chain = [] { const char* e = getenv("TETSIM_NH_CHAIN"); return !(e && e[0] == '0'); }();
-        uint32_t nblocks = 0;
-        for (const NHClusterLaunch& L : h->cluster_launch) nblocks = std::max(nblocks, (L.clusters + 63u) / 64u);
-        if (use_chain && nl > 1 && nl < 32 && nblocks <= 2048u) {
-            std::vector<uint32_t> words(1u + nblocks, 0u);
-            words[0] = 1u;   // epoch (flags start at 0 = "before the first sweep")
-            if ((rc = dev_alloc(h, &h->d_chain_words, words.size()))) return rc;
-            if ((rc = upload(h, h->d_chain_words, words))) return rc;
-            if ((rc = dev_alloc(h, &h->d_chain_launches, nl))) return rc;
-            if ((rc = upload(h, h->d_chain_launches, h->cluster_launch))) return rc;
-            h->chain.launches = h->d_chain_launches;
-            h->chain.epoch = h->d_chain_words;
-            h->chain.flags = h->d_chain_words + 1u;
-            h->chain.ncolours = nl;
-            h->chain.nblocks = nblocks;
-            d.sweep_epoch = h->d_chain_words;
-            if (const char* e = getenv("TETSIM_NH_CHAIN_TRACE"); e && e[0] == '1') {
-                if ((rc = dev_alloc(h, &h->chain.trace, 4ull * nl))) return rc;
-                HIPCHK(h, hipMemset(h->chain.trace, 0, 4ull * nl * sizeof(unsigned long long)));
-            }
-        }
     }
     return 0;
 }
