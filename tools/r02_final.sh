@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # Round-2 evidence batch (run ON the GPU box):  bash tools/r02_final.sh <tag>
 # 1. tolerance calibration of the whole GPU suite (TETSIM_RECORD_ERRORS) -> tolerances.json, 2. the suite again WITH the table,
-# 3. mutation check against the table, 4. PMC passes (polar + NH) -> pmc_traffic.json, 5. bench lines, 6. rocprofv3 kernel stats of the same command.
+# 3. mutation check against the table, 4. PMC passes (polar + NH) -> pmc_traffic.json, 5. bench lines, 6. rocprofv3 kernel stats of the same command,
+# 7. the loopback rank.
 set -u
 TAG=${1:-r02c}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -25,5 +26,7 @@ timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/b
 timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/stats.log" 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
+# 7. one interior rank with the real RCCL kernels in loopback (the stand-in for a multi-GPU rank)
+( timeout 300 python tools/loopback_rank.py 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" > "$OUT/loopback.txt" )
 find "$OUT" -name "*kernel_stats.csv" | head
 tail -3 "$OUT/pytest_calibration.log"; tail -6 "$OUT/pytest_with_table.log"; tail -12 "$OUT/mutation.txt"; head -c 600 "$OUT/bench.json"
