@@ -151,7 +151,9 @@ typedef struct TetSimProfile {
     uint32_t launches[TETSIM_K_COUNT];
     uint32_t substeps;
     uint32_t tets_per_tet_launch;    /* tets one timed TETSIM_K_TET launch processes: all of them, or on a partitioned body with a
-                                        halo transport the INTERIOR tiles' (the boundary tiles run beside them on the halo stream) */
+                                        halo transport the INTERIOR tiles' (the halo-side tiles -- those touching a ghost or a boundary particle --
+                                        run beside them on the halo stream, as do the boundary particles: TETSIM_K_VERTEX then times the
+                                        interior particles' kernel) */
 } TetSimProfile;
 
 /* --- lifecycle ------------------------------------------------------------------------------- */

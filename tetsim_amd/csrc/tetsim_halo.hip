@@ -105,7 +105,7 @@ uint32_t halo_timeout_ms() {
     return ms;
 }
 bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
-// blocked bodies with a transport and ghost-touching tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
+// blocked bodies with a transport and halo-side tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
 bool uses_flag_sync(const tetsim_body* h) {
     static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();
     static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
