@@ -1,6 +1,7 @@
 """CPU-side checks of the C-ABI library: it loads, exports every symbol include/tetsim.h declares, refuses to
 compute without a GPU (no fallback), and its host preprocessing matches the reference-pinned data."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -33,6 +34,22 @@ def test_library_info_matches_the_tree():
     assert info["abi"] == 3 and info["ablation"] is False
     assert (info["source_sha"], info["kernel_sha"]) == source_shas(), "libtetsim_hip.so is stale: run python -m tetsim_amd.build"
     assert re.fullmatch(r"[0-9a-f]{16}", info["source_sha"]) and re.fullmatch(r"[0-9a-f]{16}", info["kernel_sha"])
+
+
+def test_library_info_names_the_environment_knobs_it_sees():
+    """debug_env is a bit mask on the C side and a list of names in Python: the two tables must stay in step."""
+    import subprocess
+    import sys
+    code = "import json; from tetsim_amd import _capi; print(json.dumps(_capi.library_info()['debug_env']))"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = {k: v for k, v in os.environ.items() if k not in capi.DEBUG_ENV_NAMES}
+    assert json.loads(subprocess.run([sys.executable, "-c", code], cwd=root, env=clean, capture_output=True, text=True, check=True).stdout) == []
+    for name in capi.DEBUG_ENV_NAMES:
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(clean, **{name: "1"}), capture_output=True, text=True, check=True).stdout
+        assert json.loads(out) == [name], (name, out)
+    blob = open(capi.LIB_PATH, "rb").read()
+    for name in capi.DEBUG_ENV_NAMES:
+        assert name.encode() in blob, name
 
 
 def test_product_kernel_has_no_ablation_knobs():
