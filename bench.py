@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: M tet-solves/s on the 1 M-tet Kuhn lattice, polar-decomposition Jacobi,
 20 substeps per frame, on N MI355X (BASELINE.json metric; SURVEY.md §8(d) config 3, config 5 shape for N>1).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: spawns its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -50,46 +50,54 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 
 
 def cpu_baseline(verts, tets):
-    """Time the CPU restatement of the SAME algorithm (oracle section G) on this host, bounded to ~20 s.
-
-    One thread first (like-for-like with the reference's single JS thread), then OpenMP over tets/particles
-    with as many threads as this process may run on (capped at 64: beyond one socket the port stops scaling)."""
+    """Time the CPU restatement of the SAME algorithm (oracle section G) on this host by BASELINE.md 4.2's protocol: same
+    lattice, parameters and dt as the GPU run; 3 repetitions and their MEDIAN at 1 thread (like-for-like with the reference's
+    single JS thread), 16, 64 and all the threads this process may run on (OpenMP over tets / particles).  Every thread count is
+    reported (`by_threads`), `value` / `cores` name the fastest median.  Bounded to ~25 s of CPU work."""
     from oracle import OraclePJ, set_threads
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
     o = OraclePJ(verts, tets, PP, slot_quirk=True)
+    REPS = 3
 
     def rate(threads, budget_s):
+        """REPS repetitions of n substeps each (n from a one-substep probe so that a repetition lasts ~budget_s / REPS)."""
         set_threads(threads)
         o.simulate(DT, PP)  # warm (page faults, thread pool)
         t0 = time.perf_counter()
         o.simulate(DT, PP)
         t1 = time.perf_counter() - t0
-        n = int(max(1, min(SUBSTEPS, round(budget_s / max(t1, 1e-3)))))
-        t0 = time.perf_counter()
-        for _ in range(n):
-            o.simulate(DT, PP)
-        return len(tets) * n / (time.perf_counter() - t0) / 1e6, n
+        n = int(max(1, min(SUBSTEPS, budget_s / REPS / max(t1, 1e-3))))
+        rates = []
+        for _ in range(REPS):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o.simulate(DT, PP)
+            rates.append(len(tets) * n / (time.perf_counter() - t0) / 1e6)
+        rates.sort()
+        return {"median": round(rates[REPS // 2], 3), "min": round(rates[0], 3), "max": round(rates[-1], 3), "reps": REPS, "substeps_per_rep": n}
 
-    r1, n1 = rate(1, 4.0)
-    best, cores, nb = r1, 1, n1
-    for th in sorted({min(avail, 16), min(avail, 64)}):
-        if th > 1:
-            r, n = rate(th, 5.0)
-            if r > best:
-                best, cores, nb = r, th, n
+    by_threads = {}
+    for th, budget in ((1, 4.0), (16, 2.5), (64, 2.5), (avail, 3.0)):
+        th = min(th, avail)
+        if str(th) not in by_threads:
+            by_threads[str(th)] = rate(th, budget)
     set_threads(1)
+    cores = max(by_threads, key=lambda k: by_threads[k]["median"])
     # the reference's own CPU solver is the sequential Neo-Hookean Gauss-Seidel of Softbody.js (BASELINE config 1); its
     # restatement (oracle section A, bit-exact with Softbody.js) on ONE core of this host, same lattice, for orientation
     from oracle import OracleNH
     nh = OracleNH(verts, tets, PP)
     nh.simulate(DT, PP)
-    t0 = time.perf_counter()
-    nh.simulate(DT, PP)
-    nh.simulate(DT, PP)
-    nh_rate = 2 * len(tets) / (time.perf_counter() - t0) / 1e6
+    nh_rates = []
+    for _ in range(REPS):
+        t0 = time.perf_counter()
+        nh.simulate(DT, PP)
+        nh.simulate(DT, PP)
+        nh_rates.append(2 * len(tets) / (time.perf_counter() - t0) / 1e6)
+    nh_rates.sort()
     # ... and the same algorithm in JavaScript under node (oracle/nh_port.js, bit-exact with Softbody.js on the golden
     # vectors): the reference's design point -- one JS thread -- on this host
     js = None
@@ -103,20 +111,25 @@ def cpu_baseline(verts, tets):
                 np.ascontiguousarray(verts, dtype="<f4").tofile(os.path.join(tmp, "v.f32"))
                 np.ascontiguousarray(tets, dtype="<i4").tofile(os.path.join(tmp, "t.i32"))
                 r = subprocess.run([node, os.path.join(ROOT, "oracle", "nh_port.js"), "--verts", os.path.join(tmp, "v.f32"), "--tets",
-                                    os.path.join(tmp, "t.i32"), "--substeps", "3", "--warmup", "1", "--per-frame", str(SUBSTEPS)],
+                                    os.path.join(tmp, "t.i32"), "--substeps", "3", "--reps", str(REPS), "--warmup", "1", "--per-frame", str(SUBSTEPS)],
                                    capture_output=True, text=True, timeout=300)
             jr = json.loads(r.stdout)
             js = {"value": round(jr["m_tet_solves_per_s"], 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
-                  "sample": "3 substeps of the same lattice after 1 warm-up, oracle/nh_port.js under node " + jr["node"]}
+                  "min": round(min(jr["rates"]), 3), "max": round(max(jr["rates"]), 3), "reps": jr["reps"],
+                  "sample": "median of %d repetitions of 3 substeps of the same lattice after 1 warm-up, oracle/nh_port.js under node %s" % (jr["reps"], jr["node"])}
         except Exception as e:  # the JS leg is optional: node may be absent or too old
             js = {"error": str(e)[:200]}
-    res = {"value": round(best, 3), "unit": "M tet-solves/s", "cores": cores, "kind": "port",
+    best = by_threads[cores]
+    res = {"value": best["median"], "unit": "M tet-solves/s", "cores": int(cores), "kind": "port",
+           "by_threads": by_threads,
            "softbody_js_algorithm_node_1thread": js,
-           "softbody_js_algorithm_1core": {"value": round(nh_rate, 3), "unit": "M tet-solves/s", "cores": 1, "kind": "port",
-                                           "sample": "2 substeps of the same lattice, sequential Neo-Hookean Gauss-Seidel (oracle section A)"},
-           "sample": "%d substeps of the same %d-tet lattice (oracle/tetsim_oracle.c section G, gcc -O2 + OpenMP over "
-                     "tets/particles); best of 1/16/64 threads" % (nb, len(tets)),
-           "value_1core": round(r1, 3), "host_cpus_available": avail}
+           "softbody_js_algorithm_1core": {"value": round(nh_rates[REPS // 2], 3), "min": round(nh_rates[0], 3), "max": round(nh_rates[-1], 3), "reps": REPS,
+                                           "unit": "M tet-solves/s", "cores": 1, "kind": "port",
+                                           "sample": "median of %d repetitions of 2 substeps of the same lattice, sequential Neo-Hookean Gauss-Seidel (oracle section A)" % REPS},
+           "sample": "median of %d repetitions of %d substeps of the same %d-tet lattice, same parameters and dt as the GPU run (oracle/tetsim_oracle.c "
+                     "section G, gcc -O2 + OpenMP over tets/particles); every thread count of 1/16/64/all is in by_threads, value = the fastest median"
+                     % (REPS, best["substeps_per_rep"], len(tets)),
+           "value_1core": by_threads["1"]["median"], "host_cpus_available": avail}
     try:
         with open("/proc/cpuinfo") as f:
             res["cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
@@ -222,6 +235,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:    # RCCL's banner is printf'ed: with stdout a pipe it sits in C's buffer and would come out at exit, behind the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
 
@@ -230,12 +248,15 @@ class TorchRanks:
     """One process per GPU (the driver's launch): torch.distributed over RCCL for rendezvous, barrier and the max over ranks.
     The halo traffic itself does not go through torch: libtetsim_hip owns its RCCL communicator."""
 
-    def __init__(self, local_rank):
+    def __init__(self, local_rank, rank=0, world=1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")     # --force-dist without a launcher: a one-rank rendezvous with itself
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def broadcast_bytes(self, data, n):           # rank 0's `data` (n bytes) to everyone
         t = self.torch.zeros(n, dtype=self.torch.uint8, device="cuda")
@@ -293,6 +314,85 @@ class ThreadRanks:
         pass
 
 
+def visible_devices():
+    """HIP devices this process can see (torch is the plumbing the ranks use anyway; no context is created by the count)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, worker=None, devices=None, limit_s=None, out=None, err=None):
+    """`python bench.py --gpus N` without a launcher: be the launcher.  Starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, one device each through LOCAL_RANK, a free rendezvous port on 127.0.0.1), forwards rank 0's
+    stdout -- the ONE JSON line -- to this process's stdout and every other rank's stdout to stderr, and returns the exit code:
+    0 if every rank exited 0, otherwise the first non-zero code seen (the surviving ranks are terminated by PID, never by pattern).
+    A rank that dies takes the launch down at once instead of leaving its peers in a collective until the watchdog fires.
+
+    worker / devices / limit_s / out / err are for the CPU test of this logic (a stub worker, a pretended device count)."""
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    err = err or sys.stderr
+    have = visible_devices() if devices is None else devices
+    if have < n:
+        err.write("bench.py: %d devices requested, %d visible\n" % (n, have))
+        return 2
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    limit_s = limit_s if limit_s is not None else float(os.environ.get("TETSIM_BENCH_WATCHDOG_S", "600")) + 30.0
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs, pumps = [], []
+
+    def pump(src, dst, lock=threading.Lock()):
+        for line in iter(src.readline, ""):
+            with lock:
+                dst.write(line)
+                dst.flush()
+
+    for r in range(n):
+        p = subprocess.Popen(worker + list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=None,
+                             text=True, bufsize=1)
+        procs.append(p)
+        th = threading.Thread(target=pump, args=(p.stdout, out if r == 0 else err), daemon=True)
+        th.start()
+        pumps.append(th)
+    deadline = time.monotonic() + limit_s
+    code, live = 0, set(range(n))
+    while live and code == 0:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 128 - rc
+                    err.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, rc))
+        if time.monotonic() > deadline and live:
+            err.write("bench.py: ranks %s still running after %.0f s; stopping them\n" % (sorted(live), limit_s))
+            code = 124
+        if live and code == 0:
+            time.sleep(0.05)
+    for r in live:                      # only on failure: the ranks that are still up
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    for th in pumps:
+        th.join(timeout=5)
+    return code
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,8 +417,12 @@ def parse_args():
                     help="N > 1: append BASELINE config 5 literally (the --config5-cells^3 lattice cut into N slabs, strong scaling) as "
                          "`config5_strong` of the same JSON line; auto = when N == 8")
     ap.add_argument("--config5-cells", type=int, default=110, help="cells per side of the config-5 body (110 = 7,986,000 tets)")
+    ap.add_argument("--no-beyond-mall", action="store_true", help="N = 1: skip `roofline.beyond_mall` (the 8 M-tet body on this GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
+    ap.add_argument("--self-spawn", action="store_true",
+                    help="launch the rank processes from this process even when --gpus is 1 (what a plain `python bench.py --gpus N`, "
+                         "N > 1, does by itself when no launcher set WORLD_SIZE)")
     ap.add_argument("--fake-ranks", type=int, default=0,
                     help="development: run N ranks as threads on ONE GPU against the RCCL test double (needs TETSIM_RCCL_LIB=tests/mock_rccl/...)")
     return ap.parse_args()
@@ -360,15 +464,21 @@ def main():
         faulthandler.cancel_dump_traceback_later()
         return
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_spawn):
+        # a plain `python bench.py --gpus N` (the driver's N = 1 command with N changed): no launcher gave this process a rank, so
+        # it becomes the launcher -- one rank process per GPU, rank 0's JSON line forwarded (the torchrun launch keeps working:
+        # there WORLD_SIZE is set and this branch is not taken)
+        faulthandler.cancel_dump_traceback_later()
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.self_spawn:
+        args.force_dist = True      # a spawned rank always takes the torch.distributed path, also when it is the only one
     with stdout_to_stderr():
-        ranks = TorchRanks(local_rank) if (world > 1 or args.force_dist) else None
+        ranks = TorchRanks(local_rank, rank, world) if (world > 1 or args.force_dist) else None
         out, body = run(args, rank, world, local_rank, ranks)
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -430,6 +540,44 @@ def run_neohookean(args, verts, tets, device):
                                "kind": "port", "sample": "%d substeps of the same lattice, sequential Gauss-Seidel in the caller's tet order "
                                                          "(oracle/tetsim_oracle.c section A: Softbody.js's algorithm, bit-exact with its goldens)" % n}
     return out, body
+
+
+def beyond_mall(args, device, copy_peak, cells=110, frames=10):
+    """SURVEY.md 8(d) asks for a figure at a size beyond the 256 MB Infinity Cache as well: the 110^3-cell lattice (7,986,000 tets,
+    ~1.3 GB of per-tet state) on this one GPU, same kernels, `frames` frames after 2 warm-up frames, then the dominant kernel's own
+    events over 20 substeps.  Outside the timed region of the headline; ~3 s incl. building the body."""
+    from tetsim_amd import SoftBodyHIP, make_lattice
+    t_build = time.perf_counter()
+    v, t = make_lattice(cells)
+    kw = {"constant_rest_shape": True} if args.constant_rest_shape else {}
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", device=device, **kw)
+    t_build = time.perf_counter() - t_build
+    for _ in range(2):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    el = time.perf_counter() - t0
+    finite = bool(np.isfinite(body.pos).all())
+    pr = body.profile(SUBSTEPS, DT, PP)
+    body.close()
+    value = len(t) * SUBSTEPS * frames / el / 1e6
+    tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)
+    b_alg = tet_bytes + VERTEX_BYTES * len(v) / len(t)
+    tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
+    ach = tet_bytes * pr["tets_per_tet_launch"] / (tet_us * 1e-6) / 1e9
+    res = {"workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles), same solver and kernels, %d frames of %d substeps" % (cells, len(t), len(v), frames, SUBSTEPS),
+           "value": round(value, 1), "unit": "M tet-solves/s", "ms_per_step": round(el / frames * 1e3, 4), "finite": finite,
+           "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(pr["vertex_ms"] / pr["vertex_launches"] * 1e3, 2),
+           "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+           "substep_achieved": round(b_alg * value * 1e6 / 1e9, 1), "substep_frac": round(b_alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
+           "build_s": round(t_build, 2)}
+    if copy_peak.get("1GiB"):
+        res["frac_of_1GiB_copy"] = round(ach / copy_peak["1GiB"], 4)
+        res["substep_frac_of_1GiB_copy"] = round(b_alg * value * 1e6 / 1e9 / copy_peak["1GiB"], 4)
+    return res
 
 
 def slab_owner(nverts, cells, nz, world):
@@ -607,8 +755,14 @@ def run(args, rank, world, local_rank, ranks):
                            "substep_achieved": round(b_alg * out["value"] * 1e6 / 1e9, 1),
                            "substep_frac": round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
         if world == 1:
-            out["roofline"]["measured_copy_peak"] = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0),
-                                                     "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
+            # SURVEY.md 8(d) "bounding roofline": the peak is also MEASURED on this box -- a device copy at the footprint class of
+            # the 1 M-tet working set (fits the 256 MB Infinity Cache) and at 1 GiB (streams from HBM)
+            cp = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0), "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
+            out["roofline"]["measured_copy_peak"] = cp
+            out["roofline"]["frac_of_measured_peak"] = {"kernel_vs_64MiB_copy": round(achieved / cp["64MiB"], 4),
+                                                        "kernel_vs_1GiB_copy": round(achieved / cp["1GiB"], 4),
+                                                        "substep_vs_64MiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["64MiB"], 4),
+                                                        "substep_vs_1GiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["1GiB"], 4)}
     if rank == 0 and pr is None:
         # N > 1 without --profile-ranks: the whole-job figure only (no extra GPU work after the timed region)
         agg = b_alg * out["value"] * 1e6 / 1e9
@@ -640,6 +794,8 @@ def run(args, rank, world, local_rank, ranks):
                     "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
     if world == 1:
         body.close()
+        if not args.no_beyond_mall and args.precision == "fast" and cells == CELLS and args.solver == "polar" and "roofline" in out:
+            out["roofline"]["beyond_mall"] = beyond_mall(args, local_rank, out["roofline"].get("measured_copy_peak", {}))
         if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
             out["other_configs"] = other_configs()
         if not args.no_cpu_baseline:

@@ -134,13 +134,14 @@ function simulate(s, dt, pp) {
 function sha16(a) { return crypto.createHash('sha256').update(Buffer.from(a.buffer, a.byteOffset, a.byteLength)).digest('hex').slice(0, 16); }
 
 function main(argv) {
-    const opt = { perFrame: 10, warmup: 0, substeps: 1 };
+    const opt = { perFrame: 10, warmup: 0, substeps: 1, reps: 1 };
     for (let i = 0; i < argv.length; i++) {
         if (argv[i] === '--verts') opt.verts = argv[++i];
         else if (argv[i] === '--tets') opt.tets = argv[++i];
         else if (argv[i] === '--substeps') opt.substeps = parseInt(argv[++i], 10);
         else if (argv[i] === '--per-frame') opt.perFrame = parseInt(argv[++i], 10);
         else if (argv[i] === '--warmup') opt.warmup = parseInt(argv[++i], 10);
+        else if (argv[i] === '--reps') opt.reps = parseInt(argv[++i], 10);   // timed repetitions of `substeps` substeps each; the median is reported
         else if (argv[i] === '--params') opt.params = JSON.parse(argv[++i]);   // physicsParams keys (main.js:22-36) + timeScale/timeStep
     }
     const rd = (f, T) => { const b = fs.readFileSync(f); return new T(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)); };
@@ -150,11 +151,18 @@ function main(argv) {
     const dt = (pp.timeScale * pp.timeStep) / opt.perFrame;   // main.js:79
     const s = createBody(verts, tets, pp.density);
     for (let i = 0; i < opt.warmup; i++) simulate(s, dt, pp);
-    const t0 = process.hrtime.bigint();
-    for (let i = 0; i < opt.substeps; i++) simulate(s, dt, pp);
-    const sec = Number(process.hrtime.bigint() - t0) / 1e9;
-    console.log(JSON.stringify({ substeps: opt.substeps, warmup: opt.warmup, seconds: sec, m_tet_solves_per_s: s.nt * opt.substeps / sec / 1e6,
-                                 pos_sha16: sha16(s.pos), vol_error: s.volError, node: process.version }));
+    const rates = [];
+    let sec = 0.0;
+    for (let r = 0; r < Math.max(1, opt.reps); r++) {
+        const t0 = process.hrtime.bigint();
+        for (let i = 0; i < opt.substeps; i++) simulate(s, dt, pp);
+        const el = Number(process.hrtime.bigint() - t0) / 1e9;
+        sec += el;
+        rates.push(s.nt * opt.substeps / el / 1e6);
+    }
+    const sorted = rates.slice().sort((a, b) => a - b);
+    console.log(JSON.stringify({ substeps: opt.substeps, warmup: opt.warmup, reps: rates.length, seconds: sec, m_tet_solves_per_s: sorted[(sorted.length - 1) >> 1],
+                                 rates: rates, pos_sha16: sha16(s.pos), vol_error: s.volError, node: process.version }));
 }
 
 if (require.main === module) main(process.argv.slice(2));

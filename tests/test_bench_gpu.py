@@ -96,3 +96,31 @@ def test_multi_rank_code_path_with_thread_ranks(extra):
         assert c5["multi_gpu"]["rccl_ranks"] == 3 and c5["multi_gpu"]["halo_rank0"]["max_message_bytes"] == 16 * 19 * 19
     else:
         assert "config5_strong" not in d
+
+
+@pytest.mark.parametrize("how", [["--force-dist"], ["--self-spawn"]])
+def test_real_torch_distributed_adapter_with_one_rank(how):
+    """The five torch.distributed calls of the real launch (TorchRanks: init over RCCL, byte broadcast of the communicator id,
+    barrier, max / min over ranks) and libtetsim's own RCCL communicator, with ONE real rank: once in this process
+    (--force-dist) and once as a rank process started by bench.py's own launcher (--self-spawn = what `python bench.py --gpus N`
+    does for N > 1 when no launcher set WORLD_SIZE)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cells", "14", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"] + how, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == 1 and mg["halo_rank0"]["neighbours"] == 0
+
+
+def test_plain_python_launch_asks_for_more_devices_than_there_are():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout == "" and "%d devices requested, %d visible" % (n, n - 1) in r.stderr

@@ -1,0 +1,75 @@
+"""bench.py as its own launcher (CPU): `python bench.py --gpus N` with no WORLD_SIZE in the environment starts N rank processes,
+forwards rank 0's one JSON line, propagates a failing rank's exit code and stops the survivors.  The ranks here are a stub
+(tests/stubs/rank_stub.py); the real ranks are exercised on the GPU box by tests/test_bench_gpu.py."""
+import importlib.util
+import io
+import json
+import os
+import subprocess
+import sys
+import time
+
+from conftest import ROOT
+
+STUB = [sys.executable, os.path.join(ROOT, "tests", "stubs", "rank_stub.py")]
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _launch(n, env=None, **kw):
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        out, err = io.StringIO(), io.StringIO()
+        t0 = time.monotonic()
+        code = _bench().self_launch(n, ["--gpus", str(n), "--steps", "2"], worker=STUB, devices=kw.pop("devices", n), out=out, err=err, **kw)
+        return code, out.getvalue(), err.getvalue(), time.monotonic() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_rank_zero_line_is_forwarded_and_nothing_else():
+    code, out, err, _ = _launch(4)
+    assert code == 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["rank"] == 0 and d["world"] == 4 and d["local_rank"] == 0 and d["addr"] == "127.0.0.1" and 1024 < d["port"] < 65536
+    assert d["argv"] == ["--gpus", "4", "--steps", "2"]
+    assert err.count("noise from rank") == 3          # the other ranks' stdout goes to stderr
+
+
+def test_failing_rank_takes_the_launch_down_with_its_exit_code():
+    code, out, err, took = _launch(3, env={"STUB_FAIL_RANK": "1", "STUB_FAIL_CODE": "7", "STUB_HANG": "1"})
+    assert code == 7 and out.strip() == "" and "rank 1 exited with 7" in err
+    assert took < 20                                   # the hanging ranks were stopped, not waited for
+
+
+def test_too_few_devices_is_a_clear_message_not_a_usage_hint():
+    code, out, err, _ = _launch(8, devices=0)
+    assert code == 2 and out == "" and "8 devices requested, 0 visible" in err
+
+
+def test_hung_ranks_hit_the_limit():
+    code, _, err, took = _launch(2, env={"STUB_HANG": "1"}, limit_s=1.0)
+    assert code == 124 and "still running" in err and took < 20
+
+
+def test_plain_python_launch_on_a_box_without_gpus():
+    """The driver's N = 1 command with N changed, on this GPU-less container: fails fast, names the reason."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    assert r.returncode == 2 and r.stdout == "" and "8 devices requested, %d visible" % torch.cuda.device_count() in r.stderr
