@@ -195,7 +195,10 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams *params);
 /* n substeps with the same dt/params/grab as one host call and one HIP-graph launch: the body of the
  * caller's substep loop (main.js:79-84). */
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params);
-/* Block until everything enqueued on the handle's stream(s) has finished. */
+/* Block until everything enqueued on the handle's stream(s) has finished.  Partitioned bodies: TETSIM_ECOMM if a device-side
+ * halo wait gave up (TETSIM_HALO_TIMEOUT_MS, 30 s by default: a stuck peer, or the two chains of a graph replay sharing one
+ * hardware queue).  The substeps since then used stale data -- restore a checkpoint or stop; the body itself stays usable and
+ * steps eagerly (no graph replay of the halo chains) from then on. */
 int tetsim_sync(tetsim_handle h);
 
 /* --- state access (synchronising) ------------------------------------------------------------ */
@@ -228,7 +231,9 @@ int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
  * POLAR_JACOBI, every tet's quaternion and carried rest shape -- everything the reference keeps in its ping-pong render
  * targets (SoftbodyGPU.js:49-55).  The blob is only meaningful for a body created from the same mesh with the same options by
  * the same library build family (it starts with a header that tetsim_load_state validates: magic, ABI, solver, precision,
- * flags, counts).  A body restored from a blob continues the original trajectory bit for bit.  Both calls synchronise. */
+ * flags, counts, and a digest of the mesh -- vertices, tets, density, batch layout -- so that a blob of ANOTHER mesh with the
+ * same counts is rejected too).  A body restored from a blob continues the original trajectory bit for bit.  Both calls
+ * synchronise (both streams). */
 int tetsim_state_size(tetsim_handle h, uint64_t *bytes_out);
 int tetsim_save_state(tetsim_handle h, void *blob, uint64_t bytes);
 int tetsim_load_state(tetsim_handle h, const void *blob, uint64_t bytes);
@@ -303,7 +308,13 @@ int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps,
 
 /* RCCL transport: rank 0 calls tetsim_comm_unique_id, the host distributes the 128 bytes, every rank
  * calls tetsim_comm_init.  Afterwards tetsim_step/_step_n exchange ghost positions with neighbouring
- * partitions every substep (grouped ncclSend/ncclRecv on a dedicated stream). */
+ * partitions every substep (grouped ncclSend/ncclRecv on a dedicated stream).
+ * Deployment assumption: ONE PROCESS PER GPU stepping ONE partitioned body.  tetsim_step_n replays the two queues' kernel
+ * chains from captured graphs that wait for each other through device words, which is only live while the handle's two
+ * streams are served by independent hardware queues.  That is probed per body, again whenever this library has created
+ * another stream in the process, and a timed-out wait disables replay for good (tetsim_sync) -- but streams that other code
+ * creates in the same process are invisible to the probe.  TETSIM_HALO_GRAPH=0 keeps the halo path eager, which is live on
+ * any queue mapping. */
 int tetsim_comm_unique_id(void *id128);
 int tetsim_comm_init(tetsim_handle h, const void *id128, int32_t rank, int32_t nranks);
 /* What RCCL itself says about this handle's communicator (ncclCommCount / ncclCommUserRank) -- not what the caller passed to

@@ -31,6 +31,9 @@ UNITS = {
     "host_prep.cpp": ["-ffp-contract=off", "-x", "hip"],
     "mesh_file.cpp": ["-ffp-contract=off", "-x", "hip"],
     "tetsim_api.hip": ["-ffp-contract=off"],
+    "tetsim_state.hip": ["-ffp-contract=off"],
+    "tetsim_visual.hip": ["-ffp-contract=off"],
+    "tetsim_measure.hip": ["-ffp-contract=off"],
     "tetsim_create.hip": ["-ffp-contract=off"],
     "tetsim_halo.hip": ["-ffp-contract=off"],
     "tetsim_host.cpp": ["-ffp-contract=off", "-x", "hip"],

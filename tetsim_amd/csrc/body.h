@@ -1,6 +1,9 @@
 // body.h -- the handle behind tetsim_handle and the helpers the translation units of the C ABI share.
 //
-//   tetsim_api.hip     lifecycle, stepping (streams / graphs), state read-back, grab, visual mesh, measurement
+//   tetsim_api.hip     lifecycle, stepping (streams / graphs)
+//   tetsim_state.hip   state read-back (copying / pinned), checkpoint and resume, plan getters
+//   tetsim_visual.hip  embedded visual mesh (skinning, vertex normals), grab (pin, nearest-particle query)
+//   tetsim_measure.hip measurement: per-kernel profile, kernel timing loops, device copy bandwidth
 //   tetsim_create.hip  construction of the two solvers' device state (host preprocessing -> uploads)
 //   tetsim_halo.hip    multi-GPU: halo choreography (two queues, flag or event synchronised), RCCL / in-process transports
 //   tetsim_host.cpp    host-only entry points: preprocessing, partition plans, the .tetsim container
@@ -13,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -75,6 +79,10 @@ struct Rccl {
     }
 };
 extern Rccl g_rccl;
+// Bumped whenever this library creates a stream in the process (every handle's main stream, every halo stream): HIP does not pin a
+// stream to a hardware queue, so a queue-independence probe (probe_queue_independence) is only as good as the set of streams it
+// was taken with -- a body re-probes before it replays its two-chain halo graphs whenever this changed since its last probe.
+extern std::atomic<uint64_t> g_stream_generation;
 
 struct NeighDev {
     int rank = -1;
@@ -98,6 +106,7 @@ struct tetsim_body {
     hipEvent_t ev_fork = nullptr, ev_bnd_tet = nullptr;
     uint32_t interior_tets = 0;         // tets of the interior tiles (blocked, partitioned)
     bool queues_probed = false, queues_independent = false;   // flag path: do the two streams run on independent hardware queues?
+    uint64_t probe_generation = 0;      // g_stream_generation at the time of that probe
     std::map<uint32_t, std::pair<hipGraphExec_t, hipGraphExec_t>> flag_graphs;   // n substeps -> (main chain, halo chain), replayed side by side
     uint32_t* d_sync = nullptr;         // device counters of the flag-synchronised halo path: G done/taken, V done/taken, error
     bool flag_sync = false;             // this body steps through the flag-synchronised path (blocked + transport)
@@ -228,12 +237,16 @@ struct HostProfScope {
 // ---- kernel sequencing (tetsim_api.hip)
 void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e);   // one substep of a fused body (tet | fused x (n-1) | particle)
 void pj_repredict(tetsim_body* h);
 void nh_sweep(tetsim_body* h);
 // first / last: position inside a run of substeps enqueued back to back with one dt
 int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
 int ensure_prediction(tetsim_body* h, double dt);
 int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out);
+// ---- state read-back helpers (tetsim_state.hip)
+const float4* current_positions(tetsim_body* h);   // end-of-substep positions of either solver
+int ensure_index_map(tetsim_body* h);              // device copy of api2dev (pack / nearest kernels)
 
 // ---- construction (tetsim_create.hip)
 int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt);
@@ -252,5 +265,6 @@ int flush_v(tetsim_body* h);                                    // flag path: th
 int enqueue_phase_b(tetsim_body* h);                            // halo start
 int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
 int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains
+void drop_flag_graphs(tetsim_body* h);                          // destroy the captured chains (queues turned out not to be independent)
 
 }  // namespace tetsim

@@ -6,12 +6,14 @@ using namespace tetsim;
 namespace tetsim {
 
 Rccl g_rccl;
+std::atomic<uint64_t> g_stream_generation{0};
 
 int create_halo_stream(tetsim_body* h) {
     if (h->comm_stream) return 0;
     int lo = 0, hi = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    g_stream_generation++;
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_bnd_tet, hipEventDisableTiming));
     // the halo stream's own copy of the substep parameters (push_params fills it in THIS stream's order)
@@ -227,9 +229,19 @@ int enqueue_phase_b(tetsim_body* h) {  // halo start
 // The flag path's two chains wait for each other through device words, so replaying them from graphs is only live if the two
 // streams are served by independent hardware queues (a wait kernel at the head of one queue must not block the signal kernel
 // that sits in the other).  Probe it once: a bounded wait on the halo stream, submitted BEFORE its signal on the main stream.
+// The answer is only valid for the set of streams that existed when it was taken (HIP maps streams onto a few hardware queues as
+// it sees fit): the probe is repeated whenever this library has created another stream in the process since (g_stream_generation),
+// and a device-side wait that times out after a replay (tetsim_sync) drops the graphs for good.  Streams created by OTHER code in
+// the process are invisible to this check: the supported deployment is one process per GPU that steps one partitioned body.
+void drop_flag_graphs(tetsim_body* h) {
+    for (auto& kv : h->flag_graphs) { (void)hipGraphExecDestroy(kv.second.first); (void)hipGraphExecDestroy(kv.second.second); }
+    h->flag_graphs.clear();
+}
 int probe_queue_independence(tetsim_body* h) {
-    if (h->queues_probed) return 0;
+    const uint64_t gen = g_stream_generation.load();
+    if (h->queues_probed && h->probe_generation == gen) return 0;
     h->queues_probed = true;
+    h->probe_generation = gen;
     if (!h->d_sync || !h->comm_stream) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->comm_stream));
@@ -246,6 +258,7 @@ int probe_queue_independence(tetsim_body* h) {
     if (!h->queues_independent) {
         fprintf(stderr, "[tetsim] the halo stream and the main stream share a hardware queue: the halo path stays eager (no graph replay)\n");
         HIPCHK(h, hipMemset(h->d_sync + 6, 0, 2 * sizeof(uint32_t)));
+        drop_flag_graphs(h);   // chains captured under an earlier, better answer must not be replayed any more
     }
     return 0;
 }
