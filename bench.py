@@ -162,11 +162,11 @@ def other_configs():
         body.sync()
         el = time.perf_counter() - t0
         levels = body.info.num_levels
-        fused = bool(body.info.fused_particle_pass)
+        mode = int(body.info.fused_particle_pass)   # 0: tet + particle kernel per substep; 1: one fused kernel per substep; 2: one persistent kernel per frame
         body.close()
         return {"value": round(len(t) * n_sub * frames / el / 1e6, 2), "unit": "M tet-solves/s", "ms_per_frame": round(el / frames * 1e3, 4),
                 "us_per_substep": round(el / frames / n_sub * 1e6, 2), "frames": frames,
-                "launches_per_substep": (levels + 1) if levels else (1 if fused else 2)}
+                "launches_per_substep": (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3)}[mode]}
 
     # config 1: Dragon, the reference's CPU solver (Neo-Hookean Gauss-Seidel), 10 substeps per frame
     c1 = {"workload": "Dragon (%d tets, %d particles), Neo-Hookean XPBD Gauss-Seidel, 10 substeps/frame" % (len(dtets), len(dv))}
@@ -188,7 +188,8 @@ def other_configs():
     out["config1_dragon_neohookean_cpu_path"] = c1
     # config 2: Dragon, polar-decomposition Jacobi, f32, 20 substeps per frame
     out["config2_dragon_polar_jacobi"] = {
-        "workload": "Dragon, polar-decomposition Jacobi, 20 substeps/frame, one graph launch per frame (FAST: one fused kernel per substep)",
+        "workload": "Dragon, polar-decomposition Jacobi, 20 substeps/frame, one graph launch per frame (FAST: ONE persistent kernel per frame, "
+                    "every tile's workgroup resident for the 20 substeps; PRECISE: a tet and a particle kernel per substep)",
         "fast": hip_rate(dv, dtets, 20, 400, solver="polar", precision="fast"),
         "precise": hip_rate(dv, dtets, 20, 200, solver="polar", precision="precise")}
     # config 4: Neo-Hookean Gauss-Seidel on the 1 M-tet lattice + convergence against Jacobi (dropped 2 cm onto the floor)

@@ -140,7 +140,10 @@ typedef struct TetSimInfo {
     uint32_t num_vis_verts;      /* visual vertices attached by tetsim_set_visual_mesh / a .tetsim file (0 = none); since ABI 3 */
     uint32_t num_bodies;         /* independent bodies behind this handle (tetsim_create_batch), 1 otherwise; since ABI 3 */
     uint32_t fused_particle_pass; /* 1: tetsim_step_n runs ONE kernel per substep (particle update fused into the tet kernel's staging,
-                                     DESIGN.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel */
+                                     DESIGN.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel.
+                                     2: ... and the body is small enough for tetsim_step_n to run ONE persistent kernel per CALL (every
+                                     tile's workgroup resident for all n substeps); tetsim_step / tetsim_profile still
+                                     use the per-substep kernels, whose results are the same bit for bit */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */

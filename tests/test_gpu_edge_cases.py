@@ -197,6 +197,39 @@ def test_polar_save_load_state_continues_bit_for_bit(kw):
             other.loadState(blob)
 
 
+def test_state_blob_of_another_mesh_with_the_same_counts_is_rejected():
+    """The header's counts and options cannot tell two meshes of the same size apart; its mesh digest can (a blob of the mirrored
+    Dragon would otherwise overwrite quaternions and carried shapes while volumes and weights stayed this body's)."""
+    v, t = load_mesh("dragon")
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    a.simulateSubsteps(5, DT, PP)
+    blob = a.saveState()
+    v2 = v.copy()
+    v2[:, 0] *= 1.25                      # same particle and tet counts, same options, another shape
+    b = SoftBodyHIP(v2, t, None, dict(PP), solver="polar", precision="fast")
+    with pytest.raises(TetSimError, match="another mesh"):
+        b.loadState(blob)
+    c = SoftBodyHIP(v, t, None, dict(PP, density=500.0), solver="neohookean", order="coloured")
+    d = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured")
+    with pytest.raises(TetSimError, match="another mesh"):
+        d.loadState(c.saveState())        # the density is part of what the blob belongs to (inverse masses)
+
+
+def test_collapsed_tet_does_not_poison_the_fast_clustered_sweep():
+    """A tet whose four corners coincide has tr(F^T F) = 0: Softbody.js leaves it alone (C == 0 returns early, :176); the FAST
+    four-lane kernel's rsq(0) * 0 must not turn that into NaN positions."""
+    v, t = make_lattice(3, y0=0.3)
+    v = v.copy()
+    cell0 = np.unique(t[:6].ravel())
+    # collapse ALL of the first tet's corners onto one point, in the current positions only (the rest pose stays regular)
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order="clustered")
+    pos = body.pos
+    pos[t[body.tetOrder[0]]] = pos[t[body.tetOrder[0], 0]]
+    body.writeState(pos, np.zeros_like(pos))
+    body.simulateSubsteps(3, DT, PP)
+    assert np.isfinite(body.pos).all() and len(cell0) == 8
+
+
 def test_neohookean_save_load_state():
     v, t = load_mesh("dragon")
     a = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured")

@@ -94,14 +94,15 @@ def _compile(unit, flags, force, objdir, extra):
     return obj, True
 
 
-def _build_one(lib, objdir, defines, force, verbose):
+def _build_one(lib, objdir, defines, force, verbose, unit_flags=None):
     os.makedirs(objdir, exist_ok=True)
     src_sha, ker_sha = source_shas()
     info = ['-DTETSIM_SOURCE_SHA="%s"' % src_sha, '-DTETSIM_KERNEL_SHA="%s"' % ker_sha]
+    unit_flags = unit_flags or {}
 
     def one(kv):
         unit, flags = kv
-        return _compile(unit, flags, force, objdir, defines + (info if unit == "build_info.cpp" else []))
+        return _compile(unit, flags + unit_flags.get(unit, []), force, objdir, defines + (info if unit == "build_info.cpp" else []))
 
     with ThreadPoolExecutor(max_workers=min(12, len(UNITS))) as ex:
         results = list(ex.map(one, UNITS.items()))
@@ -123,14 +124,20 @@ def build(force=False, verbose=False, ablation=False):
     return lib
 
 
-def build_variant(name, defines, force=False, verbose=False):
-    """Development: libtetsim_hip_<name>.so with extra -D flags (kernel experiments, A/B through TETSIM_HIP_LIB; tools/ab_lib.py)."""
-    return _build_one(os.path.join(HERE, "libtetsim_hip_%s.so" % name), os.path.join(CSRC, "obj_" + name), list(defines), force, verbose)
+def build_variant(name, defines, force=False, verbose=False, unit_flags=None):
+    """Development: libtetsim_hip_<name>.so with extra -D flags (kernel experiments, A/B through TETSIM_HIP_LIB; tools/ab_lib.py);
+    unit_flags = {"pj_blocked.hip": ["-fslp-vectorize"]} appends compiler flags to single units (--unit-flag unit=flag)."""
+    return _build_one(os.path.join(HERE, "libtetsim_hip_%s.so" % name), os.path.join(CSRC, "obj_" + name), list(defines), force, verbose, unit_flags)
 
 
 if __name__ == "__main__":
     if "--variant" in sys.argv:   # python -m tetsim_amd.build --variant t128 -DTETSIM_TILE=128
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], force="--force" in sys.argv, verbose=True))
+        uf = {}
+        for j, a in enumerate(sys.argv):
+            if a == "--unit-flag":   # --unit-flag pj_blocked.hip=-fslp-vectorize
+                unit, flag = sys.argv[j + 1].split("=", 1)
+                uf.setdefault(unit, []).append(flag)
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], force="--force" in sys.argv, verbose=True, unit_flags=uf))
     else:
         print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

@@ -146,6 +146,13 @@ struct tetsim_body {
     bool blocked = false;
     // fused particle pass (unpartitioned blocked bodies): tetsim_step_n runs  tet | fused x (n-1) | particle  instead of n x (tet | particle)
     bool fused = false;
+    // persistent frame kernel (pjb_frame_kernel): tetsim_step_n runs ONE launch per call; fused bodies of few enough tiles
+    bool frame = false;
+    uint32_t frame_epoch = 1;         // sequence number of the next call's first substep (DevParams::epoch), advanced by n per call
+    uint32_t* d_frame_err = nullptr;  // raised by a tile whose neighbour's partial sums never arrived (bounded wait)
+    int32_t* d_block_tile = nullptr;  // [frame_blocks] tile of every block of the frame kernel's grid, -1 = none
+    uint32_t frame_blocks = 0;
+    bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
     bool v_pending = false;           // flag path: the interior particles of the last enqueued substep are not signalled yet (flush_v)

@@ -17,7 +17,8 @@ struct DevParams {
     float grab[3];
     int32_t grab_local;  // local vertex index, -1 = none
     int32_t grab_local2; // second pinned particle (TETSIM_FLAG_REF_GRAB_TEXEL can select two), -1 = none
-    int32_t pad3[3];
+    uint32_t epoch;      // persistent frame kernel (pj_blocked.hip): sequence number of this call's first substep (the host adds n per call)
+    int32_t pad3[2];
     // f64 view -- NEOHOOKEAN_GS: JS numbers (Softbody.js:195-240)
     double d_dt, d_gravity, d_friction, d_dev_compliance, d_vol_compliance;
     double d_lo[3], d_hi[3];
@@ -128,6 +129,15 @@ void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                        uint32_t* raise_word = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
+// n substeps of an unpartitioned fused-eligible body in ONE persistent launch (pjb_frame_kernel): every tile's workgroup stays
+// resident for the whole call.  block_tile[blocks]: the tile each block works on, -1 = none (the host places the tiles of a body
+// on one XCD that way); local: the exchange of partial sums only has to be coherent inside one XCD's L2 (valid with such a
+// placement, see pjb_probe_xcd).  pbuf: the two partial-sum buffers; err: a device word raised if a neighbour tile's partial sums
+// did not appear within timeout_ms (never in a correct run: all workgroups are co-resident -- pjb_frame_capacity).
+void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
+                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units);   // workgroups of the frame kernel one CU keeps resident (0 = query failed)
+uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks);            // 8 if block i of a grid runs on XCD i % 8, else 0
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores
 // 1 behind the producer kernel, wait spins until it is non-zero in front of the consumer kernel and clears it.  No per-launch
 // argument changes: the kernels can be replayed from a captured graph.

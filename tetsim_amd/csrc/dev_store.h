@@ -23,4 +23,30 @@ __device__ __forceinline__ void store_wt(float4* base, uint32_t index, const flo
     __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, static_cast<int>(index * 16u), 0, 0x11);  // aux: sc0 | sc1
 }
 
+// Exchange between workgroups that share ONE XCD (pj_blocked.hip: the frame kernel's tile partial sums when the host has placed a
+// body's tiles on one XCD): the store is a plain one -- the CU's L1 writes through, the line stays in the XCD's L2 --, the load
+// carries agent scope (sc1): it misses the L1 and is served by that L2.  Measured on MI355X (profiles/r03_frame_kernel.txt): bit-equal
+// results, 6.1 instead of 6.5 us per Dragon substep against the memory-side pair below.  NOT coherent across XCDs (a line dirty in
+// another XCD's L2 is invisible), and a workgroup-scope load (sc0) is served by the stale L1 line for ever; an L1 invalidate
+// (buffer_inv sc1) + plain loads works too but costs 8.1 us.
+__device__ __forceinline__ void store_plain(float4* base, uint32_t index, const float4& v) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    const v4u_t x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, static_cast<int>(index * 16u), 0, 0);
+}
+__device__ __forceinline__ float4 load_l2(const float4* base, uint32_t index) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, 0x7fffffff, 0x00020000);
+    const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(index * 16u), 0, 0x10);   // aux: sc1
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+
+// The matching load: served from the memory side (sc0 sc1), never from a line this XCD's L2 (or this CU's L1) cached before another
+// workgroup's write-through store replaced it -- what a reader needs when no kernel boundary (with its cache invalidation) lies
+// between the store and the load (pj_blocked.hip: the persistent frame kernel).  Same constraints as store_wt.
+__device__ __forceinline__ float4 load_coherent(const float4* base, uint32_t index) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, 0x7fffffff, 0x00020000);
+    const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(index * 16u), 0, 0x11);   // aux: sc0 | sc1
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+
 }  // namespace tetsim

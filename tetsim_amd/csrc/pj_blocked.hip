@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "dev_common.h"
 #include "dev_store.h"
@@ -311,6 +312,213 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(P
     pjb_tet_body<true, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 
+// ---- one persistent launch per tetsim_step_n call (small bodies) -------------------------------------------
+// A Dragon-sized body (15 tiles) occupies 15 of the chip's 2,048 workgroup slots: its substep is launch boundaries and dependent
+// memory trips and nothing else.  Here every tile's workgroup stays resident for all n substeps of a call:
+//   * a lane keeps ITS tet's record -- carried rest shape, quaternion, volume, corner slots -- in registers from substep to
+//     substep (read once, written back once), the tile's reduction order stays in LDS;
+//   * a lane keeps ITS tile slot's particle -- previous position, weight, list of partial sums -- in registers too; positions and
+//     velocities go to memory once, at the end of the call (by the slot that owns the particle);
+//   * the only per-substep traffic between workgroups is the tile partial sums: written write-through with the substep's SEQUENCE
+//     NUMBER in the unused fourth float, and read by the tiles sharing the particle with loads that bypass the caches
+//     (dev_store.h: load_coherent) in a loop that ends when every sum carries the expected number.  Data and flag are one 16-byte
+//     store / one 16-byte load: a substep's exchange is ONE memory trip, there is no barrier among workgroups and no flag array
+//     (the persistent Gauss-Seidel sweep of round 2 paid three trips per colour for flag-then-data).  Buffers alternate by
+//     substep parity: a tile overwrites its sums of substep s-2 only after it has consumed its neighbours' sums of s-1, which they
+//     wrote after consuming this tile's sums of s-2.
+// The arithmetic is the fused kernel's, operation for operation (same pjb_vertex_update, same order of additions), so a call
+// equals the same number of tetsim_step calls bit for bit.  Sequence numbers start at DevParams::epoch, which the host advances
+// by n per call (stale sums of an earlier call never match).  Every workgroup must be resident at once (a waiting tile holds its
+// slot): the host only uses this kernel for bodies of at most pjb_frame_capacity() tiles; a wait is bounded all the same.
+// kLocal: every group of tiles that exchange sums (a body) sits on ONE XCD (the host maps blocks to tiles accordingly and has
+// verified the dispatcher's block -> XCD rule with pjb_probe_xcd), so the exchange only has to be coherent in that XCD's L2: plain
+// stores (the L1 writes through) and agent-scope loads (miss the L1, served by the L2) -- dev_store.h.  !kLocal: write-through
+// stores and cache-bypassing loads, coherent at the memory side (any placement).
+template <bool kLean, bool kLocal>
+__device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
+                                               uint32_t* const err, const uint32_t timeout_ms) {
+    __shared__ float4 s_pos[kTile];
+    __shared__ float s_gx[4 * kTile];
+    __shared__ float s_gy[4 * kTile];
+    __shared__ float s_gz[4 * kTile];
+    __shared__ uint2 s_ent[kTile];
+
+    const int32_t bt = block_tile[blockIdx.x];
+    if (bt < 0) return;   // (a block that only pads the grid so that the others land on the intended XCDs)
+    const uint32_t b = static_cast<uint32_t>(bt);
+    const uint32_t tid = threadIdx.x;
+#ifdef TETSIM_ABLATION   // development build: thread 0 adds up the cycles of each phase over the call (TETSIM_DEBUG_TRACE, tools/frame_trace.py)
+    unsigned long long fr_acc[5] = {0, 0, 0, 0, 0}, fr_last = 0, fr_polls = 0;
+#define FRAME_STAMP(i) do { if (d.trace && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) fr_acc[(i) - 1] += now_ - fr_last; fr_last = now_; } } while (0)
+#define FRAME_POLL() do { if (tid == 0) fr_polls++; } while (0)
+#else
+#define FRAME_STAMP(i) do { } while (0)
+#define FRAME_POLL() do { } while (0)
+#endif
+    const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
+    const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
+    const bool has_slot = tid < nu, has_tet = tid < ntb;
+    const uint32_t slot = v0 + (has_slot ? tid : 0u), e = t0 + (has_tet ? tid : 0u);
+    // everything that stays for the whole call, requested together (ids first: the particle loads depend on them)
+    const uint32_t vid = static_cast<uint32_t>(d.blk_verts[slot]);
+    const uint32_t range = has_slot ? d.lc_range[slot] : 0u;
+    const uint32_t maxsrc = d.blk_maxsrc[b];
+    uint32_t src[9];
+    {
+        const uint32_t* col = d.slot_src + slot;
+#pragma unroll
+        for (uint32_t j = 0; j < 9u; j++) src[j] = (has_slot && j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;
+    }
+    const uchar4 li = d.tet_lidx[e];
+    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
+    float4 q = d.quat[e];
+    const float V = d.vol[e];
+    s_ent[tid] = has_tet ? d.lc_ent[e] : make_uint2(0u, 0u);
+    f3 rest[4];
+    rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
+    rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
+    f3 prev = xyz(d.pos_final[vid]);
+    const float wsum = d.wsum[vid];
+    f3 stage = xyz(d.pos_pred[vid]);     // substep 0 starts from the prediction the previous call left
+    const DevParams& P = *d.params;
+    const uint32_t epoch = P.epoch;
+    const uint32_t first = range & 0x7ffu, last = range >> 16;
+    const bool owner = has_slot && ((range >> 15) & 1u);
+    float4* const pbuf[2] = {pbuf0, pbuf1};
+    const long long limit = 100000ll * timeout_ms;   // 100 MHz ticks; 0 = unbounded
+
+    // the particle update of substep s from the partial sums of every tile that touches the particle (this one included):
+    // ascending tile order, absent = +0 -- the particle kernel's order of additions
+    auto gather_update = [&](const uint32_t s) -> VertexOut {
+        const float4* buf = pbuf[s & 1u];
+        const uint32_t expect = epoch + s;
+        f3 g[9];
+        uint32_t pend = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 9u; j++) { g[j] = F3(0.0f, 0.0f, 0.0f); pend |= (src[j] != 0xffffffffu ? 1u : 0u) << j; }
+        const long long w0 = limit ? wall_clock64() : 0ll;
+        while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+            // only the lanes (and list positions) that still miss a sum issue a request: a trip of the loop is as long as its
+            // slowest request, and a wave that asked for 9 x 64 sums where ~100 are missing waited for 576 round trips' tail
+            float4 t[9];
+#pragma unroll
+            for (uint32_t j = 0; j < 9u; j++)
+                if ((pend >> j) & 1u) t[j] = kLocal ? load_l2(buf, src[j]) : load_coherent(buf, src[j]);
+            FRAME_POLL();
+#pragma unroll
+            for (uint32_t j = 0; j < 9u; j++)
+                if (((pend >> j) & 1u) && __float_as_uint(t[j].w) == expect) { g[j] = xyz(t[j]); pend &= ~(1u << j); }
+            if (limit && pend != 0u && wall_clock64() - w0 > limit) {   // never in a correct run; a wedged GPU helps nobody
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pend = 0u;
+            }
+        }
+        f3 acc = F3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
+        if (src[8] != 0xffffffffu) { acc.x += g[8].x; acc.y += g[8].y; acc.z += g[8].z; }
+        return pjb_vertex_update(acc, wsum, prev, P, vid);
+    };
+
+    for (uint32_t s = 0; s < n; s++) {
+        FRAME_STAMP(0);
+        if (s > 0u) {
+            const VertexOut o = gather_update(s - 1u);
+            prev = o.p;
+            stage = o.pred;
+        }
+        FRAME_STAMP(1);
+        if (has_slot) s_pos[tid] = make_float4(stage.x, stage.y, stage.z, 0.0f);
+        __syncthreads();
+        FRAME_STAMP(2);
+        if (has_tet) {
+            f3 cur[4], r[4], goal[4];
+            cur[0] = xyz(s_pos[li.x]); cur[1] = xyz(s_pos[li.y]); cur[2] = xyz(s_pos[li.z]); cur[3] = xyz(s_pos[li.w]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = rest[k];
+            float4 q_new;
+            f3 cc;
+            pj_solve_tet(cur, r, q, q_new, goal, 9, true, kLean, !kLean, &cc);
+            q = q_new;
+            if (!kLean) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) rest[k] = goal[k];   // the carried shape stays in registers
+            }
+            const f3 vcc = cc * V;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                s_gx[k * kTile + tid] = fmaf(goal[k].x, V, vcc.x);
+                s_gy[k * kTile + tid] = fmaf(goal[k].y, V, vcc.y);
+                s_gz[k * kTile + tid] = fmaf(goal[k].z, V, vcc.z);
+            }
+        }
+        FRAME_STAMP(3);
+        __syncthreads();
+        FRAME_STAMP(4);
+        if (has_slot) {   // the tet kernel's reduction, entry for entry
+            const uint16_t* ent = reinterpret_cast<const uint16_t*>(s_ent);
+            auto plane = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            uint32_t i = first;
+            for (; i + 4u <= last; i += 4u) {
+                uint32_t o[4];
+                float gx[4], gy[4], gz[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) o[j] = static_cast<uint32_t>(ent[i + j]) << 2;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) { gx[j] = plane(s_gx, o[j]); gy[j] = plane(s_gy, o[j]); gz[j] = plane(s_gz, o[j]); }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) { acc.x += gx[j]; acc.y += gy[j]; acc.z += gz[j]; }
+            }
+            for (; i < last; i++) {
+                const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
+                acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
+            }
+            acc.w = __uint_as_float(epoch + s);   // data and "substep s is here" in one 16-byte store
+            if constexpr (kLocal) store_plain(pbuf[s & 1u], v0 + tid, acc);
+            else store_wt(pbuf[s & 1u], v0 + tid, acc);
+        }
+        FRAME_STAMP(5);
+        // (no barrier here: the next trip writes s_pos, last read before the second barrier above, and the planes are rewritten
+        // only behind the next trip's first barrier, which every reducing lane reaches after its reads)
+    }
+    // the particle update that ends the call, and the state back to memory: one writer per particle, every lane its own tet
+    const VertexOut o = gather_update(n - 1u);
+#ifdef TETSIM_ABLATION
+    if (d.trace && tid == 0) { for (int i = 0; i < 5; i++) d.trace[8ull * b + i] = fr_acc[i]; d.trace[8ull * b + 5] = fr_polls; d.trace[8ull * b + 6] = n; d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // XCC_ID
+#endif
+    if (owner) {
+        store_wt(d.pos_final, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
+        store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+        store_wt(d.pos_pred, vid, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+    }
+    if (has_tet) {
+        store_wt(d.quat, e, q);
+        if (!kLean) {
+            store_wt(d.rest_a, e, make_float4(rest[0].x, rest[0].y, rest[0].z, rest[1].x));
+            store_wt(d.rest_b, e, make_float4(rest[1].y, rest[1].z, rest[2].x, rest[2].y));
+            store_wt(d.rest_c, e, make_float4(rest[2].z, rest[3].x, rest[3].y, rest[3].z));
+        }
+    }
+}
+#undef FRAME_STAMP
+#undef FRAME_POLL
+#define TETSIM_FRAME_KERNEL(name, lean, local)                                                                                         \
+    __global__ __launch_bounds__(kTile, 2) void name(PJBlk d, uint32_t n, const int32_t* block_tile, float4* pbuf0, float4* pbuf1, uint32_t* err, \
+                                                     uint32_t timeout_ms) {                                                            \
+        pjb_frame_body<lean, local>(d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);                                                  \
+    }
+TETSIM_FRAME_KERNEL(pjb_frame_kernel, false, false)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest, true, false)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_local, false, true)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest_local, true, true)
+#undef TETSIM_FRAME_KERNEL
+// which XCD runs block i of a grid: the dispatcher hands consecutive workgroups to consecutive XCDs (round-robin), which the
+// host verifies with this kernel before it relies on it (hardware register XCC_ID)
+__global__ void pjb_probe_xcd_kernel(uint32_t* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+}
+
 // ---- cross-queue hand-over of partitioned bodies ----------------------------------------------------------
 // A partitioned substep runs on two queues (halo-side tiles, boundary particles and the transfer on the halo stream, everything
 // else on the main stream; tetsim_halo.hip: enqueue_phase_a).  A dependency between the queues costs ~15 us as an event (eager) and ~6 us as a fork/join edge of a captured graph
@@ -430,6 +638,38 @@ void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent
     auto* kernel = d.lean ? pjb_tet_fused_kernel_constant_rest : pjb_tet_fused_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
+}
+void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
+                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
+    if (d.nb == 0 || n == 0 || blocks == 0) return;
+    auto* kernel = local ? (d.lean ? pjb_frame_kernel_constant_rest_local : pjb_frame_kernel_local) : (d.lean ? pjb_frame_kernel_constant_rest : pjb_frame_kernel);
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
+}
+uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_constant_rest_local, static_cast<int>(kTile), 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_local, static_cast<int>(kTile), 0);
+    if (e != hipSuccess || per_cu <= 0) return 0;
+    if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
+    return static_cast<uint32_t>(per_cu);
+}
+// 8 if block i of a grid runs on XCD i % 8 (whatever the XCDs' numbering) on this device, else 0: a grid of `blocks` one-wave
+// workgroups reports its XCC_ID register
+uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks) {
+    uint32_t* d_out = nullptr;
+    if (blocks < 16u || hipMalloc(reinterpret_cast<void**>(&d_out), blocks * sizeof(uint32_t)) != hipSuccess) return 0;
+    std::vector<uint32_t> out(blocks, 0xffffffffu);
+    hipLaunchKernelGGL(pjb_probe_xcd_kernel, dim3(blocks), dim3(64), 0, s, d_out);
+    const bool ok = hipStreamSynchronize(s) == hipSuccess && hipMemcpy(out.data(), d_out, blocks * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_out);
+    if (!ok) return 0;
+    for (uint32_t i = 0; i < 8u; i++)
+        for (uint32_t j = 0; j < i; j++) if (out[i] == out[j]) return 0;          // the first eight blocks: eight different XCDs
+    for (uint32_t i = 8u; i < blocks; i++) if (out[i] != out[i & 7u]) return 0;    // ... and the pattern repeats
+    return 8;
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }

@@ -69,6 +69,7 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
             o->grab_local2 = to_device(h->grab_ref[1]);
         } else o->grab_local = to_device(h->grab_global);
     }
+    o->epoch = h->frame_epoch;
     o->d_dt = dt;
     o->d_gravity = p.gravity;
     o->d_friction = p.friction;
@@ -234,7 +235,14 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         h->halo_pending = false;
         h->fork_needed = true;
     }
-    for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
+    if (h->frame) {
+        // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
+        // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
+        pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms());
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    } else
+        for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
     if (halo && !rc) {
         hipError_t je = hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0);  // join: the last transfer
         if (je != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("join: ") + hipGetErrorString(je));
@@ -533,6 +541,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         it = h->graphs.emplace(n, exec).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+    if (h->frame) h->frame_epoch += n;   // the next call's sequence numbers (fill_params): stale partial sums never match
     return 0;
 }
 
@@ -541,6 +550,18 @@ int tetsim_sync(tetsim_handle h) {
     HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (h->d_frame_err) {   // persistent frame kernel: a tile's wait for its neighbours' partial sums gave up (never in a correct run)
+        uint32_t err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->d_frame_err, sizeof err, hipMemcpyDeviceToHost));
+        if (err) {
+            HIPCHK(h, hipMemset(h->d_frame_err, 0, sizeof err));
+            h->frame = false;   // step with one kernel per substep from now on
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "
+                                        "the state since then is invalid; this body falls back to one kernel per substep");
+        }
+    }
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted
         uint32_t err = 0;
         HIPCHK(h, hipMemcpy(&err, h->d_sync + 4, sizeof err, hipMemcpyDeviceToHost));

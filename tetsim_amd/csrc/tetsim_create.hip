@@ -229,6 +229,69 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             HIPCHK(h, hipMemset(h->partial_b, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
             if ((rc = upload(h, h->pos_final_b, pos))) return rc;
             k.slot_src = dsrc; k.blk_maxsrc = dmax; k.ns_pad = B.ns_pad;
+            // ... and bodies small enough for every tile's workgroup to be resident at once run a whole tetsim_step_n call as ONE
+            // persistent launch (pj_blocked.hip: pjb_frame_kernel; TETSIM_FRAME_KERNEL=0 keeps one kernel per substep: A/B).  Half
+            // the device's capacity at most: another body's kernels may hold slots too.
+            static const bool allow_frame = [] { const char* e = getenv("TETSIM_FRAME_KERNEL"); return !(e && e[0] == '0'); }();
+            // Placement.  The tiles of one body exchange partial sums every substep; tiles of different bodies (a batch) never do.
+            // If the dispatcher hands block i of a grid to XCD i % 8 (verified once per device with a probe kernel: the XCC_ID
+            // register of every block of a test grid), each body's tiles are put on ONE XCD -- bodies spread over the XCDs,
+            // largest first -- and the exchange only has to be coherent in that XCD's L2 (TETSIM_FRAME_LOCAL=0: never).  Else,
+            // or if a body is too large for half an XCD's resident workgroups, tiles spread over all XCDs and the exchange goes
+            // through the memory side.  Either way at most half the resident workgroups the device offers are used: another body's
+            // kernels may hold slots too, and a waiting tile keeps its slot.
+            uint32_t cus = 0;
+            const uint32_t per_cu = allow_frame ? pjb_frame_capacity(k.lean, &cus) : 0u;
+            const uint32_t nbk = B.num_blocks;
+            std::vector<int32_t> block_tile;
+            if (per_cu != 0u && nbk != 0u && nbk <= per_cu * cus / 2u) {
+                static const bool allow_local = [] { const char* e = getenv("TETSIM_FRAME_LOCAL"); return !(e && e[0] == '0'); }();
+                static int xcd_rule[64] = {};   // per device: 0 = not probed, 1 = round-robin over 8 XCDs verified, 2 = no
+                int& rule = xcd_rule[o.device & 63];
+                if (allow_local && rule == 0) rule = pjb_probe_xcd(h->stream, 256) == 8u ? 1 : 2;
+                // group the tiles by body
+                std::vector<std::vector<uint32_t>> groups(bodies);
+                for (uint32_t b = 0; b < nbk; b++) {
+                    uint32_t body = 0;
+                    if (batch) {
+                        const uint32_t lt = static_cast<uint32_t>(B.tet_perm[B.blk_tet_off[b]]);
+                        body = static_cast<uint32_t>(std::upper_bound(h->batch_first_tet.begin(), h->batch_first_tet.end(), lt) - h->batch_first_tet.begin()) - 1u;
+                    }
+                    groups[std::min(body, bodies - 1u)].push_back(b);
+                }
+                const uint32_t budget = per_cu * (cus / 8u) / 2u;   // workgroups of this body per XCD
+                std::vector<uint32_t> by_size(bodies);
+                for (uint32_t g = 0; g < bodies; g++) by_size[g] = g;
+                std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t c) { return groups[a].size() > groups[c].size(); });
+                std::vector<std::vector<uint32_t>> on_xcd(8);
+                bool local = allow_local && rule == 1 && cus % 8u == 0u;
+                for (uint32_t g : by_size) {
+                    if (!local) break;
+                    uint32_t best = 0;
+                    for (uint32_t x = 1; x < 8u; x++) if (on_xcd[x].size() < on_xcd[best].size()) best = x;
+                    if (on_xcd[best].size() + groups[g].size() > budget) { local = false; break; }
+                    on_xcd[best].insert(on_xcd[best].end(), groups[g].begin(), groups[g].end());
+                }
+                if (!local) {   // any placement: consecutive tiles on consecutive blocks
+                    for (auto& v : on_xcd) v.clear();
+                    for (uint32_t b = 0; b < nbk; b++) on_xcd[b & 7u].push_back(b);
+                }
+                uint32_t most = 0;
+                for (auto& v : on_xcd) most = std::max<uint32_t>(most, static_cast<uint32_t>(v.size()));
+                block_tile.assign(8ull * most, -1);
+                for (uint32_t x = 0; x < 8u; x++)
+                    for (uint32_t j = 0; j < on_xcd[x].size(); j++) block_tile[8ull * j + x] = static_cast<int32_t>(on_xcd[x][j]);
+                h->frame = true;
+                h->frame_local = local;
+                h->frame_blocks = static_cast<uint32_t>(block_tile.size());
+            }
+            if (h->frame) {
+                if ((rc = dev_alloc(h, &h->d_block_tile, block_tile.size()))) return rc;
+                if ((rc = upload(h, h->d_block_tile, block_tile))) return rc;
+                if ((rc = dev_alloc(h, &h->d_frame_err, 1))) return rc;
+                HIPCHK(h, hipMemset(h->d_frame_err, 0, sizeof(uint32_t)));
+                h->info.fused_particle_pass = 2u;
+            }
         }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
