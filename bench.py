@@ -225,13 +225,18 @@ def other_configs():
     return out
 
 
+REAL_STDOUT_FD = None   # the process's real stdout while fd 1 is routed to stderr (HeadlineGuard prints there)
+
+
 class stdout_to_stderr:
     """Route fd 1 to fd 2 while native libraries initialise (RCCL prints a version banner on stdout): rank 0's stdout
     must carry exactly one JSON line."""
 
     def __enter__(self):
+        global REAL_STDOUT_FD
         sys.stdout.flush()
         self._saved = os.dup(1)
+        REAL_STDOUT_FD = self._saved
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
@@ -241,8 +246,47 @@ class stdout_to_stderr:
             ctypes.CDLL(None).fflush(None)
         except Exception:  # noqa: BLE001
             pass
+        global REAL_STDOUT_FD
         os.dup2(self._saved, 1)
         os.close(self._saved)
+        REAL_STDOUT_FD = None
+
+
+class HeadlineGuard:
+    """The optional legs that follow the headline at N > 1 (the peer-to-peer halo check, BASELINE config 5) are collective: a rank
+    that fails alone leaves the others inside a barrier.  They must never cost the headline.  Once the headline line is complete it
+    is armed with a budget; if the legs are not done by then, rank 0 prints the headline as it stands (plus a note saying what was
+    cut short) on the real stdout and every rank leaves at once -- exit code 0, one JSON line, as the contract wants."""
+
+    def __init__(self):
+        self._timer = None
+
+    def arm(self, line, seconds, what):
+        import threading
+        self.disarm()
+
+        def fire():
+            try:
+                if line is not None:
+                    line.setdefault("notes", []).append("%s did not finish within %d s and was cut short; the headline above is complete" % (what, seconds))
+                    data = (json.dumps(line) + "\n").encode()
+                    fd = REAL_STDOUT_FD if REAL_STDOUT_FD is not None else 1
+                    while data:
+                        data = data[os.write(fd, data):]
+            finally:
+                os._exit(0)
+
+        self._timer = threading.Timer(seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+GUARD = HeadlineGuard()
 
 
 class TorchRanks:
@@ -265,6 +309,13 @@ class TorchRanks:
             t.copy_(self.torch.tensor(list(data), dtype=self.torch.uint8))
         self.dist.broadcast(t, src=0)
         return bytes(t.cpu().tolist())
+
+    def all_gather_bytes(self, data, n):          # every rank's `data` (n bytes), in rank order
+        t = self.torch.tensor(list(data), dtype=self.torch.uint8, device="cuda")
+        out = self.torch.empty(n * self.dist.get_world_size(), dtype=self.torch.uint8, device="cuda")
+        self.dist.all_gather_into_tensor(out, t)
+        flat = bytes(out.cpu().tolist())
+        return [flat[i * n:(i + 1) * n] for i in range(self.dist.get_world_size())]
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -295,6 +346,13 @@ class ThreadRanks:
             self.s["bytes"] = bytes(data)
         self.s["barrier"].wait()
         out = self.s["bytes"]
+        self.s["barrier"].wait()
+        return out
+
+    def all_gather_bytes(self, data, n):
+        self.s.setdefault("gather", [None] * len(self.s["vals"]))[self.rank] = bytes(data)
+        self.s["barrier"].wait()
+        out = list(self.s["gather"])
         self.s["barrier"].wait()
         return out
 
@@ -420,6 +478,12 @@ def parse_args():
     ap.add_argument("--config5-cells", type=int, default=110, help="cells per side of the config-5 body (110 = 7,986,000 tets)")
     ap.add_argument("--no-beyond-mall", action="store_true", help="N = 1: skip `roofline.beyond_mall` (the 8 M-tet body on this GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "p2p"],
+                    help="N > 1: transport of the per-substep ghost exchange of the HEADLINE run -- rccl (default: grouped ncclSend/ncclRecv) or p2p "
+                         "(the boundary-particle kernel stores straight into the neighbours' ghost ranges, mapped through HIP IPC)")
+    ap.add_argument("--p2p-check", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1 with --halo rccl: afterwards repeat the run on a fresh body with the peer-to-peer halo and report its rate and whether its "
+                         "positions equal the RCCL run's bit for bit (`multi_gpu.p2p_halo`); auto = on, except with --fake-ranks")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     ap.add_argument("--self-spawn", action="store_true",
                     help="launch the rank processes from this process even when --gpus is 1 (what a plain `python bench.py --gpus N`, "
@@ -588,7 +652,7 @@ def slab_owner(nverts, cells, nz, world):
     return np.minimum((np.arange(nverts) // plane) // layers, world - 1).astype(np.int32)
 
 
-def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False):
+def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False, halo=None):
     """This rank's body of the cells^2 x (cells [x world when weak]) lattice (+ communicator when ranks is not None).
     vote=True: creation (local, may fail on one rank alone: memory, ...) is followed by a vote of all ranks BEFORE the collective
     communicator set-up; if any rank failed, every rank returns (None, ..., error text) instead of hanging in the broadcast."""
@@ -620,6 +684,28 @@ def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False):
         from tetsim_amd import comm_init, comm_unique_id
         uid = ranks.broadcast_bytes(comm_unique_id() if rank == 0 else None, 128)
         comm_init(body, uid, rank, world)
+        if (halo or args.halo) == "p2p" and world > 1:
+            # the peer-to-peer halo on top of the communicator (RCCL keeps carrying the refresh after a dt change): every rank
+            # describes its buffers, torch gathers the descriptions, every rank opens its neighbours' (HIP IPC); a local failure is
+            # voted on so that no rank steps alone
+            from tetsim_amd import p2p_connect, p2p_export
+            perr = None
+            try:
+                blob = p2p_export(body)
+            except Exception as e:  # noqa: BLE001
+                blob, perr = b"\0" * 512, "rank %d: %r" % (rank, e)
+            blobs = ranks.all_gather_bytes(blob, 512)
+            if perr is None:
+                try:
+                    p2p_connect(body, blobs)
+                except Exception as e:  # noqa: BLE001
+                    perr = "rank %d: %r" % (rank, e)
+            if ranks.min_float(0.0 if perr else 1.0) < 1.0:
+                if not vote:
+                    raise SystemExit("peer-to-peer halo: " + (perr or "another rank could not connect"))
+                body.close()
+                return None, verts, tets, pp, nz, perr or "another rank could not connect its peer-to-peer halo"
+            ranks.barrier()
     return body, verts, tets, pp, nz, None
 
 
@@ -653,7 +739,7 @@ def multi_gpu_report(body, world, elapsed_local, host_local, steps, ranks):
         raise SystemExit("RCCL reports %d ranks in the halo communicator but --gpus is %d: refusing to report a number" % (ci["rccl_ranks"], world))
     ms = elapsed_local / steps * 1e3
     hq = host_local / (steps * SUBSTEPS) * 1e6
-    rep = {"rccl_ranks": ci["rccl_ranks"],
+    rep = {"rccl_ranks": ci["rccl_ranks"], "halo": "p2p" if ci.get("p2p") else "rccl",
            "ranks_ms_per_step": {"min": round(ranks.min_float(ms), 4), "max": round(ranks.max_float(ms), 4)},
            "host_enqueue_us_per_substep": {"min": round(ranks.min_float(hq), 2), "max": round(ranks.max_float(hq), 2)},
            "halo_rank0": {"neighbours": ci["neighbours"], "send_bytes_per_substep": ci["send_bytes_per_substep"],
@@ -663,6 +749,73 @@ def multi_gpu_report(body, world, elapsed_local, host_local, steps, ranks):
     if ci["loopback"]:
         rep["loopback"] = True
     return rep
+
+
+def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
+    """The headline run once more on a fresh body whose halo goes peer to peer (include/tetsim.h: tetsim_halo_p2p_connect): the same
+    warm-up and timed frames from the same rest state, so the owned positions must equal the RCCL run's BIT FOR BIT -- on real
+    peers, which the one-GPU tests cannot show -- and the rate says what taking RCCL's send/recv kernel off the substep's chain
+    is worth here.  Every local step is caught and VOTED on (a rank never leaves the others inside a collective), device-side
+    waits are short, one probe substep comes first, and the whole leg sits under the HeadlineGuard's budget."""
+    saved = os.environ.get("TETSIM_HALO_TIMEOUT_MS")
+    os.environ["TETSIM_HALO_TIMEOUT_MS"] = "4000"
+    state = {"err": None}
+
+    def local(fn):      # run a local step unless this rank has failed already; remember the first failure
+        if state["err"] is None:
+            try:
+                return fn()
+            except Exception as e:  # noqa: BLE001
+                state["err"] = "rank %d: %r" % (rank, e)
+        return None
+
+    def everyone_ok():  # collective
+        return ranks.min_float(0.0 if state["err"] else 1.0) >= 1.0
+
+    body2 = None
+    try:
+        body2, _, _, pp2, _, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True, halo="p2p")
+        if body2 is None:
+            return {"error": err}
+        local(lambda: (body2.simulate(DT, pp2), body2.sync()))   # a transport that does not work shows here, within seconds
+        if not everyone_ok():
+            return {"error": state["err"] or "the probe substep failed on another rank"}
+        local(lambda: body2.simulateSubsteps(SUBSTEPS - 1, DT, pp2))
+        # the first frame is done; the others as in the headline run: the rest of the warm-up untimed, then the timed frames
+        frames_before = max(args.warmup - 1, 0)
+        timed = args.warmup + args.steps - 1 - frames_before
+        for _ in range(frames_before):
+            local(lambda: body2.simulateSubsteps(SUBSTEPS, DT, pp2))
+        local(body2.sync)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            local(lambda: body2.simulateSubsteps(SUBSTEPS, DT, pp2))
+        local(body2.sync)
+        ranks.barrier()
+        el_local = time.perf_counter() - t0
+        pos2 = local(lambda: body2.pos)
+        same = pos2 is not None and pos_rccl is not None and bool(np.array_equal(pos2.view(np.uint32), pos_rccl.view(np.uint32)))
+        fin = pos2 is not None and bool(np.isfinite(pos2).all())
+        el = ranks.max_float(el_local)
+        res = {"value": round(nt_global * SUBSTEPS * timed / el / 1e6, 1) if timed > 0 else None, "unit": "M tet-solves/s",
+               "ms_per_step": round(el / max(timed, 1) * 1e3, 4), "steps": timed,
+               "bit_equal_to_rccl_run": bool(ranks.min_float(1.0 if same else 0.0) >= 1.0), "finite": bool(ranks.min_float(1.0 if fin else 0.0) >= 1.0),
+               "ranks_ms_per_step": {"min": round(ranks.min_float(el_local / max(timed, 1) * 1e3), 4), "max": round(ranks.max_float(el_local / max(timed, 1) * 1e3), 4)}}
+        if not everyone_ok():
+            res["error"] = state["err"] or "a step failed on another rank"
+        return res
+    finally:
+        if body2 is not None:
+            try:
+                ranks.barrier()
+                body2.close()
+            except Exception:  # noqa: BLE001
+                pass
+        if saved is None:
+            os.environ.pop("TETSIM_HALO_TIMEOUT_MS", None)
+        else:
+            os.environ["TETSIM_HALO_TIMEOUT_MS"] = saved
 
 
 def pmc_traffic(kname, kernel_sha):
@@ -770,6 +923,17 @@ def run(args, rank, world, local_rank, ranks):
         out["roofline"] = {"bound": "hbm", "kernel": "whole substep, all ranks (tet + particle kernels)", "achieved": round(agg, 1),
                            "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4), "traffic": None,
                            "substep_alg_bytes_per_tet": round(b_alg, 1)}
+    # ---- optional legs of an N-rank run: nothing below may cost the headline (HeadlineGuard) ------------------------------------
+    if use_dist and world > 1:
+        GUARD.arm(out, int(os.environ.get("TETSIM_BENCH_OPTIONAL_S", "240")), "the legs after the headline (peer-to-peer halo check / config 5)")
+    if use_dist and world > 1 and args.halo == "rccl" and (args.p2p_check == "on" or (args.p2p_check == "auto" and not args.fake_ranks)):
+        try:
+            pos_rccl = body.pos
+        except Exception:  # noqa: BLE001
+            pos_rccl = None
+        res = p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global)
+        if rank == 0:
+            out["multi_gpu"]["p2p_halo"] = res
     # ---- BASELINE config 5, literally: the 110^3-cell lattice (7,986,000 tets) cut into N slabs -- strong scaling -----------
     if use_dist and (args.config5 == "on" or (args.config5 == "auto" and world == 8)) and not (args.scaling == "strong" and cells == args.config5_cells):
         # (the headline body stays alive: if this second body cannot be built on some rank, the line above is still reported)
@@ -793,6 +957,7 @@ def run(args, rank, world, local_rank, ranks):
                     "scaling": "strong", "value": round(v, 1), "unit": "M tet-solves/s", "steps": steps5, "ms_per_step": round(e5 / steps5 * 1e3, 4),
                     "finite": bool(finite), "multi_gpu": mg5,
                     "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+    GUARD.disarm()
     if world == 1:
         body.close()
         if not args.no_beyond_mall and args.precision == "fast" and cells == CELLS and args.solver == "polar" and "roofline" in out:

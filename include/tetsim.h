@@ -328,6 +328,8 @@ typedef struct TetSimCommInfo {
     uint32_t neighbours;
     uint64_t send_bytes_per_substep, recv_bytes_per_substep, max_message_bytes;
     int32_t loopback;            /* TETSIM_DEBUG_LOOPBACK_HALO: the halo partner is this rank itself (measurement only) */
+    int32_t p2p;                 /* 1: the per-substep halo is stored straight into the neighbours' ghost ranges (tetsim_halo_p2p_connect);
+                                    occupies what was tail padding: the struct's size is unchanged */
 } TetSimCommInfo;
 int tetsim_comm_info(tetsim_handle h, TetSimCommInfo *out);
 /* Send 1 KiB to this handle's own rank and receive it back through the initialised communicator, on the halo
@@ -338,6 +340,23 @@ int tetsim_comm_selftest(tetsim_handle h);
  * host_us = host time to issue one group, total_us = wall time per group.  Design input for DESIGN.md "Multi-GPU". */
 int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph,
                       double *host_us, double *total_us);
+/* Peer-to-peer halo (opt-in; POLAR_JACOBI + TETSIM_FAST blocked partitions).  The per-substep ghost exchange without a transfer
+ * kernel: each rank's boundary-particle kernel stores its new predictions straight into the neighbours' ghost ranges (peer memory
+ * over xGMI, mapped through HIP IPC; double buffered by substep parity) and a word per neighbour says "arrived"; the halo-side
+ * tiles wait for those words.  RCCL's grouped send/recv kernel (~15 us even to itself) leaves the substep's critical chain.
+ *   every rank:  tetsim_halo_p2p_export(h, blob)            -> TETSIM_P2P_BLOB_BYTES bytes describing its buffers
+ *   the host:    gathers the blobs of all part_count ranks (any transport: torch.distributed, MPI, files)
+ *   every rank:  tetsim_halo_p2p_connect(h, blobs, part_count)   [blobs + r * TETSIM_P2P_BLOB_BYTES = rank r's]
+ * Ranks of the same process connect through plain pointers and must be stepped TOGETHER with tetsim_group_step_n (after its first
+ * call): their kernels wait for each other on the device, which is only live if no wait is submitted in front of the kernel that
+ * satisfies it -- the group call orders the submissions, independent tetsim_step_n calls of two bodies of one process do not.  A
+ * loopback body (TETSIM_DEBUG_LOOPBACK_HALO) connects to itself with its own blob (count 1).  Call between steps, and before ANY rank
+ * steps again (the host synchronises the ranks around it).  On top of an RCCL communicator (connect after tetsim_comm_init) RCCL keeps
+ * carrying the one refresh exchange after a dt change; without one the peer-to-peer halo is the only transport and dt must stay fixed.
+ * Device-side waits are bounded by TETSIM_HALO_TIMEOUT_MS as read at this call.  Results are the RCCL transport's, bit for bit. */
+#define TETSIM_P2P_BLOB_BYTES 512
+int tetsim_halo_p2p_export(tetsim_handle h, void *blob);
+int tetsim_halo_p2p_connect(tetsim_handle h, const void *blobs, uint32_t count);
 /* All partitions of one decomposition living in ONE process (one or several devices): n substeps with the SAME
  * stream/event choreography as the RCCL path -- interior tiles, wait for the previous halo, boundary tiles, boundary
  * particles, start the halo on a second stream, interior particles -- with asynchronous device copies standing in

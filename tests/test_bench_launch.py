@@ -73,3 +73,34 @@ def test_plain_python_launch_on_a_box_without_gpus():
     if torch.cuda.device_count() >= 8:
         return
     assert r.returncode == 2 and r.stdout == "" and "8 devices requested, %d visible" % torch.cuda.device_count() in r.stderr
+
+
+def test_headline_guard_prints_the_headline_when_an_optional_leg_hangs():
+    """bench.py's optional N > 1 legs (peer-to-peer halo check, config 5) run under a budget: when it runs out, rank 0 prints the
+    headline line it already has -- on the REAL stdout, also while fd 1 is routed to stderr -- with a note, and the process leaves
+    with exit code 0; the other ranks leave silently."""
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench_module', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "line = {'metric': 'tet_solves_per_sec', 'value': 1.0} if sys.argv[1] == '0' else None\n"
+        "with b.stdout_to_stderr():\n"
+        "    b.GUARD.arm(line, 1, 'the test leg')\n"
+        "    print('noise that must stay off the real stdout')\n"
+        "    time.sleep(30)\n"
+        "print('never reached')\n" % (ROOT, os.path.join(ROOT, "bench.py")))
+    for rank, want_line in (("0", True), ("1", False)):
+        t0 = time.monotonic()
+        r = subprocess.run([sys.executable, "-c", code, rank], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and time.monotonic() - t0 < 20
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        if want_line:
+            assert len(lines) == 1
+            d = json.loads(lines[0])
+            assert d["value"] == 1.0 and "cut short" in d["notes"][0]
+        else:
+            assert lines == []
+    # and a leg that finishes in time leaves the line alone
+    code2 = code.replace("time.sleep(30)", "b.GUARD.disarm(); time.sleep(1.5)").replace("print('never reached')", "print('reached')")
+    r = subprocess.run([sys.executable, "-c", code2, "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "reached"

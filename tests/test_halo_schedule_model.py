@@ -16,6 +16,7 @@ import pytest
 # buffers of one rank; versions count substeps: entering substep s every prediction has version s, the partial sums of substep s
 # have version s + 1, the particle passes of substep s take the predictions to version s + 1
 PRED_B, PRED_I, PRED_G, PART_H, PART_I = "pred boundary", "pred interior", "pred ghost", "partial halo-side", "partial interior"
+PRED_G1 = "pred ghost (second buffer)"   # peer-to-peer halo: the ghosts of odd substeps
 
 
 def rank_program(calls):
@@ -58,20 +59,28 @@ class Violation(Exception):
     pass
 
 
-def explore(calls, mutate=None):
+PEER = "peer:"   # prefix of a buffer / word that lives at the OTHER rank (peer-to-peer halo: stores and raises into the neighbour's memory)
+
+
+def explore(calls, mutate=None, program=None):
     """Depth-first search over all interleavings of 2 ranks x 2 queues.  Returns the number of distinct states visited."""
-    progs = [rank_program(calls), rank_program(calls)]
+    program = program or rank_program
+    progs = [program(calls), program(calls)]
     if mutate:
         progs = [mutate(p) for p in progs]
     queues = [progs[0][0], progs[0][1], progs[1][0], progs[1][1]]   # rank = q // 2
     total = sum(abs(n) for n in calls)
-    bufs = (PRED_B, PRED_I, PRED_G, PART_H, PART_I)
+    bufs = (PRED_B, PRED_I, PRED_G, PART_H, PART_I, PRED_G1)
     version0 = tuple((0,) * len(bufs) for _ in range(2))           # [rank][buffer]
-    # state: (pc per queue, running flag per queue, words per rank (G, V), versions)
-    start = ((0, 0, 0, 0), (False,) * 4, ((0, 0, 0), (0, 0, 0)), version0)
+    # state: (pc per queue, running flag per queue, words per rank (G, V, D, A0, A1), versions)
+    start = ((0, 0, 0, 0), (False,) * 4, ((0,) * 5, (0,) * 5), version0)
     seen, stack = {start}, [start]
     bi = {b: i for i, b in enumerate(bufs)}
-    wi = {"G": 0, "V": 1, "D": 2}
+    wi = {"G": 0, "V": 1, "D": 2, "A0": 3, "A1": 4}
+    p2p = program is not rank_program
+
+    def where(r, name):   # (rank, plain name) of a buffer or word that may carry the peer prefix
+        return (1 - r, name[len(PEER):]) if name.startswith(PEER) else (r, name)
 
     def active(state):   # (queue, op) of every kernel between START and END
         pcs, running = state[0], state[1]
@@ -83,7 +92,8 @@ def explore(calls, mutate=None):
         if all(pcs[q] == len(queues[q]) for q in range(4)):
             if any(w for r in words for w in r):
                 raise Violation("a word is still raised at the end: %r" % (words,))
-            if any(versions[r][bi[b]] != total for r in range(2) for b in (PRED_B, PRED_I, PRED_G)):
+            final_ghosts = (PRED_G1 if total & 1 else PRED_G) if p2p else PRED_G   # peer-to-peer: the buffer of the next substep's parity
+            if any(versions[r][bi[b]] != total for r in range(2) for b in (PRED_B, PRED_I, final_ghosts)):
                 raise Violation("final versions %r" % (versions,))
             continue
         moves = []
@@ -118,11 +128,14 @@ def explore(calls, mutate=None):
                     for rr in (0, 1):
                         if versions[rr][bi[PRED_B]] != xfer[2]:
                             raise Violation("%s sends boundary predictions of version %d" % (name, versions[rr][bi[PRED_B]]))
+                    gbuf = xfer[3] if len(xfer) > 3 else PRED_G   # (peer-to-peer bodies: the refresh lands in the buffer of the current parity)
                     for rr in (0, 1):                          # the receiver's ghosts and the sender's boundary particles must not be in use
                         for aq, op in active(state):
-                            if aq // 2 == rr and (PRED_G in op[1] or PRED_B in op[2]):
+                            if aq // 2 == rr and (gbuf in op[1] or PRED_B in op[2]):
                                 raise Violation("%s while %s is running on rank %d" % (name, op[0], rr))
-                        nver[rr][bi[PRED_G]] = xfer[2]
+                            if aq // 2 != rr and (PEER + gbuf) in op[2]:
+                                raise Violation("%s while %s is storing into the same ghosts" % (name, op[0]))
+                        nver[rr][bi[gbuf]] = xfer[2]
                     npcs[q] += 1
                     npcs[(1 - r) * 2 + 1] += 1
                 else:
@@ -130,21 +143,25 @@ def explore(calls, mutate=None):
                         nwords[r][wi[waits]] = 0               # consumed (wait kernels are modelled as atomic)
                         npcs[q] += 1
                     else:
-                        if raises is not None:
-                            if words[r][wi[raises]]:
-                                raise Violation("%s raises %s twice" % (name, raises))
-                            nwords[r][wi[raises]] = 1
+                        for word in ((raises,) if isinstance(raises, str) else (raises or ())):
+                            wr, wn = where(r, word)
+                            if nwords[wr][wi[wn]]:
+                                raise Violation("%s raises %s twice" % (name, word))
+                            nwords[wr][wi[wn]] = 1
                         for b, want in reads.items():
                             if versions[r][bi[b]] != want:
                                 raise Violation("%s reads %s at version %d, wants %d" % (name, b, versions[r][bi[b]], want))
-                        for aq, op in active(state):           # nobody (of this rank) may be writing what we read or write, or reading what we write
-                            if aq // 2 != r:
-                                continue
+                        # nobody may be writing what we read or write, or reading what we write -- buffers named per rank, so a
+                        # store into the peer's memory is checked against the PEER's kernels
+                        mine_r = {where(r, b) for b in reads}
+                        mine_w = {where(r, b) for b in writes}
+                        for aq, op in active(state):
+                            ar = aq // 2
                             for b in op[2]:
-                                if b in reads or b in writes:
+                                if where(ar, b) in mine_r or where(ar, b) in mine_w:
                                     raise Violation("%s starts while %s writes %s" % (name, op[0], b))
                             for b in op[1]:
-                                if b in writes:
+                                if where(ar, b) in mine_w:
                                     raise Violation("%s would write %s while %s reads it" % (name, b, op[0]))
                         if not reads and not writes:           # a signal kernel: atomic
                             npcs[q] += 1
@@ -152,7 +169,8 @@ def explore(calls, mutate=None):
                             nrun[q] = True
             else:
                 for b, new in writes.items():
-                    nver[r][bi[b]] = new
+                    br, bn = where(r, b)
+                    nver[br][bi[bn]] = new
                 nrun[q] = False
                 npcs[q] += 1
             nxt = (tuple(npcs), tuple(nrun), tuple(tuple(w) for w in nwords), tuple(tuple(v) for v in nver))
@@ -197,3 +215,88 @@ def test_the_model_notices_a_broken_choreography(what, mutate):
     with pytest.raises(Violation):
         for calls in ([2], [3], [2, 2], [2, -2]):
             explore(calls, mutate)
+
+
+# ---- peer-to-peer halo (tetsim_halo_p2p_connect): no transfer; the boundary-particle kernel stores into the PEER's ghost buffer of the
+# next substep's parity, the wait kernel in front of the halo-side tiles raises the peer's "arrived" word of that parity as it starts and
+# waits for its own ------------------------------------------------------------------------------------------------------------------
+def rank_program_p2p(calls, raise_in_own_kernel=False):
+    """As rank_program, for a connected body.  Substep s reads ghost buffer s & 1; P_b(s) also writes the peer's buffer (s + 1) & 1; the
+    words A0 / A1 ("arrived", by parity) live at the receiver.  raise_in_own_kernel: partitions of one process give the raise a kernel of
+    its own right behind P_b (tetsim_group_step_n), one rank per process folds it into the next wait kernel / the flush."""
+    main, halo = [], []
+    s = 0
+    gb = lambda k: PRED_G1 if k & 1 else PRED_G
+    pending = False   # P_b's "arrived" not raised yet
+    for call, n in enumerate(calls):
+        if n < 0:
+            n = -n
+            main.append(("repredict", {PRED_B: s, PRED_I: s}, {PRED_B: s, PRED_I: s}, None, None, None, len(halo)))
+            main.append(("signal D", {}, {}, "D", None, None, None))
+            halo.append(("wait D", {}, {}, None, "D", None, None))
+            halo.append(("X(refresh %d)" % call, {PRED_B: s}, {}, None, None, ("refresh", call, s, gb(s)), None))   # RCCL / copies, into the current parity's buffer
+        v_pending = False
+        for _ in range(n):
+            main.append(("T_int(%d)" % s, {PRED_I: s}, {PART_I: s + 1}, "V" if v_pending else None, None, None, None))
+            # the wait kernel: raises (as it starts), then V, then the peer's "arrived" of this parity
+            if pending:
+                halo.append(("raise A%d" % (s & 1), {}, {}, PEER + "A%d" % (s & 1), None, None, None))
+                pending = False
+            if v_pending:
+                halo.append(("wait V(%d)" % (s - 1), {}, {}, None, "V", None, None))
+            if s > 0:
+                halo.append(("wait A%d(%d)" % (s & 1, s), {}, {}, None, "A%d" % (s & 1), None, None))
+            halo.append(("T_H(%d)" % s, {PRED_B: s, PRED_I: s, gb(s): s}, {PART_H: s + 1}, None, None, None, None))
+            halo.append(("P_b(%d)" % s, {PART_H: s + 1}, {PRED_B: s + 1, PEER + gb(s + 1): s + 1}, "G", None, None, None))
+            pending = True
+            if raise_in_own_kernel:
+                halo.append(("raise A%d" % ((s + 1) & 1), {}, {}, PEER + "A%d" % ((s + 1) & 1), None, None, None))
+                pending = False
+            main.append(("wait G(%d)" % s, {}, {}, None, "G", None, None))
+            main.append(("P_i(%d)" % s, {PART_H: s + 1, PART_I: s + 1}, {PRED_I: s + 1}, None, None, None, None))
+            v_pending = True
+            s += 1
+        main.append(("signal V(%d)" % (s - 1), {}, {}, "V", None, None, None))
+        if pending:
+            halo.append(("raise A%d" % (s & 1), {}, {}, PEER + "A%d" % (s & 1), None, None, None))
+            pending = False
+        halo.append(("wait V(%d)" % (s - 1), {}, {}, None, "V", None, None))
+    return main, halo
+
+
+def _final_arrived_is_expected(fn):
+    """The last substep's "arrived" stays raised at the end of a run (the next call's first wait consumes it): clear it in the model by
+    appending that wait."""
+    def program(calls):
+        main, halo = fn(calls)
+        total = sum(abs(n) for n in calls)
+        return main, halo + [("wait A%d(next call)" % (total & 1), {}, {}, None, "A%d" % (total & 1), None, None)]
+    return program
+
+
+P2P = _final_arrived_is_expected(rank_program_p2p)
+P2P_GROUP = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, raise_in_own_kernel=True))
+
+
+@pytest.mark.parametrize("program", [P2P, P2P_GROUP], ids=["one rank per process", "ranks of one process"])
+@pytest.mark.parametrize("calls", [[1], [2], [3], [1, 1], [2, 1, 2], [4], [2, -2], [1, -1, -3, 2], [3, 3]])
+def test_peer_to_peer_halo_every_interleaving_is_live_and_race_free(calls, program):
+    assert explore(calls, program=program) > 10 * sum(abs(n) for n in calls)
+
+
+@pytest.mark.parametrize("what,mutate", [
+    # ONE ghost buffer: a fast neighbour's boundary-particle kernel of substep s stores the ghosts of s + 1 while this rank's
+    # halo-side tiles of substep s still read the ghosts of s
+    ("no double buffering", _edit(lambda op: (op[0], {(PRED_G if b == PRED_G1 else b): v for b, v in op[1].items()},
+                                              {(PEER + PRED_G if b == PEER + PRED_G1 else b): v for b, v in op[2].items()}) + op[3:])),
+    # ONE word: substep s + 1's raise can land before this rank's wait kernel (still waiting for V) has consumed substep s's
+    ("one arrived word instead of a pair", _edit(lambda op: op[:3] + (PEER + "A0" if op[3] in (PEER + "A0", PEER + "A1") else op[3], "A0" if op[4] in ("A0", "A1") else op[4]) + op[5:])),
+    # the halo-side tiles must not start before the neighbour's stores are complete
+    ("no wait for arrived", _drop(lambda op: op[4] in ("A0", "A1") and "next call" not in op[0])),
+    # without the raise at the end of a call (nothing follows the last boundary-particle kernel) the neighbour's next call waits for ever
+    ("no raise at the end of the last call", lambda p: (p[0], [op for i, op in enumerate(p[1]) if i != max(j for j, o in enumerate(p[1]) if o[0].startswith("raise A"))])),
+])
+def test_the_model_notices_a_broken_peer_to_peer_choreography(what, mutate):
+    with pytest.raises(Violation):
+        for calls in ([2], [3], [2, 2], [3, 3]):
+            explore(calls, mutate, program=P2P)

@@ -61,7 +61,7 @@ DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "
 
 class TetSimCommInfo(C.Structure):
     _fields_ = [("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("neighbours", C.c_uint32), ("send_bytes_per_substep", C.c_uint64),
-                ("recv_bytes_per_substep", C.c_uint64), ("max_message_bytes", C.c_uint64), ("loopback", C.c_int32)]
+                ("recv_bytes_per_substep", C.c_uint64), ("max_message_bytes", C.c_uint64), ("loopback", C.c_int32), ("p2p", C.c_int32)]
 
 
 class TetSimPlanSizes(C.Structure):
@@ -86,6 +86,7 @@ SYMBOLS = [
     "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
+    "tetsim_halo_p2p_export", "tetsim_halo_p2p_connect",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
     "tetsim_prep_tiles", "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
@@ -158,6 +159,8 @@ def lib():
     L.tetsim_comm_info.argtypes = [H, C.POINTER(TetSimCommInfo)]
     L.tetsim_group_step_n.argtypes = [C.POINTER(H), u32, u32, dbl, PP]
     L.tetsim_halo_exchange_local.argtypes = [C.POINTER(H), u32]
+    L.tetsim_halo_p2p_export.argtypes = [H, C.c_void_p]
+    L.tetsim_halo_p2p_connect.argtypes = [H, C.c_void_p, u32]
     L.tetsim_get_halo_plan.argtypes = [H, ip, ip, ip, ip, ip]
     L.tetsim_halo_export.argtypes = [H, u32, fp]
     L.tetsim_halo_import.argtypes = [H, u32, fp]

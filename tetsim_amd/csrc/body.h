@@ -84,6 +84,14 @@ extern Rccl g_rccl;
 // was taken with -- a body re-probes before it replays its two-chain halo graphs whenever this changed since its last probe.
 extern std::atomic<uint64_t> g_stream_generation;
 
+// Peer-to-peer halo: where this rank's boundary predictions go at one neighbour -- its ghost run for this rank and the word that
+// says "arrived", per substep parity -- in the neighbour's memory (an IPC mapping, a pointer of the same process, or this rank's
+// own buffers in loopback measurements).
+struct PeerLink {
+    float4* ghost[2] = {nullptr, nullptr};
+    uint32_t* arrived[2] = {nullptr, nullptr};
+    void* ipc[3] = {nullptr, nullptr, nullptr};   // mappings to close (hipIpcCloseMemHandle)
+};
 struct NeighDev {
     int rank = -1;
     uint32_t send_count = 0, recv_start = 0, recv_count = 0;
@@ -170,6 +178,17 @@ struct tetsim_body {
     float dt_pred = 0.0f;
     ncclComm_t comm = nullptr;
     int comm_rank = -1, comm_size = 0;
+    // peer-to-peer halo (tetsim_halo_p2p_export / _connect): no transfer kernel -- the boundary-particle kernel stores into the
+    // neighbours' ghost ranges, double buffered by substep parity (pos_pred's tail | ghost_alt)
+    bool p2p = false;
+    uint32_t timeout_ms = 0;              // bound of the device-side waits of this body (TETSIM_HALO_TIMEOUT_MS when it was created / connected)
+    float4* ghost_alt = nullptr;          // [nv_local - nv_owned] the ghost buffer of odd substeps
+    uint32_t* d_arrived = nullptr;        // [2][kMaxPeers] words the neighbours raise here
+    uint32_t* d_peer_slots = nullptr;     // ELL [p2p_cols][p2p_stride]: where a boundary particle goes at which neighbour
+    uint32_t p2p_cols = 0, p2p_stride = 0;
+    std::vector<PeerLink> links;          // parallel to `neigh`
+    uint64_t p2p_round = 0;               // substeps enqueued since the connection; its parity selects the buffers
+    bool p2p_raise_pending = false;       // the last boundary-particle kernel's "arrived" has not been raised yet (no kernel behind it)
     bool halo_pending = false;            // a halo was started and nobody has waited for it yet
     std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
 
@@ -264,12 +283,13 @@ int create_halo_stream(tetsim_body* h);
 int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what);
 int halo_start(tetsim_body* h);
 int halo_wait(tetsim_body* h, hipStream_t on);
-uint32_t halo_timeout_ms();
+uint32_t halo_timeout_ms(const tetsim_body* h = nullptr);   // the body's bound, or the environment's
 bool has_transport(const tetsim_body* h);
 bool uses_flag_sync(const tetsim_body* h);
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev = nullptr);  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
 int flush_v(tetsim_body* h);                                    // flag path: the V hand-over that no following substep will carry
-int enqueue_phase_b(tetsim_body* h);                            // halo start
+int enqueue_phase_b(tetsim_body* h, bool refresh = false);      // halo start (peer-to-peer bodies: only for the refresh after a dt change)
+float4* ghost_buffer(tetsim_body* h, uint32_t parity);          // where ghost particle nv_owned + i of that substep parity lives (+ i)
 int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
 int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains
 void drop_flag_graphs(tetsim_body* h);                          // destroy the captured chains (queues turned out not to be independent)

@@ -78,6 +78,9 @@ struct PJBlk {
     const uint32_t* blk_maxsrc = nullptr;    // [nb] longest such list in the tile
     uint32_t ns_pad = 0;
     const DevParams* params = nullptr;
+    // peer-to-peer halo (tetsim_halo.hip): the neighbours store their boundary predictions straight into this rank's ghost range,
+    // double buffered by substep parity -- pos_pred's own tail on even substeps, ghost_alt on odd ones (pjb_tet_kernel_alt)
+    const float4* ghost_alt = nullptr;       // [nv_local - nv_owned]
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
@@ -146,7 +149,28 @@ struct PJSync {
     uint32_t* error = nullptr;
     uint32_t timeout_ms = 0;   // 0 = unbounded
 };
+// Peer-to-peer halo: what the boundary-particle kernel needs to store a boundary particle's new prediction straight into the
+// ghost ranges of the (<= kMaxPeers) neighbours that read it.  slots: ELL [cols][stride] per boundary particle, entry =
+// neighbour index << 24 | position in that neighbour's ghost run for this rank, 0xffffffff = none.
+constexpr uint32_t kMaxPeers = 8;
+struct PJPeer {
+    float4* ghost[kMaxPeers] = {};           // the neighbours' ghost runs for this rank, of the parity being written (peer memory)
+    const uint32_t* slots = nullptr;
+    uint32_t cols = 0, stride = 0, n = 0;   // n: neighbours in use
+};
+// ... and the hand-over around it: the wait kernel in front of the halo-side tiles raises `raise` words in the NEIGHBOURS' memory as
+// it starts ("my boundary predictions of the previous substep are in your ghost range": the kernel in front of it in the queue, the
+// boundary-particle kernel, is complete) and then waits for the words the neighbours raise HERE, clearing them.
+struct PJPeerSync {
+    uint32_t* raise[kMaxPeers] = {};         // peer memory
+    uint32_t* wait[kMaxPeers] = {};          // own memory
+    uint32_t n_raise = 0, n_wait = 0;
+    uint32_t delay_us = 0;                   // loopback measurements: pretend the data arrived this much later
+};
 void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await + clear
+void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w);   // y.flag may be null (nothing local to wait for)
+void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word);
+void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count);   // ghosts from d.ghost_alt
 void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: set
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);

@@ -111,7 +111,8 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 #endif
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
-template <bool kLean, bool kFused>
+// kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
+template <bool kLean, bool kFused, bool kAlt = false>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
@@ -197,6 +198,8 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             store_wt(d.fin_out, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
             store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
         }
+    } else if constexpr (kAlt) {
+        pos_stage = vid >= d.nv_owned ? d.ghost_alt[vid - d.nv_owned] : d.pos_pred[vid];
     } else {
         pos_stage = d.pos_pred[vid];
     }
@@ -301,6 +304,15 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_raise(P
                                                                             uint32_t tiles_per_xcd, uint32_t* sig TETSIM_DBG_PARAM) {
     raise(sig);
     pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+// ... reading the ghosts from the second buffer (peer-to-peer halo; halo-side tiles of odd substeps)
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                            uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                                          uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -554,7 +566,8 @@ __device__ __forceinline__ void await_done(const PJSync& y) {
 
 // 64-thread workgroups: 175,616 particles are only 2,744 waves (2.7 per SIMD); one-wave workgroups spread over the
 // 256 CUs evenly (10.7 per CU) where 256-thread ones leave some CUs with 3 and others with 2.
-__device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, uint32_t count) {
+template <bool kPeer = false>
+__device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, uint32_t count, const PJPeer* peer = nullptr) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = first + i;
@@ -581,12 +594,47 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
     store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
     store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
     store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+    if constexpr (kPeer) {
+        // peer-to-peer halo: the prediction also goes straight into the ghost range of every neighbour that reads this particle
+        // (write-through, system scope: peer memory over xGMI, or this device's own memory for partitions sharing a GPU).  The
+        // "it is there" word follows when the next kernel of this queue starts (pjb_wait_peers_kernel).
+        const uint32_t* col = peer->slots + v;
+        for (uint32_t c = 0; c < peer->cols; c++) {
+            const uint32_t e = col[static_cast<size_t>(c) * peer->stride];
+            for (uint32_t k = 0; k < peer->n; k++)   // (the store wants a wave-uniform base: one neighbour at a time, the others' lanes masked)
+                if (e != 0xffffffffu && (e >> 24) == k) store_wt(peer->ghost[k], e & 0xffffffu, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
 __global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t first, uint32_t count, uint32_t* sig) {
     raise(sig);
     pjb_vertex_body(d, first, count);
+}
+__global__ __launch_bounds__(64) void pjb_vertex_kernel_peer(PJBlk d, uint32_t first, uint32_t count, PJPeer peer, uint32_t* sig) {
+    if (sig) raise(sig);
+    pjb_vertex_body<true>(d, first, count, &peer);
+}
+// One wave in front of the halo-side tiles of a peer-to-peer body: (1) as it STARTS, the boundary-particle kernel in front of it
+// in this queue is complete, i.e. this rank's predictions are in the neighbours' ghost ranges -- tell them (one system-scope store
+// per neighbour, into THEIR memory); (2) wait for the local word (V: this rank's interior particles) if there is one; (3) wait for
+// the words the neighbours raise here, and clear them.  Words alternate by substep parity (the host passes the right pair): the
+// raise of substep s+2 lands on the word of substep s only after its consumer has cleared it -- the dependency cycle orders
+// them -- whereas ONE word per neighbour could see two raises before a wait (s+1's while this wave still waits for V).
+__global__ void pjb_wait_peers_kernel(PJSync y, PJPeerSync w) {
+    const uint32_t t = threadIdx.x;
+    if (t < w.n_raise) __hip_atomic_store(w.raise[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (y.flag) await_done(y);
+    if (t < w.n_wait) {
+        const long long t0 = wall_clock64(), limit = 100000ll * y.timeout_ms;
+        while (__hip_atomic_load(w.wait[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (limit && wall_clock64() - t0 > limit) { __hip_atomic_store(y.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        __hip_atomic_store(w.wait[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (w.delay_us) { const long long d0 = wall_clock64(); while (wall_clock64() - d0 < 100ll * w.delay_us) __builtin_amdgcn_s_sleep(8); }
+    }
 }
 __global__ void pjb_wait_kernel(PJSync y) { await_done(y); }
 __global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
@@ -670,6 +718,17 @@ uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks) {
         for (uint32_t j = 0; j < i; j++) if (out[i] == out[j]) return 0;          // the first eight blocks: eight different XCDs
     for (uint32_t i = 8u; i < blocks; i++) if (out[i] != out[i & 7u]) return 0;    // ... and the pattern repeats
     return 8;
+}
+void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w) { hipLaunchKernelGGL(pjb_wait_peers_kernel, dim3(1), dim3(64), 0, s, y, w); }
+void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(pjb_vertex_kernel_peer, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, peer, raise_word);
+}
+void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count) {
+    if (tile_count == 0) return;
+    const uint32_t per_xcd = (tile_count + 7u) / 8u;
+    auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_alt : pjb_tet_kernel_alt;
+    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }

@@ -86,6 +86,9 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
     if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
+    // every call gets a fresh block of sequence numbers for the partial sums of the frame kernel (DevParams::epoch + the substep's
+    // index inside the call): stale sums of an earlier call never match
+    h->frame_epoch += 65536u;
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
@@ -189,6 +192,9 @@ int ensure_prediction(tetsim_body* h, double dt) {
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return 0;
     const float fdt = static_cast<float>(dt);
     if (!h->pred_any_dt && fdt != h->dt_pred) {
+        if (h->p2p && !h->comm && h->group.empty())
+            return fail(h, TETSIM_ESTATE, "dt changed between calls on a body whose only transport is the peer-to-peer halo: nothing refreshes the neighbours' ghost "
+                                          "predictions (keep dt fixed, or connect on top of an RCCL communicator, which carries the refresh exchange)");
         if (h->partitioned && !h->neigh.empty() && !has_transport(h))
             return fail(h, TETSIM_ESTATE, "dt changed between substeps on a partitioned body without a transport (ghost predictions would be stale): "
                                           "exchange halos through tetsim_comm_init / tetsim_group_step_n, or keep dt fixed");
@@ -211,12 +217,12 @@ int ensure_prediction(tetsim_body* h, double dt) {
                 // not consumed yet, and the two would collapse into one.  Between two uses of this word lies at least one whole
                 // substep, whose G hand-over orders them.)
                 PJSync y;
-                y.flag = h->d_sync + 3; y.error = h->d_sync + 4; y.timeout_ms = halo_timeout_ms();
+                y.flag = h->d_sync + 3; y.error = h->d_sync + 4; y.timeout_ms = halo_timeout_ms(h);
                 pjb_launch_signal(h->stream, y);
                 pjb_launch_wait(h->comm_stream, y);
             }
             if (h->comm) {
-                int rc = enqueue_phase_b(h);
+                int rc = enqueue_phase_b(h, true);
                 if (rc) return rc;
             } else h->needs_halo_refresh = true;
         }
@@ -238,7 +244,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
     if (h->frame) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
-        pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms());
+        pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else
@@ -363,6 +369,7 @@ int create_common(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     if (o.tet_colour && nt) h->tet_colour.assign(o.tet_colour, o.tet_colour + nt);
     h->opt.tet_colour = nullptr;
     h->fast = o.precision == TETSIM_FAST;
+    h->timeout_ms = halo_timeout_ms(nullptr);
     h->info.num_particles = nv;
     h->info.num_elems = nt;
     h->info.solver = o.solver; h->info.precision = o.precision; h->info.order = o.order; h->info.device = o.device; h->info.flags = o.flags;
@@ -453,6 +460,7 @@ void tetsim_destroy(tetsim_handle h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
     drop_flag_graphs(h);
+    for (PeerLink& l : h->links) for (void* m : l.ipc) if (m) (void)hipIpcCloseMemHandle(m);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -500,7 +508,8 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
         // critical path.  TETSIM_HALO_GRAPH=0 keeps everything eager.
         static const bool use_graph = [] { const char* e = getenv("TETSIM_HALO_GRAPH"); return !(e && e[0] == '0'); }();
-        if (h->comm && use_graph && h->halo_warm && !h->halo_graph_broken && uses_flag_sync(h)) {
+        const bool own_rank = h->group.empty() && (h->comm || h->p2p);   // one rank per process: RCCL and / or the peer-to-peer halo
+        if (own_rank && use_graph && h->halo_warm && !h->halo_graph_broken && uses_flag_sync(h)) {
             // flag path: the two streams' chains as two captured linear graphs, replayed side by side -- if the streams are served
             // by independent hardware queues (probed once) and the chains can be captured (else: eager for good, loudly)
             if ((rc = probe_queue_independence(h))) return rc;
@@ -513,7 +522,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
                 rc = 0;
             }
         }
-        if (!h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {
+        if (!own_rank || !h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {
             for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
             if (!rc) rc = flush_v(h);
             h->halo_warm = true;
@@ -541,7 +550,6 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         it = h->graphs.emplace(n, exec).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
-    if (h->frame) h->frame_epoch += n;   // the next call's sequence numbers (fill_params): stale partial sums never match
     return 0;
 }
 

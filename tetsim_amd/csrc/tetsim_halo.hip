@@ -1,6 +1,8 @@
 // tetsim_halo.hip -- multi-GPU: the per-substep halo of partitioned POLAR_JACOBI bodies and its C ABI.
 #include "body.h"
 
+#include <unistd.h>
+
 using namespace tetsim;
 
 namespace tetsim {
@@ -20,6 +22,11 @@ int create_halo_stream(tetsim_body* h) {
     return dev_alloc(h, &h->d_params_halo, 1);
 }
 
+// Ghost particle nv_owned + i of a substep with that parity: pos_pred's own tail, or -- peer-to-peer bodies, odd substeps -- the
+// second ghost buffer.
+float4* ghost_buffer(tetsim_body* h, uint32_t parity) {
+    return (h->p2p && (parity & 1u)) ? h->ghost_alt : h->pj.pos_pred + h->pj.nv_owned;
+}
 int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
     return fail(h, TETSIM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
 }
@@ -49,7 +56,7 @@ int halo_start(tetsim_body* h) {
     static const bool lb_copy = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_COPY"); return e && e[0] == '1'; }();
     if (h->comm && h->loopback && lb_copy) {  // measurement only: the loopback transfer as a plain copy kernel instead of RCCL
         for (auto& nb : h->neigh)
-            if (nb.send_count) util_launch_copy(h->comm_stream, nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf, h->pj.pos_pred + nb.recv_start, nb.send_count);
+            if (nb.send_count) util_launch_copy(h->comm_stream, nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf, ghost_buffer(h, static_cast<uint32_t>(h->p2p_round)) + (nb.recv_start - h->pj.nv_owned), nb.send_count);
     } else if (h->comm) {
         ncclResult_t r = g_rccl.GroupStart();
         if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
@@ -62,7 +69,7 @@ int halo_start(tetsim_body* h) {
             if (nb.recv_count) {
                 // posted on OUR halo stream, i.e. after our boundary pass of this substep: the ghosts are overwritten only
                 // once this partition's tet kernels (which read them) are done
-                r = g_rccl.Recv(h->pj.pos_pred + nb.recv_start, 4ull * nb.recv_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
+                r = g_rccl.Recv(ghost_buffer(h, static_cast<uint32_t>(h->p2p_round)) + (nb.recv_start - h->pj.nv_owned), 4ull * nb.recv_count, ncclFloat, h->loopback ? h->comm_rank : nb.rank, h->comm, h->comm_stream);
                 if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
             }
         }
@@ -77,7 +84,7 @@ int halo_start(tetsim_body* h) {
             if (!back || back->recv_count != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan");
             { HP("comm wait dst boundary"); HIPCHK(h, hipStreamWaitEvent(h->comm_stream, dst->ev_boundary2[p], 0)); }  // receiver finished reading its ghosts
             const float4* from = nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf;
-            { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(dst->pj.pos_pred + back->recv_start, from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
+            { HP("memcpyAsync d2d"); HIPCHK(h, hipMemcpyAsync(ghost_buffer(dst, static_cast<uint32_t>(dst->p2p_round)) + (back->recv_start - dst->pj.nv_owned), from, nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, h->comm_stream)); }
         }
     }
     if (h->loopback) {   // measurement only: how much wire latency the choreography hides (tools/loopback_rank.py)
@@ -94,7 +101,7 @@ int halo_wait(tetsim_body* h, hipStream_t on) {
     const uint32_t p = h->halo_parity ^ 1u;  // the previous substep's parity
     // our own transfers (RCCL: includes our receives); implied by stream order when the consumer runs on the halo stream
     if (on != h->comm_stream) { HP("wait own sent"); HIPCHK(h, hipStreamWaitEvent(on, h->ev_sent2[p], 0)); }
-    if (!h->comm)
+    if (!h->comm && !h->group.empty())
         for (auto& nb : h->neigh)
             if (nb.recv_count) { HP("wait peer sent"); HIPCHK(h, hipStreamWaitEvent(on, h->group[nb.rank]->ev_sent2[p], 0)); }
     h->halo_pending = false;
@@ -102,11 +109,13 @@ int halo_wait(tetsim_body* h, hipStream_t on) {
 }
 // Bound of the device-side waits of the flag path.  `wait G` sits behind a transfer, i.e. behind the PEER's progress: a rank
 // that steps this much later than its neighbour is reported as TETSIM_ECOMM at the next synchronisation.  0 = wait for ever.
-uint32_t halo_timeout_ms() {
-    static const uint32_t ms = [] { const char* e = getenv("TETSIM_HALO_TIMEOUT_MS"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 30000u; }();
-    return ms;
+uint32_t halo_timeout_ms(const tetsim_body* h) {
+    if (h && h->timeout_ms) return h->timeout_ms;
+    const char* e = getenv("TETSIM_HALO_TIMEOUT_MS");   // (read when a body is created / connected, not per call)
+    return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 30000u;
 }
-bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty()); }
+// (a connected peer-to-peer halo is a transport of its own: ranks in different processes need no RCCL communicator for it)
+bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty() || h->p2p); }
 // blocked bodies with a transport and halo-side tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
 bool uses_flag_sync(const tetsim_body* h) {
     static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();
@@ -150,7 +159,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             }
             h->flag_sync = true;
             PJSync yg, yv;   // word 0: "the H tiles of this substep are done"; word 2: "the interior particles of this substep are done"
-            yg.flag = h->d_sync + 0; yg.error = h->d_sync + 4; yg.timeout_ms = halo_timeout_ms();
+            yg.flag = h->d_sync + 0; yg.error = h->d_sync + 4; yg.timeout_ms = halo_timeout_ms(h);
             yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = yg.timeout_ms;
             const uint32_t nvb = h->pj.nv_boundary;
             int rc;
@@ -159,10 +168,52 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             else if ((rc = flush_v(h))) return rc;
             { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr,
                                                        v_open && h->blk.nb_interior ? yv.flag : nullptr); }
-            if (v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
-            if ((rc = halo_wait(h, h->comm_stream))) return rc;   // in-process groups: the neighbours' transfers of the previous substep (events)
             PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
             if (h->d_params_halo) kb.params = h->d_params_halo;
+            if (h->p2p) {
+                // Peer-to-peer halo: no transfer.  Substep r reads its ghosts from buffer r & 1, which the neighbours' boundary-particle
+                // kernels of substep r - 1 filled; this rank's boundary-particle kernel fills THEIR buffers (r + 1) & 1.  One wave in
+                // front of the halo-side tiles does all the hand-overs of the queue: it raises the neighbours' "arrived" words of
+                // parity r & 1 as it starts (the kernel in front of it is this rank's boundary-particle kernel of r - 1), waits for V
+                // (this rank's interior particles) and for the neighbours' words here.
+                const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
+                PJPeerSync w;
+                if (h->p2p_raise_pending) for (const PeerLink& l : h->links) if (l.arrived[par]) w.raise[w.n_raise++] = l.arrived[par];
+                h->p2p_raise_pending = false;
+                if (h->p2p_round > 0)
+                    for (size_t i = 0; i < h->neigh.size(); i++) if (h->neigh[i].recv_count) w.wait[w.n_wait++] = h->d_arrived + par * kMaxPeers + i;
+                if (h->loopback) { static const uint32_t delay_us = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_DELAY_US"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 0u; }(); w.delay_us = delay_us; }
+                PJSync yw = yv;
+                if (!(v_open && h->blk.nb_interior)) yw.flag = nullptr;
+                if (yw.flag || w.n_raise || w.n_wait) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
+                if ((rc = halo_wait(h, h->comm_stream))) return rc;   // (a refresh exchange after a dt change, in-process groups)
+                kb.ghost_alt = h->ghost_alt;
+                PJPeer pr;
+                pr.slots = h->d_peer_slots; pr.cols = h->p2p_cols; pr.stride = h->p2p_stride; pr.n = static_cast<uint32_t>(h->links.size());
+                for (size_t i = 0; i < h->links.size(); i++) pr.ghost[i] = h->links[i].ghost[par ^ 1u];
+                { HP("launch tet halo-side"); if (par) pjb_launch_tet_alt(h->comm_stream, kb, h->blk.nb_interior, nbnd); else pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
+                if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+                else { HP("launch vertex boundary"); pjb_launch_vertex_peer(h->comm_stream, kb, 0, nvb, pr, yg.flag); h->p2p_raise_pending = true; }
+                if (h->p2p_raise_pending && !h->group.empty()) {
+                    // partitions of ONE process may share hardware queues: a wait of one body must never be submitted in front of the
+                    // kernel of another body that raises its word.  Here the raise gets a kernel of its own right behind the
+                    // boundary particles (all bodies finish a substep's submission before any starts the next: tetsim_group_step_n);
+                    // one rank per process folds it into the next substep's wait kernel, whose peers live on other devices' queues.
+                    PJPeerSync sg;
+                    for (const PeerLink& l : h->links) if (l.arrived[par ^ 1u]) sg.raise[sg.n_raise++] = l.arrived[par ^ 1u];
+                    PJSync none;
+                    none.error = yg.error;
+                    { HP("raise peers"); pjb_launch_wait_peers(h->comm_stream, none, sg); }
+                    h->p2p_raise_pending = false;
+                }
+                h->p2p_round++;
+                { HP("wait G"); pjb_launch_wait(h->stream, yg); }
+                { HP("launch vertex interior"); pj_vertex(h, nvb, h->pj.nv_owned - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+                h->v_pending = true;
+                return 0;
+            }
+            if (v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            if ((rc = halo_wait(h, h->comm_stream))) return rc;   // in-process groups: the neighbours' transfers of the previous substep (events)
             { HP("launch tet halo-side"); pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
             if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
             if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
@@ -209,16 +260,24 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
     return 0;
 }
 int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of its own: signal on the main queue, wait on the halo queue
-    if (!h->v_pending) return 0;
+    if (!h->v_pending && !h->p2p_raise_pending) return 0;
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     PJSync yv;
-    yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms();
-    { HP("signal V"); pjb_launch_signal(h->stream, yv); }
-    { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+    yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms(h);
+    if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv); }
+    if (h->p2p) {   // ... and the "arrived" words of the last boundary-particle kernel, which no following substep's wait will raise
+        PJPeerSync w;
+        const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
+        if (h->p2p_raise_pending) for (const PeerLink& l : h->links) if (l.arrived[par]) w.raise[w.n_raise++] = l.arrived[par];
+        if (!h->v_pending) yv.flag = nullptr;
+        { HP("wait V + raise peers"); pjb_launch_wait_peers(h->comm_stream, yv, w); }
+        h->p2p_raise_pending = false;
+    } else { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
     h->v_pending = false;
     return 0;
 }
-int enqueue_phase_b(tetsim_body* h) {  // halo start
+int enqueue_phase_b(tetsim_body* h, bool refresh) {  // halo start
+    if (h->p2p && !refresh) return 0;   // peer-to-peer bodies: the boundary-particle kernel has stored the halo already
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = halo_start(h);
     if (rc) return rc;
@@ -270,7 +329,9 @@ int probe_queue_independence(tetsim_body* h) {
 // binary-semaphore words, whose kernels take constant arguments.  Inside a chain a kernel boundary costs 1.6 us instead of the
 // 2.7 us of an eager launch, and the host enqueues two graph launches per call instead of 9 operations per substep.
 int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
-    auto it = h->flag_graphs.find(n);
+    // (peer-to-peer bodies: the chain of a call depends on the parity of its first substep -- which ghost buffer, which words)
+    const uint32_t key = n | (h->p2p && (h->p2p_round & 1u) ? 0x80000000u : 0u);
+    auto it = h->flag_graphs.find(key);
     if (it == h->flag_graphs.end()) {
         hipGraph_t gm = nullptr, gh = nullptr;
         hipGraphExec_t em = nullptr, eh = nullptr;
@@ -291,8 +352,10 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
         if (gm) (void)hipGraphDestroy(gm);
         if (gh) (void)hipGraphDestroy(gh);
         if (rc) { if (em) (void)hipGraphExecDestroy(em); if (eh) (void)hipGraphExecDestroy(eh); return rc; }
-        it = h->flag_graphs.emplace(n, std::make_pair(em, eh)).first;
+        it = h->flag_graphs.emplace(key, std::make_pair(em, eh)).first;
+        if (h->p2p) h->p2p_round -= n;   // (the capture advanced the counter; the replay below is what runs)
     }
+    if (h->p2p) h->p2p_round += n;
     HIPCHK(h, hipGraphLaunch(it->second.second, h->comm_stream));
     HIPCHK(h, hipGraphLaunch(it->second.first, h->stream));
     h->halo_pending = true;
@@ -383,6 +446,7 @@ int tetsim_comm_info(tetsim_handle h, TetSimCommInfo* out) {
         out->max_message_bytes = std::max<uint64_t>(out->max_message_bytes, 16ull * std::max(nb.send_count, nb.recv_count));
     }
     out->loopback = h->loopback ? 1 : 0;
+    out->p2p = h->p2p ? 1 : 0;
     return 0;
 }
 
@@ -524,6 +588,134 @@ int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
     return 0;
 }
 
+// ---- peer-to-peer halo ---------------------------------------------------------------------------------------------------
+namespace {
+struct P2PBlob {   // what a rank tells the others about its buffers (TETSIM_P2P_BLOB_BYTES)
+    uint32_t magic, rank, part_count, device;
+    uint64_t pid;
+    uint32_t nv_owned, nv_local, n_neigh, pad;
+    hipIpcMemHandle_t h_pred, h_alt, h_arrived;                 // IPC handles of pos_pred / ghost_alt / the "arrived" words
+    uint64_t p_pred, p_alt, p_arrived;                          // ... and the plain pointers (ranks of the same process)
+    struct { int32_t rank; uint32_t recv_start, recv_count; } neigh[kMaxPeers];
+};
+static_assert(sizeof(P2PBlob) <= TETSIM_P2P_BLOB_BYTES, "blob too large");
+constexpr uint32_t kP2PMagic = 0x50325054u;
+}  // namespace
+
+int tetsim_halo_p2p_export(tetsim_handle h, void* blob) {
+    if (!h || !blob) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->partitioned || !h->blocked || h->blk.nb == h->blk.nb_interior)
+        return fail(h, TETSIM_ESTATE, "the peer-to-peer halo needs a partitioned POLAR_JACOBI body in the blocked FAST formulation with halo-side tiles");
+    if (h->neigh.size() > kMaxPeers) return fail(h, TETSIM_ESTATE, "the peer-to-peer halo supports at most 8 neighbours per partition");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
+    if (!h->ghost_alt) {
+        int rc;
+        if ((rc = dev_alloc(h, &h->ghost_alt, ng))) return rc;
+        if ((rc = dev_alloc(h, &h->d_arrived, 2 * kMaxPeers))) return rc;
+        HIPCHK(h, hipMemset(h->d_arrived, 0, 2 * kMaxPeers * sizeof(uint32_t)));
+        // where each boundary particle goes: (neighbour, position in that neighbour's ghost run for this rank), ELL by particle
+        const uint32_t nvb = h->pj.nv_boundary;
+        std::vector<std::vector<uint32_t>> per(nvb);
+        for (size_t k = 0; k < h->neigh.size(); k++)
+            for (size_t j = 0; j < h->neigh[k].send_local.size(); j++) {
+                const uint32_t api = static_cast<uint32_t>(h->neigh[k].send_local[j]);
+                const uint32_t dv = h->api2dev.empty() ? api : h->api2dev[api];
+                if (dv >= nvb) return fail(h, TETSIM_ESTATE, "internal error: a sent particle is not a boundary particle");
+                per[dv].push_back((static_cast<uint32_t>(k) << 24) | static_cast<uint32_t>(j));
+            }
+        uint32_t cols = 1;
+        for (auto& v : per) cols = std::max<uint32_t>(cols, static_cast<uint32_t>(v.size()));
+        h->p2p_cols = cols; h->p2p_stride = std::max(nvb, 1u);
+        std::vector<uint32_t> ell(static_cast<size_t>(cols) * h->p2p_stride, 0xffffffffu);
+        for (uint32_t v = 0; v < nvb; v++) for (size_t c = 0; c < per[v].size(); c++) ell[c * h->p2p_stride + v] = per[v][c];
+        if ((rc = dev_alloc(h, &h->d_peer_slots, ell.size()))) return rc;
+        if ((rc = upload(h, h->d_peer_slots, ell))) return rc;
+    }
+    P2PBlob b;
+    std::memset(&b, 0, sizeof b);
+    b.magic = kP2PMagic; b.rank = static_cast<uint32_t>(h->opt.part_index); b.part_count = static_cast<uint32_t>(h->opt.part_count);
+    b.device = static_cast<uint32_t>(h->opt.device); b.pid = static_cast<uint64_t>(getpid());
+    b.nv_owned = nvo; b.nv_local = h->pj.nv_local; b.n_neigh = static_cast<uint32_t>(h->neigh.size());
+    b.p_pred = reinterpret_cast<uint64_t>(h->pj.pos_pred); b.p_alt = reinterpret_cast<uint64_t>(h->ghost_alt); b.p_arrived = reinterpret_cast<uint64_t>(h->d_arrived);
+    // (a handle can only be opened by ANOTHER process; failing to make one is not an error for ranks of one process)
+    (void)hipIpcGetMemHandle(&b.h_pred, h->pj.pos_pred);
+    (void)hipIpcGetMemHandle(&b.h_alt, h->ghost_alt);
+    (void)hipIpcGetMemHandle(&b.h_arrived, h->d_arrived);
+    (void)hipGetLastError();
+    for (size_t k = 0; k < h->neigh.size(); k++) { b.neigh[k].rank = h->neigh[k].rank; b.neigh[k].recv_start = h->neigh[k].recv_start; b.neigh[k].recv_count = h->neigh[k].recv_count; }
+    std::memset(blob, 0, TETSIM_P2P_BLOB_BYTES);
+    std::memcpy(blob, &b, sizeof b);
+    return 0;
+}
+
+int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) {
+    if (!h || !blobs) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->ghost_alt) return fail(h, TETSIM_ESTATE, "call tetsim_halo_p2p_export first");
+    // Transports it can follow: RCCL (connect after tetsim_comm_init; RCCL keeps carrying the refresh after a dt change), an
+    // in-process group (after its first tetsim_group_step_n), or none at all -- ranks in different processes that exchange the
+    // blobs themselves; such a body cannot change dt between calls (nothing would refresh the ghosts).
+    {
+        const char* sy = getenv("TETSIM_HALO_SYNC");
+        const char* os = getenv("TETSIM_DEBUG_ONE_STREAM");
+        if ((sy && sy[0] == 'e') || (os && os[0] == '1')) return fail(h, TETSIM_ESTATE, "the peer-to-peer halo rides on the two-queue flag path (TETSIM_HALO_SYNC=events / TETSIM_DEBUG_ONE_STREAM exclude it)");
+    }
+    if (!h->comm_stream) { int rc = create_halo_stream(h); if (rc) return rc; }
+    h->timeout_ms = 0;
+    h->timeout_ms = halo_timeout_ms(h);
+    if (!(h->loopback && count == 1) && count != static_cast<uint32_t>(h->opt.part_count)) return fail(h, TETSIM_EINVAL, "one blob per partition, in rank order");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
+    // both ghost buffers start from the ghosts as they are now (the last exchange of the previous transport, or the rest pose)
+    if (ng) HIPCHK(h, hipMemcpy(h->ghost_alt, h->pj.pos_pred + nvo, ng * sizeof(float4), hipMemcpyDeviceToDevice));
+    HIPCHK(h, hipMemset(h->d_arrived, 0, 2 * kMaxPeers * sizeof(uint32_t)));
+    const char* all = static_cast<const char*>(blobs);
+    std::vector<PeerLink> links(h->neigh.size());
+    for (size_t k = 0; k < h->neigh.size(); k++) {
+        const NeighDev& nb = h->neigh[k];
+        P2PBlob pb;
+        std::memcpy(&pb, all + static_cast<size_t>(h->loopback ? 0 : nb.rank) * TETSIM_P2P_BLOB_BYTES, sizeof pb);
+        if (pb.magic != kP2PMagic || (!h->loopback && static_cast<int>(pb.rank) != nb.rank)) return fail(h, TETSIM_EINVAL, "bad peer blob for rank " + std::to_string(nb.rank));
+        if (!nb.send_count) continue;
+        // this rank's run in the neighbour's ghost range, and this rank's slot among the neighbour's neighbours
+        uint32_t start = 0, cnt = 0, slot = kMaxPeers;
+        if (h->loopback) { start = nb.recv_start; cnt = nb.recv_count; slot = static_cast<uint32_t>(k); }
+        else
+            for (uint32_t j = 0; j < pb.n_neigh && j < kMaxPeers; j++)
+                if (pb.neigh[j].rank == h->opt.part_index) { start = pb.neigh[j].recv_start; cnt = pb.neigh[j].recv_count; slot = j; }
+        if (slot == kMaxPeers || cnt != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan between ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank));
+        float4 *pred = nullptr, *alt = nullptr;
+        uint32_t* arr = nullptr;
+        if (pb.pid == static_cast<uint64_t>(getpid())) {   // same process: plain pointers (peer access if the devices differ)
+            pred = reinterpret_cast<float4*>(pb.p_pred); alt = reinterpret_cast<float4*>(pb.p_alt); arr = reinterpret_cast<uint32_t*>(pb.p_arrived);
+            if (static_cast<int>(pb.device) != h->opt.device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(static_cast<int>(pb.device), 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(h, TETSIM_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        } else {
+            PeerLink& l = links[k];
+            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[0], pb.h_pred, hipIpcMemLazyEnablePeerAccess));
+            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[1], pb.h_alt, hipIpcMemLazyEnablePeerAccess));
+            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[2], pb.h_arrived, hipIpcMemLazyEnablePeerAccess));
+            pred = static_cast<float4*>(l.ipc[0]); alt = static_cast<float4*>(l.ipc[1]); arr = static_cast<uint32_t*>(l.ipc[2]);
+        }
+        links[k].ghost[0] = pred + start;                       // even substeps read pos_pred's tail
+        links[k].ghost[1] = alt + (start - pb.nv_owned);        // odd ones the second buffer
+        links[k].arrived[0] = arr + slot;
+        links[k].arrived[1] = arr + kMaxPeers + slot;
+    }
+    h->links = std::move(links);
+    h->p2p = true;
+    h->p2p_round = 0;
+    h->p2p_raise_pending = false;
+    h->halo_warm = false;     // the first call after the connection runs eagerly (its first substep has no "arrived" to wait for)
+    drop_flag_graphs(h);
+    return 0;
+}
+
 int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
     if (!hs || count == 0) return TETSIM_EINVAL;
     for (uint32_t i = 0; i < count; i++) {
@@ -551,7 +743,7 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
             // "my ghosts may be overwritten": flag bodies record it on the halo stream, which ensure_prediction put behind the re-prediction
             HIPCHK(hs[i], hipEventRecord(hs[i]->ev_boundary2[hs[i]->halo_parity], hs[i]->flag_sync ? hs[i]->comm_stream : hs[i]->stream));
         }
-        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
+        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i], true); if (rc) return rc; }
     }
     static const bool dbg_sync = getenv("TETSIM_DEBUG_GROUP_SYNC") != nullptr;  // development: serialise every phase
     for (uint32_t s = 0; s < n; s++) {

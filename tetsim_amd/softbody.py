@@ -396,7 +396,7 @@ def comm_info(body):
     capi.check(capi.lib().tetsim_comm_info(body._h, C.byref(ci)), body._h)
     return {"rccl_ranks": ci.rccl_ranks, "rccl_rank": ci.rccl_rank, "neighbours": ci.neighbours,
             "send_bytes_per_substep": ci.send_bytes_per_substep, "recv_bytes_per_substep": ci.recv_bytes_per_substep,
-            "max_message_bytes": ci.max_message_bytes, "loopback": bool(ci.loopback)}
+            "max_message_bytes": ci.max_message_bytes, "loopback": bool(ci.loopback), "p2p": bool(ci.p2p)}
 
 
 def comm_selftest(body):
@@ -413,6 +413,32 @@ def group_step_n(bodies, n, dt, physicsParams):
     """n substeps of every partition of one decomposition (same choreography as the RCCL path, in-process copies)."""
     arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
     capi.check(capi.lib().tetsim_group_step_n(arr, len(bodies), int(n), float(dt), C.byref(make_params(physicsParams))))
+
+
+P2P_BLOB_BYTES = 512
+
+
+def p2p_export(body):
+    """This partition's buffers for the peer-to-peer halo (include/tetsim.h: tetsim_halo_p2p_export): TETSIM_P2P_BLOB_BYTES bytes
+    that the host hands to every other rank."""
+    buf = (C.c_char * P2P_BLOB_BYTES)()
+    capi.check(capi.lib().tetsim_halo_p2p_export(body._h, buf), body._h)
+    return bytes(buf.raw)
+
+
+def p2p_connect(body, blobs):
+    """blobs: one per partition, in rank order (a loopback body: its own, alone).  From the next step on the boundary-particle kernel
+    stores the halo straight into the neighbours' ghost ranges; every rank must have connected before any of them steps."""
+    raw = b"".join(bytes(b) for b in blobs)
+    assert len(raw) == P2P_BLOB_BYTES * len(blobs)
+    capi.check(capi.lib().tetsim_halo_p2p_connect(body._h, raw, len(blobs)), body._h)
+
+
+def group_p2p_connect(bodies):
+    """All partitions of one decomposition living in this process: switch their halo to peer-to-peer stores."""
+    blobs = [p2p_export(b) for b in bodies]
+    for b in bodies:
+        p2p_connect(b, blobs)
 
 
 def halo_exchange_local(bodies):
