@@ -368,10 +368,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
                   uint32_t nv_boundary) {
     BlockPlan& B = *out;
     B = BlockPlan();
-    constexpr uint32_t kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
-    // (development A/B, profiles/r03_tet_kernel_ab.txt: TETSIM_DEBUG_TILE_TETS caps the tets of a tile below the workgroup size, i.e.
-    // changes the number of tiles and with it how many "rounds" of workgroups a launch is)
-    static const uint32_t kMaxTets = [] { const char* e = getenv("TETSIM_DEBUG_TILE_TETS"); const uint32_t v = e ? static_cast<uint32_t>(atoi(e)) : 0u; return v >= 32u && v <= kBlockTile ? v : kBlockTile; }();
+    constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
     const uint32_t one_t[2] = {0u, nt}, one_v[2] = {0u, nv};
     if (!body_first_tet || !body_first_vert || bodies == 0) { body_first_tet = one_t; body_first_vert = one_v; bodies = 1; }
     // 1. Morton order of rest centroids (quantised to 10 bits per axis over the body's bounding box), body after body

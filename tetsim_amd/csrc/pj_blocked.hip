@@ -667,34 +667,9 @@ static uint32_t tet_mode() {
 #else
 #define TETSIM_DBG_LAUNCH
 #endif
-#ifdef TETSIM_ABLATION
-// Development (profiles/r03_tet_kernel_ab.txt, "heterogeneous first round"): TETSIM_DEBUG_PREFETCH_ROUND=<k> launches, in front of the tet
-// kernel, one workgroup per EVERY k-th tile of the first round of each XCD (the first 256 tiles an XCD is handed) that reads the tile's
-// streamed record -- rest shape, quaternion, tables -- and throws it away: the lines are then in THAT XCD's L2 when the tile's own
-// workgroup asks for them, so that a part of the first round starts solving while the rest still waits for memory.
-__global__ __launch_bounds__(kTile) void pjb_prefetch_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t every) {
-    const uint32_t x = blockIdx.x & 7u, j = (blockIdx.x >> 3) * every;
-    const uint32_t rel = x * tiles_per_xcd + j;
-    if (j >= 256u || j >= tiles_per_xcd || rel >= tile_count) return;
-    const uint32_t b = tile_first + rel, tid = threadIdx.x;
-    const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
-    const uint32_t e = t0 + (tid < ntb ? tid : 0u);
-    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e], q = d.quat[e];
-    const float V = d.vol[e];
-    const uint2 en = d.lc_ent[e];
-    const uchar4 li = d.tet_lidx[e];
-    asm volatile("" ::"v"(ra.x), "v"(rb.x), "v"(rc.x), "v"(q.x), "v"(V), "v"(en.x), "v"(static_cast<uint32_t>(li.x)));
-}
-#endif
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
     if (tile_count == 0) return;   // (callers with a word to raise check this themselves)
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-#ifdef TETSIM_ABLATION
-    {
-        static const uint32_t every = [] { const char* e = getenv("TETSIM_DEBUG_PREFETCH_ROUND"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
-        if (every) hipLaunchKernelGGL(pjb_prefetch_kernel, dim3(8u * ((256u + every - 1u) / every)), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, every);
-    }
-#endif
     if (raise_word) {
         auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_raise : pjb_tet_kernel_raise;
         if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, raise_word TETSIM_DBG_LAUNCH);
