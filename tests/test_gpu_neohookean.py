@@ -149,18 +149,33 @@ def test_fast_tolerance_vs_reference_goldens(golden):
             within("neo-hookean fast dragon vs reference golden @%d" % step, np.abs(body.pos - ref).max(), tol[step])
 
 
+@pytest.mark.parametrize("precision", ["precise", "fast"])
 @pytest.mark.parametrize("order", ["coloured", "clustered"])
-def test_graph_equals_eager(order):
-    v, t = make_lattice(5, y0=0.1)
-    pp = dict(density=1000.0)
-    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order)
-    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order)
+def test_graph_equals_eager(order, precision):
+    """tetsim_step_n fuses the particle pass that ends a substep with the prediction that starts the next; clustered schedules fold
+    it into the sweep itself -- the lane of the first cluster to touch a particle does it while loading the particle
+    (nh_kernels.inc: fold_particle), particles no cluster touches keep a small pass of their own.  Same operations per particle:
+    n substeps in one call equal n tetsim_step calls bit for bit, in both arithmetics, with floor contact, a grab, and two
+    particles that belong to no tet."""
+    v, t = make_lattice(5, y0=0.01)
+    v = np.vstack([v, np.float32([[0.3, 0.02, 0.2], [-0.4, 1.5, 0.1]])])      # two loose particles: free fall, one hits the floor
+    pp = dict(density=1000.0, friction=100.0)
+    a = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order, precision=precision)
+    b = SoftBodyHIP(v, t, None, pp, solver="neohookean", order=order, precision=precision)
     dt = 1.0 / 600
-    for _ in range(3):
-        a.simulateSubsteps(7, dt, pp)
-        for _ in range(7):
+    for k, n in enumerate((7, 1, 12, 2)):
+        if k == 1:
+            for body in (a, b):
+                body.setGrab(40, [0.2, 0.8, -0.1])
+        if k == 3:
+            for body in (a, b):
+                body.endGrab()
+        a.simulateSubsteps(n, dt, pp)
+        for _ in range(n):
             b.simulate(dt, pp)
-    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+        assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32)), (k, n)
+        assert np.array_equal(a.vel.view(np.uint32), b.vel.view(np.uint32)) and np.array_equal(a.prevPos.view(np.uint32), b.prevPos.view(np.uint32))
+    assert a.pos[:, 1].min() == 0.0 and a.pos[-2, 1] < 0.02
 
 
 def test_repeated_vertex_is_rejected():

@@ -203,6 +203,12 @@ struct tetsim_body {
     NHDev nh;
     std::vector<NHClusterLaunch> cluster_launch;  // TETSIM_ORDER_CLUSTERED: one per cluster colour
     int32_t* d_slot_vid = nullptr;
+    // clustered schedule: the particle pass between two substeps of a run is folded into the sweep's first touchers
+    // (NHClusterLaunch::first_mask); nh_untouched lists the particles no cluster touches, which keep a (tiny) pass of their own
+    bool nh_fold = false;
+    uint8_t* d_first_mask = nullptr;
+    uint32_t* d_nh_untouched = nullptr;
+    uint32_t nh_untouched = 0;
     std::vector<uint32_t> level_off;
     std::vector<int32_t> order;
     std::vector<float> h_inv_mass;
@@ -265,7 +271,7 @@ void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e);   // one substep of a fused body (tet | fused x (n-1) | particle)
 void pj_repredict(tetsim_body* h);
-void nh_sweep(tetsim_body* h);
+void nh_sweep(tetsim_body* h, bool fold = false);   // fold: first touchers do the particle pass between two substeps
 // first / last: position inside a run of substeps enqueued back to back with one dt
 int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
 int ensure_prediction(tetsim_body* h, double dt);

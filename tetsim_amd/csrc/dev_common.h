@@ -107,6 +107,10 @@ struct NHClusterLaunch {
     uint32_t nsteps = 0, clusters = 0;
     uint32_t first[kNHClusterTets] = {}, count[kNHClusterTets] = {};
     const int32_t* slot_vid = nullptr;
+    // folded particle pass (tetsim_step_n, substeps after the first of a run): bit k of first_mask[cluster] = this cluster is the
+    // FIRST of the sweep to touch the particle in its slot k -- its lane finishes the previous substep for that particle (bounds,
+    // floor, grab, velocity: Softbody.js:213-239) and predicts this one (:198-202) as it loads it
+    const uint8_t* first_mask = nullptr;
 };
 
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
@@ -121,8 +125,12 @@ void pj_launch_repredict_fast(hipStream_t s, const PJDev& d);
 
 void nh_launch_post_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
-void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
-void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L);
+// fold: this sweep's first touchers do the particle pass between the previous substep and this one (L.first_mask)
+void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
+void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
+// the same pass for the particles no cluster touches (list of particle ids), when the sweeps fold the rest
+void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
+void nh_launch_post_predict_list_fast(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
 // in its queue is done" -- a signal kernel folded into its successor
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,

@@ -150,9 +150,9 @@ void pj_repredict(tetsim_body* h) {
 // The halo stream carries the transfers AND the boundary tiles that consume them; high priority so that its few
 // workgroups are dispatched ahead of the interior kernel's backlog.
 // NEOHOOKEAN_GS: the Gauss-Seidel sweep over all tets (A3-A5), as dependency levels or as cluster colours
-void nh_sweep(tetsim_body* h) {
+void nh_sweep(tetsim_body* h, bool fold) {
     if (!h->cluster_launch.empty()) {
-        for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L) : nh_launch_cluster_precise(h->stream, h->nh, L);
+        for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L, fold) : nh_launch_cluster_precise(h->stream, h->nh, L, fold);
         return;
     }
     for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
@@ -177,9 +177,14 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
             pj_vertex(h, 0, h->pj.nv_owned);
         }
     } else {
+        // clustered schedules fold the particle pass BETWEEN two substeps of a run into the next sweep: the lane of the first cluster
+        // to touch a particle finishes the previous substep and predicts the next for it while loading it (nh_kernels.inc:
+        // fold_particle) -- one kernel and one launch boundary less per substep, the same operations per particle
         if (first) h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
-        nh_sweep(h);
+        nh_sweep(h, !first && h->nh_fold);
         if (last) h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
+        else if (h->nh_fold) h->fast ? nh_launch_post_predict_list_fast(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched)
+                                     : nh_launch_post_predict_list_precise(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched);
         else h->fast ? nh_launch_post_predict_fast(h->stream, h->nh) : nh_launch_post_predict_precise(h->stream, h->nh);
     }
     hipError_t e = hipGetLastError();

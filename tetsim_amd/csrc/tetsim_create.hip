@@ -464,8 +464,41 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         if ((rc = upload(h, d.corner_slots, plan.corner_slots))) return rc;
         if ((rc = dev_alloc(h, &h->d_slot_vid, plan.slot_vid.size()))) return rc;
         if ((rc = upload(h, h->d_slot_vid, plan.slot_vid))) return rc;
+        // who touches a particle FIRST in a sweep (launch order; the clusters of one launch share no particle): that lane also does
+        // the particle pass between two substeps of a run (TETSIM_NH_FOLD=0, read here: a pass of its own as in round 2 -- A/B)
+        std::vector<uint8_t> first_mask;
+        std::vector<uint32_t> mask_off(nl + 1, 0);
+        {
+            const char* e = getenv("TETSIM_NH_FOLD");
+            const char* q = getenv("TETSIM_NH_QUADS");
+            // FAST on four lanes per cluster only: a lane folds two particles there; with one lane per cluster (PRECISE) it would fold
+            // eight one after the other, in f64 -- as long as the pass it replaces (measured: 132 against 120 us per substep)
+            h->nh_fold = h->fast && !(q && q[0] == '0') && !(e && e[0] == '0');
+        }
+        if (h->nh_fold) {
+            std::vector<uint8_t> seen(nv, 0);
+            for (uint32_t l = 0; l < nl; l++) {
+                const uint32_t nsteps = plan.step_off[l + 1] - plan.step_off[l];
+                const uint32_t clusters = nsteps ? plan.step_count[plan.step_off[l]] : 0;
+                mask_off[l + 1] = mask_off[l] + clusters;
+                first_mask.resize(mask_off[l + 1], 0);
+                for (uint32_t k = 0; k < kClusterVerts; k++)
+                    for (uint32_t i = 0; i < clusters; i++) {
+                        const int32_t v = plan.slot_vid[plan.vid_off[l] + static_cast<size_t>(k) * clusters + i];
+                        if (v >= 0 && !seen[v]) { seen[v] = 1; first_mask[mask_off[l] + i] |= static_cast<uint8_t>(1u << k); }
+                    }
+            }
+            std::vector<uint32_t> untouched;
+            for (uint32_t v = 0; v < nv; v++) if (!seen[v]) untouched.push_back(v);
+            h->nh_untouched = static_cast<uint32_t>(untouched.size());
+            if ((rc = dev_alloc(h, &h->d_first_mask, first_mask.size()))) return rc;
+            if ((rc = upload(h, h->d_first_mask, first_mask))) return rc;
+            if ((rc = dev_alloc(h, &h->d_nh_untouched, untouched.size()))) return rc;
+            if ((rc = upload(h, h->d_nh_untouched, untouched))) return rc;
+        }
         for (uint32_t l = 0; l < nl; l++) {
             NHClusterLaunch L;
+            if (h->nh_fold) L.first_mask = h->d_first_mask + mask_off[l];
             L.nsteps = plan.step_off[l + 1] - plan.step_off[l];
             for (uint32_t j = 0; j < L.nsteps; j++) {
                 L.first[j] = plan.step_first[plan.step_off[l] + j];
