@@ -622,7 +622,9 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel_peer(PJBlk d, uint32_t f
 // the words the neighbours raise here, and clear them.  Words alternate by substep parity (the host passes the right pair): the
 // raise of substep s+2 lands on the word of substep s only after its consumer has cleared it -- the dependency cycle orders
 // them -- whereas ONE word per neighbour could see two raises before a wait (s+1's while this wave still waits for V).
-__global__ void pjb_wait_peers_kernel(PJSync y, PJPeerSync w) {
+__global__ void pjb_wait_peers_kernel(uint32_t* flag, uint32_t* error, uint32_t timeout_ms, PJPeerSync w) {
+    PJSync y;
+    y.flag = flag; y.error = error; y.timeout_ms = timeout_ms;
     const uint32_t t = threadIdx.x;
     if (t < w.n_raise) __hip_atomic_store(w.raise[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (y.flag) await_done(y);
@@ -636,8 +638,14 @@ __global__ void pjb_wait_peers_kernel(PJSync y, PJPeerSync w) {
         if (w.delay_us) { const long long d0 = wall_clock64(); while (wall_clock64() - d0 < 100ll * w.delay_us) __builtin_amdgcn_s_sleep(8); }
     }
 }
-__global__ void pjb_wait_kernel(PJSync y) { await_done(y); }
-__global__ void pjb_signal_kernel(PJSync y) { if (threadIdx.x == 0) __hip_atomic_store(y.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// (scalar arguments, not the PJSync struct: the unit is built with kernel-argument preload, which hands leading SCALARS to the wave in
+// SGPRs -- these one-wave kernels sit on the substep's critical chains and have nothing to hide a scalar load behind)
+__global__ void pjb_wait_kernel(uint32_t* flag, uint32_t* error, uint32_t timeout_ms) {
+    PJSync y;
+    y.flag = flag; y.error = error; y.timeout_ms = timeout_ms;
+    await_done(y);
+}
+__global__ void pjb_signal_kernel(uint32_t* flag) { if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -719,7 +727,7 @@ uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks) {
     for (uint32_t i = 8u; i < blocks; i++) if (out[i] != out[i & 7u]) return 0;    // ... and the pattern repeats
     return 8;
 }
-void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w) { hipLaunchKernelGGL(pjb_wait_peers_kernel, dim3(1), dim3(64), 0, s, y, w); }
+void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w) { hipLaunchKernelGGL(pjb_wait_peers_kernel, dim3(1), dim3(64), 0, s, y.flag, y.error, y.timeout_ms, w); }
 void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word) {
     if (count == 0) return;
     hipLaunchKernelGGL(pjb_vertex_kernel_peer, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, peer, raise_word);
@@ -730,8 +738,8 @@ void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_alt : pjb_tet_kernel_alt;
     hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
-void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y); }
-void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y); }
+void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y.flag, y.error, y.timeout_ms); }
+void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y.flag); }
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
     if (count == 0) return;
     if (raise_word) {

@@ -1,7 +1,8 @@
 #!/bin/bash
-# kernel timeline of the loopback rank (eager and graph replay), with and without an added wire delay
+# kernel timeline of the loopback rank (eager and graph replay), with and without an added wire delay:  bash tools/halo_trace.sh [outdir]
+# LOOPBACK_P2P=1 traces the peer-to-peer halo instead of the RCCL transfer
 set -u
-cd "$GRAFT_REPO_ROOT"; O=$PWD/gpurun_out/r02n; mkdir -p $O
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"; O=${1:-$PWD/gpurun_out/halo_trace}; mkdir -p $O; : > $O/timeline.txt
 export TMPDIR=/tmp
 for g in 0 1; do for d in 0 20; do
   rm -rf /tmp/tr; 
