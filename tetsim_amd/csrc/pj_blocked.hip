@@ -346,6 +346,11 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(P
 // verified the dispatcher's block -> XCD rule with pjb_probe_xcd), so the exchange only has to be coherent in that XCD's L2: plain
 // stores (the L1 writes through) and agent-scope loads (miss the L1, served by the L2) -- dev_store.h.  !kLocal: write-through
 // stores and cache-bypassing loads, coherent at the memory side (any placement).
+#ifdef TETSIM_ABLATION
+constexpr int kFrameIters = 9;                  // (the ablation knobs belong to the per-substep kernel)
+#else
+constexpr int kFrameIters = TETSIM_DBG_ITERS;   // the product's compile-time constant (tools/mutation_check.sh mutates it for both kernels)
+#endif
 template <bool kLean, bool kLocal>
 __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
                                                uint32_t* const err, const uint32_t timeout_ms) {
@@ -450,7 +455,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
             for (int k = 0; k < 4; k++) r[k] = rest[k];
             float4 q_new;
             f3 cc;
-            pj_solve_tet(cur, r, q, q_new, goal, 9, true, kLean, !kLean, &cc);
+            pj_solve_tet(cur, r, q, q_new, goal, kFrameIters, true, kLean, !kLean, &cc);
             q = q_new;
             if (!kLean) {
 #pragma unroll
