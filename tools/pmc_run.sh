@@ -6,7 +6,7 @@ TAG=${1:-pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs ${BENCH_ARGS:-}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-beyond-mall ${BENCH_ARGS:-}"
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
