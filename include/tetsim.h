@@ -419,6 +419,18 @@ typedef struct TetSimPlanSizes {
 } TetSimPlanSizes;
 int tetsim_plan_create(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
                        const int32_t *vert_owner, tetsim_plan *out);
+/* The same plan with a ghost region `depth` layers deep (1 or 2).  Depth 2: the second layer holds the particles that share a tet
+ * with a first-layer ghost, the local tets include the tets of the first-layer ghosts that touch no owned particle, and every
+ * neighbour has a second pair of lists -- what lets a partition advance its first ghost layer itself and exchange ghosts only every
+ * other substep (exercised on the CPU by tests/test_partition_gloo.py).  Local numbering: owned boundary | owned
+ * interior | first-layer ghosts by owner | second-layer ghosts by owner. */
+int tetsim_plan_create_deep(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
+                            const int32_t *vert_owner, int32_t depth, tetsim_plan *out);
+/* first_layer_ghosts: ghosts [owned, owned + that) are the first layer; tet_layer [local_elems]: 0 = touches an owned particle, 1 = not */
+int tetsim_plan_layers(tetsim_plan p, uint32_t *first_layer_ghosts, uint8_t *tet_layer);
+/* neighbour i's SECOND-layer lists (disjoint from the first-layer ones of tetsim_plan_neighbour) */
+int tetsim_plan_neighbour_layer2(tetsim_plan p, uint32_t i, uint32_t *send_count, uint32_t *recv_start, uint32_t *recv_count);
+int tetsim_plan_neighbour_layer2_ids(tetsim_plan p, uint32_t i, int32_t *send_local, int32_t *send_global, int32_t *recv_global);
 void tetsim_plan_destroy(tetsim_plan p);
 int tetsim_plan_sizes(tetsim_plan p, TetSimPlanSizes *out);
 /* local_to_global_vert [local_particles], local_to_global_tet [local_elems], local_tets [4*local_elems] */

@@ -68,6 +68,7 @@ def _load():
         getattr(lib, "orc_pj_read_" + n).argtypes = [vp, fp]
     lib.orc_pj_read_elem.argtypes = [vp, C.c_int, fp]
     lib.orc_pj_write_particles.argtypes = [vp, C.c_int, ip, fp, fp]
+    lib.orc_pj_write_tets.argtypes = [vp, C.c_int, ip, fp, fp]
     lib.orc_pj_slots.restype, lib.orc_pj_slots.argtypes = ip, [vp]
     lib.orc_pj_inv_rest_volume.restype, lib.orc_pj_inv_rest_volume.argtypes = fp, [vp]
     lib.orc_pj_inv_mass.restype, lib.orc_pj_inv_mass.argtypes = fp, [vp]
@@ -253,6 +254,18 @@ class OraclePJ(_Base):
 
     def endGrab(self):
         self.setGrab(-1)
+
+    def tetState(self, idx):
+        """(quaternions [n,4], carried rest corners [n,4,4]) of the listed tets."""
+        idx = np.asarray(idx, dtype=np.int64)
+        q = self.quats[idx]
+        el = np.stack([self.elems(k)[idx] for k in range(4)], axis=1)
+        return q, el
+
+    def writeTets(self, idx, quats, elems):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        q, el = _f32(quats).reshape(-1), _f32(elems).reshape(-1)
+        self._lib.orc_pj_write_tets(self._h, len(idx), idx.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(q), _fptr(el))
 
     def writeParticles(self, idx, pos, vel):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

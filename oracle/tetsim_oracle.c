@@ -626,6 +626,19 @@ void orc_pj_write_particles(OrcPJ *s, int n, const int32_t *idx, const float *po
         s->vel[s->cur_vel][idx[i]] = V3(vel3[3 * i], vel3[3 * i + 1], vel3[3 * i + 2]);
     }
 }
+/* Overwrite the per-tet state (quaternion xyzw, the 4 carried rest corners as xyzw each) of the listed tets (partitioned tests with a
+ * two-layer ghost region: second-layer ghost tets are restored / evolved after the fact, tests/test_partition_gloo.py). */
+void orc_pj_write_tets(OrcPJ *s, int n, const int32_t *idx, const float *quat4, const float *elem16) {
+    for (int i = 0; i < n; i++) {
+        const int e = idx[i];
+        v4 q = {quat4[4 * i], quat4[4 * i + 1], quat4[4 * i + 2], quat4[4 * i + 3]};
+        s->quat[s->cur_quat][e] = q;
+        for (int k = 0; k < 4; k++) {
+            v4 c = {elem16[16 * i + 4 * k], elem16[16 * i + 4 * k + 1], elem16[16 * i + 4 * k + 2], elem16[16 * i + 4 * k + 3]};
+            s->elem[s->cur_elem][k][e] = c;
+        }
+    }
+}
 void orc_pj_read_pos(OrcPJ *s, float *out) { memcpy(out, s->pos[s->cur_pos], sizeof(v3) * s->nv); }
 void orc_pj_read_prev(OrcPJ *s, float *out) { memcpy(out, s->prev[s->cur_prev], sizeof(v3) * s->nv); }
 void orc_pj_read_vel(OrcPJ *s, float *out) { memcpy(out, s->vel[s->cur_vel], sizeof(v3) * s->nv); }

@@ -91,6 +91,7 @@ SYMBOLS = [
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
     "tetsim_prep_tiles", "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
+    "tetsim_plan_create_deep", "tetsim_plan_layers", "tetsim_plan_neighbour_layer2", "tetsim_plan_neighbour_layer2_ids",
     "tetsim_mesh_write", "tetsim_mesh_open", "tetsim_mesh_arrays", "tetsim_mesh_close", "tetsim_create_from_file",
 ]
 
@@ -179,6 +180,10 @@ def lib():
     L.tetsim_plan_arrays.argtypes = [H, ip, ip, ip]
     L.tetsim_plan_neighbour.argtypes = [H, u32, ip, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), ip]
     L.tetsim_plan_neighbour_ids.argtypes = [H, u32, ip, ip, ip]
+    L.tetsim_plan_create_deep.argtypes = [ip, u32, u32, i32, i32, ip, i32, C.POINTER(H)]
+    L.tetsim_plan_layers.argtypes = [H, C.POINTER(u32), C.POINTER(C.c_uint8)]
+    L.tetsim_plan_neighbour_layer2.argtypes = [H, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.tetsim_plan_neighbour_layer2_ids.argtypes = [H, u32, ip, ip, ip]
     for s in SYMBOLS:
         f = getattr(L, s)
         if s not in ("tetsim_default_options", "tetsim_default_params", "tetsim_destroy", "tetsim_last_error",

@@ -530,14 +530,16 @@ std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, 
 }
 
 std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
-                            const int32_t* vert_owner, Partition* out) {
+                            const int32_t* vert_owner, Partition* out, int depth) {
     Partition& P = *out;
     P = Partition();
     P.nv_global = nv;
     P.nt_global = nt;
     P.part_count = part_count;
     P.part_index = part_index;
+    P.depth = depth;
     if (part_count < 1 || part_index < 0 || part_index >= part_count) return "bad part_index/part_count";
+    if (depth != 1 && depth != 2) return "ghost depth must be 1 or 2";
 
     std::vector<int32_t> owner(nv);
     if (vert_owner) {
@@ -551,77 +553,102 @@ std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int p
     }
     const int me = part_index;
 
-    // local tets = every tet with at least one owned vertex (ascending global id)
-    std::vector<char> is_ghost(nv, 0), is_boundary(nv, 0);
+    // Which ranks read a particle as a ghost.  near1[v]: ranks r != owner(v) that own a particle sharing a tet with v -- v is in
+    // r's FIRST ghost layer.  near2[v] (depth 2): ranks r that neither own v nor have it in their first layer, but have a
+    // first-layer ghost sharing a tet with v -- v is in r's SECOND layer.  (Small sorted vectors; empty for interior particles.)
+    std::vector<std::vector<int32_t>> near1(nv), near2(depth == 2 ? nv : 0);
+    auto add = [](std::vector<int32_t>& s, int32_t r) { if (std::find(s.begin(), s.end(), r) == s.end()) s.push_back(r); };
     for (uint32_t e = 0; e < nt; e++) {
         const int32_t* t = &tets[4 * e];
-        bool mine = false, foreign = false;
+        const int32_t o[4] = {owner[t[0]], owner[t[1]], owner[t[2]], owner[t[3]]};
+        if (o[0] == o[1] && o[1] == o[2] && o[2] == o[3]) continue;
+        for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++)
+                if (o[b] != o[a]) add(near1[t[a]], o[b]);
+    }
+    if (depth == 2)
+        for (uint32_t e = 0; e < nt; e++) {
+            const int32_t* t = &tets[4 * e];
+            for (int a = 0; a < 4; a++)
+                for (int32_t r : near1[t[a]])            // t[a] is a first-layer ghost of r ...
+                    for (int b = 0; b < 4; b++) {        // ... so every other corner r does not already hold is in its second layer
+                        const int32_t v = t[b];
+                        if (owner[v] != r && std::find(near1[v].begin(), near1[v].end(), r) == near1[v].end()) add(near2[v], r);
+                    }
+        }
+    auto reads = [&](const std::vector<std::vector<int32_t>>& near, uint32_t v, int32_t r) {
+        return !near.empty() && std::find(near[v].begin(), near[v].end(), r) != near[v].end();
+    };
+
+    // local tets (ascending global id): every tet with an owned corner, and -- depth 2 -- every tet with a first-layer ghost corner
+    for (uint32_t e = 0; e < nt; e++) {
+        const int32_t* t = &tets[4 * e];
+        bool mine = false, first_layer = false;
         int lowest = part_count;
         for (int k = 0; k < 4; k++) {
-            if (owner[t[k]] == me) mine = true; else foreign = true;
+            if (owner[t[k]] == me) mine = true;
+            else if (reads(near1, static_cast<uint32_t>(t[k]), me)) first_layer = true;
             lowest = std::min(lowest, owner[t[k]]);
         }
-        if (!mine) continue;
+        if (!mine && !(depth == 2 && first_layer)) continue;
         P.local_to_global_tet.push_back(static_cast<int32_t>(e));
-        if (lowest == me) P.owned_tets++;
-        if (foreign)
-            for (int k = 0; k < 4; k++) {
-                if (owner[t[k]] == me) is_boundary[t[k]] = 1;  // some other partition reads it as a ghost
-                else is_ghost[t[k]] = 1;
-            }
+        P.tet_layer.push_back(mine ? 0 : 1);
+        if (mine && lowest == me) P.owned_tets++;
     }
-    // NOTE: an owned vertex is a ghost of rank r iff it shares a tet with an r-owned vertex; that tet has
-    // an owned vertex of mine and a foreign one, so it is covered by the loop above.
 
-    // local vertex numbering: [owned boundary | owned interior | ghosts sorted by (owner, id)]
+    // local vertex numbering: [owned boundary | owned interior | first-layer ghosts by (owner, id) | second-layer ghosts by (owner, id)];
+    // boundary = an owned particle some other rank reads (in either layer)
     std::vector<int32_t> g2l(nv, -1);
+    auto is_boundary = [&](uint32_t v) { return !near1[v].empty() || (depth == 2 && !near2[v].empty()); };
     for (uint32_t v = 0; v < nv; v++)
-        if (owner[v] == me && is_boundary[v]) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+        if (owner[v] == me && is_boundary(v)) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
     P.n_boundary = static_cast<uint32_t>(P.local_to_global_vert.size());
     for (uint32_t v = 0; v < nv; v++)
-        if (owner[v] == me && !is_boundary[v]) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+        if (owner[v] == me && !is_boundary(v)) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
     P.n_owned = static_cast<uint32_t>(P.local_to_global_vert.size());
-    std::vector<int32_t> ghosts;
-    for (uint32_t v = 0; v < nv; v++)
-        if (is_ghost[v]) ghosts.push_back(static_cast<int32_t>(v));
-    std::stable_sort(ghosts.begin(), ghosts.end(), [&](int32_t a, int32_t b) { return owner[a] < owner[b]; });
-    for (int32_t v : ghosts) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+    std::vector<int32_t> ghosts1, ghosts2;
+    for (uint32_t v = 0; v < nv; v++) {
+        if (owner[v] == me) continue;
+        if (reads(near1, v, me)) ghosts1.push_back(static_cast<int32_t>(v));
+        else if (reads(near2, v, me)) ghosts2.push_back(static_cast<int32_t>(v));
+    }
+    auto by_owner = [&](int32_t a, int32_t b) { return owner[a] < owner[b]; };
+    std::stable_sort(ghosts1.begin(), ghosts1.end(), by_owner);
+    std::stable_sort(ghosts2.begin(), ghosts2.end(), by_owner);
+    for (int32_t v : ghosts1) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
+    P.n_ghost1 = static_cast<uint32_t>(ghosts1.size());
+    for (int32_t v : ghosts2) { g2l[v] = static_cast<int32_t>(P.local_to_global_vert.size()); P.local_to_global_vert.push_back(v); }
 
     P.local_tets.resize(4 * P.local_to_global_tet.size());
     for (size_t i = 0; i < P.local_to_global_tet.size(); i++)
-        for (int k = 0; k < 4; k++) P.local_tets[4 * i + k] = g2l[tets[4 * P.local_to_global_tet[i] + k]];
-
-    // halo lists.  recv from r = my ghosts owned by r (contiguous by construction).  send to r = my owned
-    // vertices that share a tet with an r-owned vertex (ascending global id): exactly r's ghosts owned by me.
-    std::vector<std::vector<int32_t>> send(part_count);
-    {
-        std::vector<uint64_t> pairs;  // (rank << 32 | vertex)
-        for (uint32_t e = 0; e < nt; e++) {
-            const int32_t* t = &tets[4 * e];
-            for (int a = 0; a < 4; a++) {
-                if (owner[t[a]] != me) continue;
-                for (int b = 0; b < 4; b++)
-                    if (owner[t[b]] != me) pairs.push_back((static_cast<uint64_t>(owner[t[b]]) << 32) | static_cast<uint32_t>(t[a]));
-            }
+        for (int k = 0; k < 4; k++) {
+            const int32_t l = g2l[tets[4 * P.local_to_global_tet[i] + k]];
+            if (l < 0) return "internal error in the partition plan: a local tet has a corner outside the ghost layers";
+            P.local_tets[4 * i + k] = l;
         }
-        std::sort(pairs.begin(), pairs.end());
-        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-        for (uint64_t p : pairs) send[p >> 32].push_back(static_cast<int32_t>(p & 0xffffffffu));
-    }
-    size_t gpos = 0;
+
+    // halo lists, per neighbour: received = my ghosts it owns (one contiguous range per layer); sent = my owned particles it reads
+    // (per layer, ascending global id) -- exactly its ghosts owned by me, in its order
+    size_t g1 = 0, g2 = 0;
     for (int r = 0; r < part_count; r++) {
         if (r == me) continue;
         Partition::Neighbour nb;
         nb.rank = r;
-        nb.recv_start = P.n_owned + static_cast<uint32_t>(gpos);
-        while (gpos < ghosts.size() && owner[ghosts[gpos]] == r) { nb.recv_global.push_back(ghosts[gpos]); gpos++; }
+        nb.recv_start = P.n_owned + static_cast<uint32_t>(g1);
+        while (g1 < ghosts1.size() && owner[ghosts1[g1]] == r) { nb.recv_global.push_back(ghosts1[g1]); g1++; }
         nb.recv_count = static_cast<uint32_t>(nb.recv_global.size());
-        nb.send_global = send[r];
-        for (int32_t v : nb.send_global) nb.send_local.push_back(g2l[v]);
+        nb.recv2_start = P.n_owned + P.n_ghost1 + static_cast<uint32_t>(g2);
+        while (g2 < ghosts2.size() && owner[ghosts2[g2]] == r) { nb.recv2_global.push_back(ghosts2[g2]); g2++; }
+        nb.recv2_count = static_cast<uint32_t>(nb.recv2_global.size());
+        for (uint32_t v = 0; v < nv; v++) {
+            if (owner[v] != me) continue;
+            if (reads(near1, v, r)) { nb.send_global.push_back(static_cast<int32_t>(v)); nb.send_local.push_back(g2l[v]); }
+            else if (reads(near2, v, r)) { nb.send2_global.push_back(static_cast<int32_t>(v)); nb.send2_local.push_back(g2l[v]); }
+        }
         nb.send_contiguous = !nb.send_local.empty();
         for (size_t i = 1; i < nb.send_local.size(); i++)
             if (nb.send_local[i] != nb.send_local[i - 1] + 1) { nb.send_contiguous = false; break; }
-        if (nb.recv_count || !nb.send_local.empty()) P.neigh.push_back(std::move(nb));
+        if (nb.recv_count || nb.recv2_count || !nb.send_local.empty() || !nb.send2_local.empty()) P.neigh.push_back(std::move(nb));
     }
     return "";
 }

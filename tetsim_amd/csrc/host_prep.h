@@ -68,12 +68,24 @@ struct Partition {
         uint32_t recv_start = 0, recv_count = 0;  // contiguous ghost range in local numbering
         std::vector<int32_t> recv_global;
         bool send_contiguous = false;
+        // depth 2: the SECOND ghost layer of this neighbour's particles (received), and the owned particles that are the
+        // neighbour's second layer (sent) -- disjoint from the first-layer lists above
+        std::vector<int32_t> send2_local, send2_global;
+        uint32_t recv2_start = 0, recv2_count = 0;
+        std::vector<int32_t> recv2_global;
     };
     std::vector<Neighbour> neigh;
+    // depth 2 (a two-layer ghost region: the partition can advance its first ghost layer itself, so that ghosts need to cross
+    // only every other substep -- DESIGN.md 6): ghosts [n_owned, n_owned + n_ghost1) are the first layer (share a tet with an
+    // owned particle), the rest the second (share a tet with a first-layer ghost); local tets with tet_layer 1 touch no owned
+    // particle (first-layer ghost tets' outer neighbours).  depth 1: n_ghost1 = all ghosts, tet_layer all 0.
+    int depth = 1;
+    uint32_t n_ghost1 = 0;
+    std::vector<uint8_t> tet_layer;
 };
 // vert_owner may be null (equal contiguous index ranges). Returns "" or an error message.
 std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
-                            const int32_t* vert_owner, Partition* out);
+                            const int32_t* vert_owner, Partition* out, int depth = 1);
 
 // Permutation that sorts points [first, first+count) of `xyz` along a Morton (Z-order) curve; entries outside that
 // range map to themselves.  order[new] = old.  Used to renumber particles internally so that particles that are

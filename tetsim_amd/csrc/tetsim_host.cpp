@@ -130,6 +130,40 @@ int tetsim_plan_create(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t pa
     *out = p;
     return 0;
 }
+int tetsim_plan_create_deep(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
+                            const int32_t* vert_owner, int32_t depth, tetsim_plan* out) {
+    if (!out) return fail(nullptr, TETSIM_EINVAL, "null plan pointer");
+    *out = nullptr;
+    std::string e = validate_mesh(reinterpret_cast<const float*>(tets), nv, tets, nt, false);
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    tetsim_plan_s* p = new tetsim_plan_s();
+    e = build_partition(tets, nt, nv, part_count, part_index, vert_owner, &p->P, depth);
+    if (!e.empty()) { delete p; return fail(nullptr, TETSIM_EINVAL, e); }
+    *out = p;
+    return 0;
+}
+int tetsim_plan_layers(tetsim_plan p, uint32_t* first_layer_ghosts, uint8_t* tet_layer) {
+    if (!p) return TETSIM_EINVAL;
+    if (first_layer_ghosts) *first_layer_ghosts = p->P.n_ghost1;
+    if (tet_layer) std::copy(p->P.tet_layer.begin(), p->P.tet_layer.end(), tet_layer);
+    return 0;
+}
+int tetsim_plan_neighbour_layer2(tetsim_plan p, uint32_t i, uint32_t* send_count, uint32_t* recv_start, uint32_t* recv_count) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (send_count) *send_count = static_cast<uint32_t>(nb.send2_local.size());
+    if (recv_start) *recv_start = nb.recv2_start;
+    if (recv_count) *recv_count = nb.recv2_count;
+    return 0;
+}
+int tetsim_plan_neighbour_layer2_ids(tetsim_plan p, uint32_t i, int32_t* send_local, int32_t* send_global, int32_t* recv_global) {
+    if (!p || i >= p->P.neigh.size()) return TETSIM_EINVAL;
+    const auto& nb = p->P.neigh[i];
+    if (send_local) std::copy(nb.send2_local.begin(), nb.send2_local.end(), send_local);
+    if (send_global) std::copy(nb.send2_global.begin(), nb.send2_global.end(), send_global);
+    if (recv_global) std::copy(nb.recv2_global.begin(), nb.recv2_global.end(), recv_global);
+    return 0;
+}
 void tetsim_plan_destroy(tetsim_plan p) { delete p; }
 int tetsim_plan_sizes(tetsim_plan p, TetSimPlanSizes* out) {
     if (!p || !out) return TETSIM_EINVAL;

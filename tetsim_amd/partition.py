@@ -19,18 +19,19 @@ def slab_owner(n_cells_xy, nz_cells, parts):
 
 
 class Neighbour:
-    __slots__ = ("rank", "send_local", "send_global", "recv_start", "recv_count", "recv_global", "contiguous")
+    __slots__ = ("rank", "send_local", "send_global", "recv_start", "recv_count", "recv_global", "contiguous",
+                 "send2_local", "send2_global", "recv2_start", "recv2_count", "recv2_global")   # second ghost layer (depth 2)
 
 
 class PartitionPlan:
-    def __init__(self, tetIds, num_particles, part_count, part_index, vert_owner=None):
+    def __init__(self, tetIds, num_particles, part_count, part_index, vert_owner=None, depth=1):
         L = capi.lib()
         tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
         ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
         owner = None if vert_owner is None else np.ascontiguousarray(vert_owner, dtype=np.int32)
         h = C.c_void_p()
-        capi.check(L.tetsim_plan_create(ip(tets), tets.size // 4, int(num_particles), part_count, part_index,
-                                        ip(owner) if owner is not None else None, C.byref(h)))
+        capi.check(L.tetsim_plan_create_deep(ip(tets), tets.size // 4, int(num_particles), part_count, part_index,
+                                             ip(owner) if owner is not None else None, int(depth), C.byref(h)))
         try:
             sz = capi.TetSimPlanSizes()
             capi.check(L.tetsim_plan_sizes(h, C.byref(sz)))
@@ -42,6 +43,13 @@ class PartitionPlan:
             self.local_tets = np.empty(4 * self.n_local_tets, dtype=np.int32)
             capi.check(L.tetsim_plan_arrays(h, ip(self.local_to_global_vert), ip(self.local_to_global_tet), ip(self.local_tets)))
             self.local_tets = self.local_tets.reshape(-1, 4)
+            # ghost layers (depth 2): ghosts [n_owned, n_owned + n_ghost1) share a tet with an owned particle, the rest with a
+            # first-layer ghost; tet_layer 1 = a local tet that touches no owned particle
+            self.depth = depth
+            g1 = C.c_uint32()
+            self.tet_layer = np.zeros(self.n_local_tets, dtype=np.uint8)
+            capi.check(L.tetsim_plan_layers(h, C.byref(g1), self.tet_layer.ctypes.data_as(C.POINTER(C.c_uint8))))
+            self.n_ghost1 = g1.value
             self.neighbours = []
             for i in range(sz.num_neighbours):
                 r, c = C.c_int32(), C.c_int32()
@@ -53,6 +61,12 @@ class PartitionPlan:
                 nb.send_global = np.empty(sc.value, dtype=np.int32)
                 nb.recv_global = np.empty(rc.value, dtype=np.int32)
                 capi.check(L.tetsim_plan_neighbour_ids(h, i, ip(nb.send_local), ip(nb.send_global), ip(nb.recv_global)))
+                capi.check(L.tetsim_plan_neighbour_layer2(h, i, C.byref(sc), C.byref(rs), C.byref(rc)))
+                nb.recv2_start, nb.recv2_count = rs.value, rc.value
+                nb.send2_local = np.empty(sc.value, dtype=np.int32)
+                nb.send2_global = np.empty(sc.value, dtype=np.int32)
+                nb.recv2_global = np.empty(rc.value, dtype=np.int32)
+                capi.check(L.tetsim_plan_neighbour_layer2_ids(h, i, ip(nb.send2_local), ip(nb.send2_global), ip(nb.recv2_global)))
                 self.neighbours.append(nb)
         finally:
             L.tetsim_plan_destroy(h)
