@@ -478,9 +478,10 @@ def parse_args():
     ap.add_argument("--config5-cells", type=int, default=110, help="cells per side of the config-5 body (110 = 7,986,000 tets)")
     ap.add_argument("--no-beyond-mall", action="store_true", help="N = 1: skip `roofline.beyond_mall` (the 8 M-tet body on this GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
-    ap.add_argument("--halo", default="rccl", choices=["rccl", "p2p"],
-                    help="N > 1: transport of the per-substep ghost exchange of the HEADLINE run -- rccl (default: grouped ncclSend/ncclRecv) or p2p "
-                         "(the boundary-particle kernel stores straight into the neighbours' ghost ranges, mapped through HIP IPC)")
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "p2p", "deep"],
+                    help="N > 1: transport of the per-substep ghost exchange of the HEADLINE run -- rccl (default: grouped ncclSend/ncclRecv), p2p "
+                         "(the boundary-particle kernel stores straight into the neighbours' ghost ranges, mapped through HIP IPC) or deep (p2p over a "
+                         "two-layer ghost region: ghosts cross every other substep, TETSIM_FLAG_DEEP_GHOSTS)")
     ap.add_argument("--p2p-check", default="auto", choices=["auto", "on", "off"],
                     help="N > 1 with --halo rccl: afterwards repeat the run on a fresh body with the peer-to-peer halo and report its rate and whether its "
                          "positions equal the RCCL run's bit for bit (`multi_gpu.p2p_halo`); auto = on, except with --fake-ranks")
@@ -671,6 +672,8 @@ def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False, 
             kw = dict(part_count=world, part_index=rank, vert_owner=slab_owner(len(verts), cells, nz, world), ref_fixed_bounds=False)
         if args.constant_rest_shape:
             kw["constant_rest_shape"] = True
+        if (halo or args.halo) == "deep" and ranks is not None and world > 1:
+            kw["deep_ghosts"] = True
         body = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision=args.precision, device=local_rank, **kw)
     except Exception as e:  # noqa: BLE001
         if not vote:
@@ -684,7 +687,7 @@ def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False, 
         from tetsim_amd import comm_init, comm_unique_id
         uid = ranks.broadcast_bytes(comm_unique_id() if rank == 0 else None, 128)
         comm_init(body, uid, rank, world)
-        if (halo or args.halo) == "p2p" and world > 1:
+        if (halo or args.halo) in ("p2p", "deep") and world > 1:
             # the peer-to-peer halo on top of the communicator (RCCL keeps carrying the refresh after a dt change): every rank
             # describes its buffers, torch gathers the descriptions, every rank opens its neighbours' (HIP IPC); a local failure is
             # voted on so that no rank steps alone
@@ -739,7 +742,7 @@ def multi_gpu_report(body, world, elapsed_local, host_local, steps, ranks):
         raise SystemExit("RCCL reports %d ranks in the halo communicator but --gpus is %d: refusing to report a number" % (ci["rccl_ranks"], world))
     ms = elapsed_local / steps * 1e3
     hq = host_local / (steps * SUBSTEPS) * 1e6
-    rep = {"rccl_ranks": ci["rccl_ranks"], "halo": "p2p" if ci.get("p2p") else "rccl",
+    rep = {"rccl_ranks": ci["rccl_ranks"], "halo": ("p2p" if ci.get("p2p") else "rccl") + (" (two-layer ghost region, ghosts every other substep)" if body.info.flags & 32 else ""),
            "ranks_ms_per_step": {"min": round(ranks.min_float(ms), 4), "max": round(ranks.max_float(ms), 4)},
            "host_enqueue_us_per_substep": {"min": round(ranks.min_float(hq), 2), "max": round(ranks.max_float(hq), 2)},
            "halo_rank0": {"neighbours": ci["neighbours"], "send_bytes_per_substep": ci["send_bytes_per_substep"],

@@ -92,7 +92,11 @@ enum {
      * (SoftbodyGPU.js:335-338, "This isn't quite correct") maps texel (px,py) of the R x R position texture to
      * int(uv.x*(R-1)) + int(uv.y*(R-1)*R), not to px + R*py, so `grabId` selects zero, one or two OTHER particles.
      * Off by default (the library pins exactly grabId); on for bit-faithful replays of the reference's grab. */
-    TETSIM_FLAG_REF_GRAB_TEXEL = 1u << 4
+    TETSIM_FLAG_REF_GRAB_TEXEL = 1u << 4,
+    /* partitioned POLAR_JACOBI + TETSIM_FAST (blocked): a ghost region TWO layers deep.  The partition advances its first ghost layer
+     * itself and its neighbours' particles cross only every other substep -- half the hand-overs on the substep's critical chain
+     * (DESIGN.md 6).  Needs the peer-to-peer halo (tetsim_halo_p2p_connect) before the first step; dt must stay fixed. */
+    TETSIM_FLAG_DEEP_GHOSTS = 1u << 5
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */

@@ -165,3 +165,63 @@ def test_two_processes_share_one_gpu_through_ipc_mappings(tmp_path):
     for r in range(2):
         got[np.load(tmp_path / ("ids%d.npy" % r))] = np.load(tmp_path / ("pos%d.npy" % r))
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- two-layer ghost region: ghosts cross only every other substep (TETSIM_FLAG_DEEP_GHOSTS) -------------------------------------------
+def _deep_parts(v, t, n, owner):
+    return [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=n, part_index=p, vert_owner=owner, deep_ghosts=True) for p in range(n)]
+
+
+@pytest.mark.parametrize("case", ["slabs2", "slabs4", "dragon3"])
+def test_two_layer_ghost_region_tracks_the_monolithic_body_and_its_ghost_tets_track_their_owners(case):
+    """The device form of tests/test_partition_gloo.py's algorithm (which is bit-exact there, with the oracle as compute body): a
+    partition advances its first ghost layer itself on even substeps, its neighbours' particles arrive after odd ones, the
+    second-layer ghost tets are evolved after the fact from the early message.  FAST sums depend on the tiling, which differs from a
+    monolithic body's, so positions are compared within the FAST tolerance -- under floor contact and a grab, where a ghost tet
+    whose state was one substep stale would show -- and the sharp check is on the STATE: after an even number of substeps every
+    ghost tet's quaternion (second layer included) equals the copy its owner carries to rounding; a missed late evolve leaves it a
+    whole substep's rotation behind."""
+    if case == "dragon3":
+        v, t = load_mesh("dragon")
+        v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])
+        n, owner = 3, None
+    else:
+        n = int(case[5:])
+        cells = 16
+        v, t = make_lattice(cells, y0=0.02)
+        owner = np.minimum((np.arange(len(v)) // (cells + 1) ** 2) * n // (cells + 1), n - 1).astype(np.int32)
+    parts = _deep_parts(v, t, n, owner)
+    assert all(p.info.local_elems > q.info.local_elems for p, q in zip(parts, _parts(v, t, n, owner)))   # the second layer of ghost tets is there
+    with pytest.raises(TetSimError):                                       # such a body steps through the peer-to-peer halo only
+        group_step_n(parts, 1, DT, PP)
+    group_p2p_connect(parts)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    gid = int(parts[0].ownedIds[0])
+    total = 0
+    for k, n_sub in enumerate((20, 1, 7, 2, 20, 3, 5, 20)):              # odd call lengths: an exchange may straddle two calls
+        if k == 2:
+            for b in parts + [mono]:
+                b.setGrab(gid, [float(v[gid, 0]) + 0.15, float(v[gid, 1]) + 0.3, float(v[gid, 2])])
+        if k == 6:
+            for b in parts + [mono]:
+                b.endGrab()
+        group_step_n(parts, n_sub, DT, PP)
+        mono.simulateSubsteps(n_sub, DT, PP)
+        total += n_sub
+    pos = _gather(parts, len(v))
+    assert np.isfinite(pos).all()
+    # (the grab is a violent transient: a one-layer decomposition is 3e-4 off the monolithic body ten substeps into it, too;
+    # in calm phases the redundant first ghost layer costs ~2e-7 m per substep -- the twin copies of a straddling tet see inputs that
+    # differ by a rounding on odd substeps)
+    within("polar fast two-layer ghosts %s vs monolithic @%d" % (case, total), np.abs(pos - mono.pos).max(), 2e-3)
+    # ghost tets against their owners' copies (total is even: the last exchange has happened)
+    assert total % 2 == 0
+    owner_q = {}
+    for b in parts:
+        for gt, q in zip(b.localTets[:b.info.owned_elems] if False else b.localTets, b.quats):
+            owner_q.setdefault(int(gt), []).append(q)
+    worst = max(float(np.abs(np.array(qs) - qs[0]).max()) for qs in owner_q.values() if len(qs) > 1)
+    assert sum(len(qs) > 1 for qs in owner_q.values()) > 50
+    within("polar fast two-layer ghosts %s ghost-tet quaternions vs owners @%d" % (case, total), worst, 2e-4)
+    with pytest.raises(TetSimError):                                       # ... and cannot change dt
+        group_step_n(parts, 1, DT * 2, PP)

@@ -367,7 +367,7 @@ def test_lattice_1m_two_partitions_match_monolithic():
         group_step_n(parts, 20, DT20, PP)
     ref = mono.pos
     for b in parts:
-        within("polar fast 1M two slabs vs monolithic @40", np.abs(b.pos - ref[b.ownedIds]).max(), 2e-5)
+        within("polar fast 1M two slabs vs monolithic @40", np.abs(b.pos - ref[b.ownedIds]).max(), 1e-4)
 
 
 def test_lattice_8m_eight_slabs_match_monolithic():

@@ -13,7 +13,7 @@ OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ECOMM, ESTATE = range(7)
 SOLVER_POLAR_JACOBI, SOLVER_NEOHOOKEAN_GS = 0, 1
 PRECISE, FAST = 0, 1
 ORDER_ORIGINAL, ORDER_COLOURED, ORDER_CLUSTERED = 0, 1, 2
-FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE, FLAG_REF_GRAB_TEXEL = 1, 2, 4, 8, 16
+FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE, FLAG_REF_GRAB_TEXEL, FLAG_DEEP_GHOSTS = 1, 2, 4, 8, 16, 32
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
 
@@ -57,7 +57,7 @@ class TetSimLibraryInfo(C.Structure):
 
 DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "TETSIM_DEBUG_ONE_STREAM", "TETSIM_DEBUG_GROUP_SYNC",
                    "TETSIM_DEBUG_HOSTPROF", "TETSIM_DEBUG_TRACE", "TETSIM_HALO_SYNC", "TETSIM_HALO_GRAPH", "TETSIM_DEBUG_LOOPBACK_DELAY_US", "TETSIM_NH_QUADS", "TETSIM_FUSED_PARTICLE_PASS",
-                   "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD"]
+                   "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES"]
 
 
 class TetSimCommInfo(C.Structure):

@@ -91,6 +91,13 @@ struct PeerLink {
     float4* ghost[2] = {nullptr, nullptr};
     uint32_t* arrived[2] = {nullptr, nullptr};
     void* ipc[3] = {nullptr, nullptr, nullptr};   // mappings to close (hipIpcCloseMemHandle)
+    // two-layer ghost regions (TETSIM_FLAG_DEEP_GHOSTS): this rank's runs in the neighbour's four buffers, two sets each (the sets
+    // alternate from one exchange to the next), and its words [set][0 = the even substep's data, 1 = the early, odd-substep data]
+    float4* g1_even[2] = {nullptr, nullptr};    // predictions of the neighbour's first-layer ghosts, for its next even substep
+    float4* g1_final[2] = {nullptr, nullptr};   // ... and their end-of-substep positions (the neighbour advances them itself)
+    float4* g2_even[2] = {nullptr, nullptr};    // predictions of its second-layer ghosts for the even substep
+    float4* g2_odd[2] = {nullptr, nullptr};     // ... and for the odd substep before it (evolves its second-layer ghost tets after the fact)
+    uint32_t* arrived2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 struct NeighDev {
     int rank = -1;
@@ -180,12 +187,24 @@ struct tetsim_body {
     int comm_rank = -1, comm_size = 0;
     // peer-to-peer halo (tetsim_halo_p2p_export / _connect): no transfer kernel -- the boundary-particle kernel stores into the
     // neighbours' ghost ranges, double buffered by substep parity (pos_pred's tail | ghost_alt)
+    // two-layer ghost region (TETSIM_FLAG_DEEP_GHOSTS): ghosts [nv_owned, nv_owned + n_ghost1) are advanced here on even substeps,
+    // the second-layer ghost tets are tiles [nb_first, nb) -- solved on even substeps, evolved after the fact on odd ones
+    bool deep = false;
+    uint32_t n_ghost1 = 0, nb_first = 0;
+    std::vector<int32_t> g2l_ghost1;      // global vertex -> local id of a first-layer ghost, or -1 (grab)
     bool p2p = false;
     uint32_t timeout_ms = 0;              // bound of the device-side waits of this body (TETSIM_HALO_TIMEOUT_MS when it was created / connected)
     float4* ghost_alt = nullptr;          // [nv_local - nv_owned] the ghost buffer of odd substeps
     uint32_t* d_arrived = nullptr;        // [2][kMaxPeers] words the neighbours raise here
     uint32_t* d_peer_slots = nullptr;     // ELL [p2p_cols][p2p_stride]: where a boundary particle goes at which neighbour
     uint32_t p2p_cols = 0, p2p_stride = 0;
+    uint32_t* d_peer_slots2 = nullptr;    // two-layer regions: the same for the neighbours' SECOND layer (disjoint lists)
+    uint32_t p2p_cols2 = 0;
+    // two-layer regions, own receive buffers: ghost_alt holds [g1_even x2 | g1_final x2 | g2_even x2 | g2_odd x2]
+    float4* own_g1_even[2] = {nullptr, nullptr};
+    float4* own_g1_final[2] = {nullptr, nullptr};
+    float4* own_g2_even[2] = {nullptr, nullptr};
+    float4* own_g2_odd[2] = {nullptr, nullptr};
     std::vector<PeerLink> links;          // parallel to `neigh`
     uint64_t p2p_round = 0;               // substeps enqueued since the connection; its parity selects the buffers
     bool p2p_raise_pending = false;       // the last boundary-particle kernel's "arrived" has not been raised yet (no kernel behind it)

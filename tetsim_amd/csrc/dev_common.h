@@ -81,6 +81,9 @@ struct PJBlk {
     // peer-to-peer halo (tetsim_halo.hip): the neighbours store their boundary predictions straight into this rank's ghost range,
     // double buffered by substep parity -- pos_pred's own tail on even substeps, ghost_alt on odd ones (pjb_tet_kernel_alt)
     const float4* ghost_alt = nullptr;       // [nv_local - nv_owned]
+    // two-layer ghost regions: ghosts [nv_owned, nv_owned + n_ghost1) come from ghost_alt, the second layer from ghost2
+    const float4* ghost2 = nullptr;
+    uint32_t n_ghost1 = 0xffffffffu;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
@@ -165,6 +168,13 @@ struct PJPeer {
     float4* ghost[kMaxPeers] = {};           // the neighbours' ghost runs for this rank, of the parity being written (peer memory)
     const uint32_t* slots = nullptr;
     uint32_t cols = 0, stride = 0, n = 0;   // n: neighbours in use
+    // two-layer ghost regions: `slots` lists the particles that are a neighbour's FIRST layer (prediction -> ghost[k], and their
+    // end-of-substep position -> fin[k]: the neighbour advances them itself and needs both), slots2 the ones that are its SECOND
+    // layer (prediction -> ghost2[k]).  A null destination = nothing goes there in this substep.
+    float4* fin[kMaxPeers] = {};
+    float4* ghost2[kMaxPeers] = {};
+    const uint32_t* slots2 = nullptr;
+    uint32_t cols2 = 0;
 };
 // ... and the hand-over around it: the wait kernel in front of the halo-side tiles raises `raise` words in the NEIGHBOURS' memory as
 // it starts ("my boundary predictions of the previous substep are in your ghost range": the kernel in front of it in the queue, the

@@ -365,9 +365,10 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet, const uint32_t* body_first_vert, uint32_t bodies,
-                  uint32_t nv_boundary) {
+                  uint32_t nv_boundary, const uint8_t* tet_class, uint32_t nv_owned) {
     BlockPlan& B = *out;
     B = BlockPlan();
+    if (nv_owned > nv_sum) nv_owned = nv_sum;
     constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
     const uint32_t one_t[2] = {0u, nt}, one_v[2] = {0u, nv};
     if (!body_first_tet || !body_first_vert || bodies == 0) { body_first_tet = one_t; body_first_vert = one_v; bodies = 1; }
@@ -383,6 +384,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
             for (int k = 0; k < 4; k++)
                 for (int c = 0; c < 3; c++) m[c] += verts[3 * tets[4 * e + k] + c];
             key[e] = (static_cast<uint64_t>(Q.code(0.25f * m[0], 0.25f * m[1], 0.25f * m[2])) << 32) | (e - tb);  // ties keep the caller's order
+            if (tet_class) key[e] |= static_cast<uint64_t>(tet_class[e] & 3u) << 62;   // classes one after the other (the code uses bits 32..61)
         }
         std::sort(key.begin() + tb, key.begin() + te);
         for (uint32_t i = tb; i < te; i++) { B.tet_perm[i] = static_cast<int32_t>(tb + (key[i] & 0xffffffffu)); body_of_pos[i] = b; }
@@ -395,7 +397,8 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     // 2. greedy tiling along the curve: tile = a run [begin, end) of the sorted tets
     std::vector<int32_t> slot_of(nv, -1);
     std::vector<int32_t> touched;
-    struct Run { uint32_t begin, end; bool ghost; };
+    struct Run { uint32_t begin, end; bool ghost; uint8_t cls; };
+    auto cls_of = [&](uint32_t sorted_pos) -> uint8_t { return tet_class ? tet_class[B.tet_perm[sorted_pos]] : 0; };
     std::vector<Run> runs;
     {
         uint32_t i = 0;
@@ -403,7 +406,7 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
             const uint32_t t0 = i;
             touched.clear();
             bool ghost = false;
-            while (i < nt && i - t0 < kMaxTets && body_of_pos[i] == body_of_pos[t0]) {   // a tile never spans two bodies
+            while (i < nt && i - t0 < kMaxTets && body_of_pos[i] == body_of_pos[t0] && cls_of(i) == cls_of(t0)) {   // a tile never spans two bodies, nor two tet classes
                 const int32_t* t = &tets[4 * B.tet_perm[i]];
                 uint32_t fresh = 0;
                 for (int k = 0; k < 4; k++) {
@@ -415,16 +418,16 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
                 for (int k = 0; k < 4; k++)
                     if (slot_of[t[k]] < 0) {
                         slot_of[t[k]] = 0; touched.push_back(t[k]);
-                        ghost |= static_cast<uint32_t>(t[k]) >= nv_sum || static_cast<uint32_t>(t[k]) < nv_boundary;   // halo-side
+                        ghost |= static_cast<uint32_t>(t[k]) >= nv_owned || static_cast<uint32_t>(t[k]) < nv_boundary;   // halo-side
                     }
                 i++;
             }
             for (int32_t v : touched) slot_of[v] = -1;
-            runs.push_back({t0, i, ghost});
+            runs.push_back({t0, i, ghost, cls_of(t0)});
         }
     }
     // tiles that touch a ghost or a boundary particle go last: a partitioned body solves the others while the halo is in flight
-    std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.ghost < b.ghost; });
+    std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.cls != b.cls ? a.cls < b.cls : a.ghost < b.ghost; });
     {
         std::vector<int32_t> perm2(nt);
         uint32_t o = 0;
@@ -445,7 +448,8 @@ void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t
     std::vector<std::vector<uint32_t>> vert_partials(nv_sum);
     for (const Run& r : runs) {
         const uint32_t t0 = r.begin, i = r.end;
-        if (!r.ghost) B.num_interior_blocks++;
+        if (!r.ghost && r.cls == 0) B.num_interior_blocks++;
+        if (r.cls <= 1) B.num_first_blocks++;
         touched.clear();
         for (uint32_t j = t0; j < i; j++)
             for (int k = 0; k < 4; k++) {

@@ -121,6 +121,7 @@ struct BlockPlan {
     uint32_t nv_pad = 0;
     uint32_t max_tile_verts = 0, max_partials = 0;
     uint32_t num_interior_blocks = 0;    // tiles [0, num_interior_blocks) touch no ghost (id >= nv_sum) and no boundary particle
+    uint32_t num_first_blocks = 0;       // tiles [0, num_first_blocks) hold tets of classes 0 and 1; the rest (two-layer ghost regions) the second-layer ghost tets
 };
 // `inc` (build_incidence) decides WHICH (tet,corner) contributions count (reference quirk / cap); contributions
 // it drops are left out of lc_ent.  Only vertices < nv_sum get vp lists (the owned ones).
@@ -131,9 +132,16 @@ struct BlockPlan {
 // "halo-side" -- ordered last, counted out of num_interior_blocks -- if it touches a ghost (id >= nv_sum) OR a boundary particle:
 // then every tile that contributes to a boundary particle is halo-side, and the halo queue can finish the boundary particles
 // and start the transfer without waiting for the interior tiles.
+// Partitions: tet_class[e] (0..2) keeps tets of different classes in different tiles, class after class.  1 = the tets that touch a
+// boundary or a ghost particle: with tiles of their own the halo-side tiles are exactly those tets -- two or three cell layers
+// along an interface instead of every cube-shaped tile that happens to reach it (14.5% -> 7% of a 1 M-tet slab's tets on the halo
+// queue's critical chain).  2 = the second-layer ghost tets of a two-layer ghost region, ordered last (solved on every other substep
+// only); nv_owned (default nv_sum) is then smaller than nv_sum -- the first ghost layer is summed here too -- and "halo-side" means
+// touching a particle >= nv_owned or < nv_boundary.
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet = nullptr,
-                  const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1, uint32_t nv_boundary = 0);
+                  const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1, uint32_t nv_boundary = 0,
+                  const uint8_t* tet_class = nullptr, uint32_t nv_owned = 0xffffffffu);
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 

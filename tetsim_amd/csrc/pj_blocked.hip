@@ -199,7 +199,9 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
         }
     } else if constexpr (kAlt) {
-        pos_stage = vid >= d.nv_owned ? d.ghost_alt[vid - d.nv_owned] : d.pos_pred[vid];
+        const uint32_t g = vid - d.nv_owned;   // (ghost index; two-layer regions keep the layers in separate buffers)
+        const float4* src = vid >= d.nv_owned ? (g < d.n_ghost1 ? d.ghost_alt + g : d.ghost2 + (g - d.n_ghost1)) : d.pos_pred + vid;
+        pos_stage = *src;
     } else {
         pos_stage = d.pos_pred[vid];
     }
@@ -603,11 +605,22 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
         // peer-to-peer halo: the prediction also goes straight into the ghost range of every neighbour that reads this particle
         // (write-through, system scope: peer memory over xGMI, or this device's own memory for partitions sharing a GPU).  The
         // "it is there" word follows when the next kernel of this queue starts (pjb_wait_peers_kernel).
+        const float4 pred4 = make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f), fin4 = make_float4(o.p.x, o.p.y, o.p.z, 0.0f);
         const uint32_t* col = peer->slots + v;
         for (uint32_t c = 0; c < peer->cols; c++) {
             const uint32_t e = col[static_cast<size_t>(c) * peer->stride];
-            for (uint32_t k = 0; k < peer->n; k++)   // (the store wants a wave-uniform base: one neighbour at a time, the others' lanes masked)
-                if (e != 0xffffffffu && (e >> 24) == k) store_wt(peer->ghost[k], e & 0xffffffu, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+            for (uint32_t k = 0; k < peer->n; k++) {   // (the store wants a wave-uniform base: one neighbour at a time, the others' lanes masked)
+                if (peer->ghost[k] && e != 0xffffffffu && (e >> 24) == k) store_wt(peer->ghost[k], e & 0xffffffu, pred4);
+                if (peer->fin[k] && e != 0xffffffffu && (e >> 24) == k) store_wt(peer->fin[k], e & 0xffffffu, fin4);
+            }
+        }
+        if (peer->slots2) {
+            const uint32_t* col2 = peer->slots2 + v;
+            for (uint32_t c = 0; c < peer->cols2; c++) {
+                const uint32_t e = col2[static_cast<size_t>(c) * peer->stride];
+                for (uint32_t k = 0; k < peer->n; k++)
+                    if (peer->ghost2[k] && e != 0xffffffffu && (e >> 24) == k) store_wt(peer->ghost2[k], e & 0xffffffu, pred4);
+            }
         }
     }
 }

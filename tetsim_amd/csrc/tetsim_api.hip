@@ -59,6 +59,8 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
         int32_t a = -1;  // API-local index
         if (!h->partitioned) a = global;
         else if (static_cast<size_t>(global) < h->g2l_owned.size()) a = h->g2l_owned[global];
+        // (two-layer ghost regions: a first-layer ghost is advanced here too, so a grab of its particle applies to this copy as well)
+        if (a < 0 && static_cast<size_t>(global) < h->g2l_ghost1.size()) a = h->g2l_ghost1[global];
         if (a < 0) return -1;
         return h->api2dev.empty() ? a : static_cast<int32_t>(h->api2dev[a]);
     };
@@ -166,6 +168,7 @@ void nh_sweep(tetsim_body* h, bool fold) {
 // that ends a substep with the prediction that starts the next one)
 int enqueue_substep(tetsim_body* h, bool first, bool last) {
     if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
+        if (h->deep && !h->p2p) return fail(h, TETSIM_ESTATE, "a body with a two-layer ghost region steps through the peer-to-peer halo only: call tetsim_halo_p2p_export / _connect first");
         if (has_transport(h)) {
             int rc = enqueue_phase_a(h);
             if (!rc) rc = enqueue_phase_b(h);
@@ -197,6 +200,9 @@ int ensure_prediction(tetsim_body* h, double dt) {
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return 0;
     const float fdt = static_cast<float>(dt);
     if (!h->pred_any_dt && fdt != h->dt_pred) {
+        if (h->deep)
+            return fail(h, TETSIM_ESTATE, "dt changed between calls on a body with a two-layer ghost region (TETSIM_FLAG_DEEP_GHOSTS): its neighbours hold predictions "
+                                          "made with the old dt for up to two substeps; keep dt fixed");
         if (h->p2p && !h->comm && h->group.empty())
             return fail(h, TETSIM_ESTATE, "dt changed between calls on a body whose only transport is the peer-to-peer halo: nothing refreshes the neighbours' ghost "
                                           "predictions (keep dt fixed, or connect on top of an RCCL communicator, which carries the refresh exchange)");

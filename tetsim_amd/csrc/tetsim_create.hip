@@ -11,9 +11,19 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     std::vector<int32_t> l2g_v, l2g_t;
     uint32_t nvl = nv, nvo = nv, nvb = 0, ntl = nt;
     h->partitioned = o.part_count > 1;
+    h->deep = h->partitioned && (o.flags & TETSIM_FLAG_DEEP_GHOSTS);
+    if ((o.flags & TETSIM_FLAG_DEEP_GHOSTS) && !(h->partitioned && h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION)))
+        return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_DEEP_GHOSTS needs a partitioned POLAR_JACOBI body in the blocked FAST formulation");
+    uint32_t nvg1 = 0;   // first-layer ghosts that this partition advances itself (two-layer ghost regions)
     if (h->partitioned) {
-        std::string e = build_partition(tets, nt, nv, o.part_count, o.part_index, o.vert_owner, &h->part);
+        std::string e = build_partition(tets, nt, nv, o.part_count, o.part_index, o.vert_owner, &h->part, h->deep ? 2 : 1);
         if (!e.empty()) return fail(h, TETSIM_EINVAL, e);
+        if (h->deep) {
+            nvg1 = h->part.n_ghost1;
+            h->n_ghost1 = nvg1;
+            h->g2l_ghost1.assign(nv, -1);
+            for (uint32_t i = 0; i < nvg1; i++) h->g2l_ghost1[h->part.local_to_global_vert[h->part.n_owned + i]] = static_cast<int32_t>(h->part.n_owned + i);
+        }
         const Partition& P = h->part;
         ltets = P.local_tets;
         l2g_v = P.local_to_global_vert;
@@ -75,7 +85,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     }
     // Only owned vertices are averaged here; the table rows of ghosts are never read.
     uint32_t maxv = 0;
-    for (uint32_t v = 0; v < nvo; v++) maxv = std::max(maxv, inc.offset[v + 1] - inc.offset[v]);
+    for (uint32_t v = 0; v < nvo + nvg1; v++) maxv = std::max(maxv, inc.offset[v + 1] - inc.offset[v]);
 
     PJDev& d = h->pj;
     d.nv_local = nvl; d.nv_owned = nvo; d.nv_boundary = nvb; d.nt = ntl;
@@ -118,9 +128,27 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
     if (h->blocked) {
         BlockPlan B;
-        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
-                     batch ? h->batch_first_vert.data() : nullptr, bodies, nvb);
+        // partitions: the tets that touch a boundary or a ghost particle get tiles of their own (class 1), and so do the second-layer
+        // ghost tets of a two-layer ghost region (class 2) -- host_prep.h.  TETSIM_HALO_ALIGNED_TILES=0 (read here): the round-2 tiling,
+        // where every tile that reaches the interface is halo-side (A/B)
+        std::vector<uint8_t> tet_class;
+        if (h->partitioned) {
+            const char* e = getenv("TETSIM_HALO_ALIGNED_TILES");
+            const bool aligned = !(e && e[0] == '0');
+            tet_class.assign(ntl, 0);
+            for (uint32_t i = 0; i < ntl; i++) {
+                if (h->deep && h->part.tet_layer[i]) { tet_class[i] = 2; continue; }
+                if (!aligned) continue;
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t v = static_cast<uint32_t>(ltets[4ull * i + c]);
+                    if (v < nvb || v >= nvo) tet_class[i] = 1;
+                }
+            }
+        }
+        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo + nvg1, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
+                     batch ? h->batch_first_vert.data() : nullptr, bodies, nvb, h->partitioned ? tet_class.data() : nullptr, nvo);
         h->tet_perm = B.tet_perm;
+        h->nb_first = B.num_first_blocks;
         // the two-queue halo path (tetsim_halo.hip) rests on this: an interior tile touches neither a ghost nor a boundary particle
         for (uint32_t b = 0; b < B.num_interior_blocks; b++)
             for (uint32_t e = B.blk_tet_off[b]; e < B.blk_tet_off[b + 1]; e++)
@@ -192,7 +220,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                     slot_w[v0 + u] = w;
                 }
             }
-            for (uint32_t v = 0; v < nvo; v++) {
+            for (uint32_t v = 0; v < nvo + nvg1; v++) {
                 float w = 0.0f;
                 for (uint32_t j = 0; j < B.max_partials; j++) {
                     const uint32_t idx = B.vp_ell[static_cast<size_t>(j) * B.nv_pad + v];

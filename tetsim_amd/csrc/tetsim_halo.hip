@@ -43,6 +43,7 @@ int rccl_fail(tetsim_body* h, ncclResult_t r, const char* what) {
 //   the next substep's first ghost-reading tet kernel waits for every neighbour's sent[p] -- and for OUR sent[p], because
 //   our next boundary pass overwrites the very buffer our transfer reads
 int halo_start(tetsim_body* h) {
+    if (h->deep) return fail(h, TETSIM_ESTATE, "bodies with a two-layer ghost region exchange their ghosts through the peer-to-peer halo only");
     const uint32_t p = h->halo_parity;
     if (h->flag_sync) {  // the halo stream ran this substep's boundary particles itself: stay in stream order
         for (auto& nb : h->neigh)
@@ -131,6 +132,7 @@ bool uses_flag_sync(const tetsim_body* h) {
 // In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
+    if (h->deep && !h->p2p) return fail(h, TETSIM_ESTATE, "a body with a two-layer ghost region steps through the peer-to-peer halo only: call tetsim_halo_p2p_export / _connect first");
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));  // in-process groups may span devices: streams, events and lazy allocations below are per device
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
@@ -170,6 +172,77 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                                                        v_open && h->blk.nb_interior ? yv.flag : nullptr); }
             PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
             if (h->d_params_halo) kb.params = h->d_params_halo;
+            if (h->p2p && h->deep) {
+                // Two-layer ghost region: ghosts cross only every other substep (the algorithm is
+                // tests/test_partition_gloo.py's).  r = substeps since the connection, set = (r / 2) & 1 the exchange's buffer set.
+                //   EVEN r:  wait [V, arrived(set, even)] - tiles: halo-side + second-layer ghost tets, ghosts from the set's EVEN buffers -
+                //            boundary particles [their second-layer share -> the neighbours' ODD buffer of this set: the early message] -
+                //            first ghost layer, advanced here (previous positions: the set's g1_final)
+                //   ODD r:   wait [V; raises the early message's word] - halo-side tiles (first-layer ghosts: the local predictions) -
+                //            boundary particles [both layers -> the neighbours' EVEN buffers of the NEXT set, + end-of-substep positions of
+                //            their first layer: the one message on the critical chain] - wait [raises its word at once; the neighbours'
+                //            early message] - second-layer ghost tets evolved after the fact (ghosts: local first layer, ODD buffer)
+                // Nothing a neighbour stores can hit a buffer still being read: its next store into a set needs this rank's next
+                // message, which this rank's queue sends behind the reads.
+                const uint64_t r = h->p2p_round;
+                const uint32_t par = static_cast<uint32_t>(r & 1u), set = static_cast<uint32_t>((r >> 1) & 1u);
+                const uint32_t nvo = h->pj.nv_owned, ng1 = h->n_ghost1;
+                const bool group = !h->group.empty();
+                auto own_word = [&](uint32_t st, uint32_t pr, size_t i) { return h->d_arrived + (st * 2u + pr) * kMaxPeers + i; };
+                auto raise_list = [&](PJPeerSync& w, uint32_t st, uint32_t pr) { for (const PeerLink& l : h->links) if (l.arrived2[st][pr]) w.raise[w.n_raise++] = l.arrived2[st][pr]; };
+                const uint32_t delay_us = h->loopback ? [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_DELAY_US"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 0u; }() : 0u;
+                PJPeerSync w;
+                if (h->p2p_raise_pending) raise_list(w, set, 1u);   // (only an even substep leaves a raise behind: its early message)
+                h->p2p_raise_pending = false;
+                if (par == 0u && r > 0)
+                    for (size_t i = 0; i < h->neigh.size(); i++)
+                        if (h->neigh[i].recv_count || h->part.neigh[i].recv2_count) w.wait[w.n_wait++] = own_word(set, 0u, i);
+                if (par == 0u) w.delay_us = delay_us;   // (loopback measurements: the message on the critical chain arrives later)
+                PJSync yw = yv;
+                if (!(v_open && h->blk.nb_interior)) yw.flag = nullptr;
+                if (yw.flag || w.n_raise || w.n_wait) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
+                PJPeer pr;
+                pr.slots = h->d_peer_slots; pr.cols = h->p2p_cols; pr.stride = h->p2p_stride; pr.n = static_cast<uint32_t>(h->links.size());
+                pr.slots2 = h->d_peer_slots2; pr.cols2 = h->p2p_cols2;
+                kb.n_ghost1 = ng1;
+                if (par == 0u) {
+                    kb.ghost_alt = h->own_g1_even[set]; kb.ghost2 = h->own_g2_even[set];
+                    { HP("launch tet halo-side + second layer"); pjb_launch_tet_alt(h->comm_stream, kb, h->blk.nb_interior, h->blk.nb - h->blk.nb_interior); }
+                    for (size_t i = 0; i < h->links.size(); i++) pr.ghost2[i] = h->links[i].g2_odd[set];
+                    if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+                    else { HP("launch vertex boundary"); pjb_launch_vertex_peer(h->comm_stream, kb, 0, nvb, pr, yg.flag); }
+                    PJBlk kg = kb;   // the first ghost layer: previous positions from the set's g1_final (indexed by particle id)
+                    kg.fin_in = h->own_g1_final[set] - nvo;
+                    { HP("launch vertex first ghost layer"); pjb_launch_vertex(h->comm_stream, kg, nvo, ng1); }
+                    h->p2p_raise_pending = true;
+                    if (group) {   // (ranks of one process: the raise gets a kernel of its own, see the one-layer branch)
+                        PJPeerSync sg;
+                        raise_list(sg, set, 1u);
+                        PJSync none;
+                        none.error = yg.error;
+                        pjb_launch_wait_peers(h->comm_stream, none, sg);
+                        h->p2p_raise_pending = false;
+                    }
+                } else {
+                    { HP("launch tet halo-side"); pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, h->nb_first - h->blk.nb_interior); }
+                    for (size_t i = 0; i < h->links.size(); i++) { pr.ghost[i] = h->links[i].g1_even[set ^ 1u]; pr.fin[i] = h->links[i].g1_final[set ^ 1u]; pr.ghost2[i] = h->links[i].g2_even[set ^ 1u]; }
+                    if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
+                    else { HP("launch vertex boundary"); pjb_launch_vertex_peer(h->comm_stream, kb, 0, nvb, pr, yg.flag); }
+                    PJPeerSync wl;   // its first thread tells the neighbours "your even buffers of the next set are full"; then the early message
+                    raise_list(wl, set ^ 1u, 0u);
+                    for (size_t i = 0; i < h->neigh.size(); i++) if (h->part.neigh[i].recv2_count) wl.wait[wl.n_wait++] = own_word(set, 1u, i);
+                    PJSync ye;
+                    ye.error = yg.error; ye.timeout_ms = yg.timeout_ms;
+                    { HP("raise + wait early message"); pjb_launch_wait_peers(h->comm_stream, ye, wl); }
+                    kb.ghost_alt = h->pj.pos_pred + nvo; kb.ghost2 = h->own_g2_odd[set];
+                    { HP("evolve second-layer tets"); pjb_launch_tet_alt(h->comm_stream, kb, h->nb_first, h->blk.nb - h->nb_first); }
+                }
+                h->p2p_round++;
+                { HP("wait G"); pjb_launch_wait(h->stream, yg); }
+                { HP("launch vertex interior"); pj_vertex(h, nvb, nvo - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+                h->v_pending = true;
+                return 0;
+            }
             if (h->p2p) {
                 // Peer-to-peer halo: no transfer.  Substep r reads its ghosts from buffer r & 1, which the neighbours' boundary-particle
                 // kernels of substep r - 1 filled; this rank's boundary-particle kernel fills THEIR buffers (r + 1) & 1.  One wave in
@@ -268,7 +341,10 @@ int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of 
     if (h->p2p) {   // ... and the "arrived" words of the last boundary-particle kernel, which no following substep's wait will raise
         PJPeerSync w;
         const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
-        if (h->p2p_raise_pending) for (const PeerLink& l : h->links) if (l.arrived[par]) w.raise[w.n_raise++] = l.arrived[par];
+        if (h->p2p_raise_pending && h->deep) {   // (an even substep's early message: set of the substep just enqueued)
+            const uint32_t st = static_cast<uint32_t>(((h->p2p_round - 1u) >> 1) & 1u);
+            for (const PeerLink& l : h->links) if (l.arrived2[st][1]) w.raise[w.n_raise++] = l.arrived2[st][1];
+        } else if (h->p2p_raise_pending) for (const PeerLink& l : h->links) if (l.arrived[par]) w.raise[w.n_raise++] = l.arrived[par];
         if (!h->v_pending) yv.flag = nullptr;
         { HP("wait V + raise peers"); pjb_launch_wait_peers(h->comm_stream, yv, w); }
         h->p2p_raise_pending = false;
@@ -330,7 +406,7 @@ int probe_queue_independence(tetsim_body* h) {
 // 2.7 us of an eager launch, and the host enqueues two graph launches per call instead of 9 operations per substep.
 int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
     // (peer-to-peer bodies: the chain of a call depends on the parity of its first substep -- which ghost buffer, which words)
-    const uint32_t key = n | (h->p2p && (h->p2p_round & 1u) ? 0x80000000u : 0u);
+    const uint32_t key = n | (h->p2p ? static_cast<uint32_t>(h->p2p_round & (h->deep ? 3u : 1u)) << 30 : 0u);
     auto it = h->flag_graphs.find(key);
     if (it == h->flag_graphs.end()) {
         hipGraph_t gm = nullptr, gh = nullptr;
@@ -593,11 +669,12 @@ namespace {
 struct P2PBlob {   // what a rank tells the others about its buffers (TETSIM_P2P_BLOB_BYTES)
     uint32_t magic, rank, part_count, device;
     uint64_t pid;
-    uint32_t nv_owned, nv_local, n_neigh, pad;
+    uint32_t nv_owned, nv_local, n_neigh, n_ghost1;             // n_ghost1: 0xffffffff = one ghost layer
     hipIpcMemHandle_t h_pred, h_alt, h_arrived;                 // IPC handles of pos_pred / ghost_alt / the "arrived" words
     uint64_t p_pred, p_alt, p_arrived;                          // ... and the plain pointers (ranks of the same process)
-    struct { int32_t rank; uint32_t recv_start, recv_count; } neigh[kMaxPeers];
+    struct { int32_t rank; uint32_t recv_start, recv_count, recv2_start, recv2_count; } neigh[kMaxPeers];
 };
+constexpr uint32_t kArrivedWords = 4 * kMaxPeers;               // [set][parity][neighbour]; one-layer bodies use the first 2 * kMaxPeers as [parity][neighbour]
 static_assert(sizeof(P2PBlob) <= TETSIM_P2P_BLOB_BYTES, "blob too large");
 constexpr uint32_t kP2PMagic = 0x50325054u;
 }  // namespace
@@ -609,11 +686,21 @@ int tetsim_halo_p2p_export(tetsim_handle h, void* blob) {
     if (h->neigh.size() > kMaxPeers) return fail(h, TETSIM_ESTATE, "the peer-to-peer halo supports at most 8 neighbours per partition");
     HIPCHK(h, hipSetDevice(h->opt.device));
     const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
+    const uint32_t ng1 = h->deep ? h->n_ghost1 : ng, ng2 = ng - ng1;
     if (!h->ghost_alt) {
         int rc;
-        if ((rc = dev_alloc(h, &h->ghost_alt, ng))) return rc;
-        if ((rc = dev_alloc(h, &h->d_arrived, 2 * kMaxPeers))) return rc;
-        HIPCHK(h, hipMemset(h->d_arrived, 0, 2 * kMaxPeers * sizeof(uint32_t)));
+        // one ghost layer: the second (odd-substep) ghost buffer.  Two layers: the eight receive buffers in one allocation,
+        // [g1_even x2 | g1_final x2 | g2_even x2 | g2_odd x2]
+        if ((rc = dev_alloc(h, &h->ghost_alt, h->deep ? 4ull * ng1 + 4ull * ng2 : ng))) return rc;
+        if (h->deep)
+            for (uint32_t st = 0; st < 2; st++) {
+                h->own_g1_even[st] = h->ghost_alt + static_cast<size_t>(st) * ng1;
+                h->own_g1_final[st] = h->ghost_alt + (2ull + st) * ng1;
+                h->own_g2_even[st] = h->ghost_alt + 4ull * ng1 + static_cast<size_t>(st) * ng2;
+                h->own_g2_odd[st] = h->ghost_alt + 4ull * ng1 + (2ull + st) * ng2;
+            }
+        if ((rc = dev_alloc(h, &h->d_arrived, kArrivedWords))) return rc;
+        HIPCHK(h, hipMemset(h->d_arrived, 0, kArrivedWords * sizeof(uint32_t)));
         // where each boundary particle goes: (neighbour, position in that neighbour's ghost run for this rank), ELL by particle
         const uint32_t nvb = h->pj.nv_boundary;
         std::vector<std::vector<uint32_t>> per(nvb);
@@ -631,19 +718,40 @@ int tetsim_halo_p2p_export(tetsim_handle h, void* blob) {
         for (uint32_t v = 0; v < nvb; v++) for (size_t c = 0; c < per[v].size(); c++) ell[c * h->p2p_stride + v] = per[v][c];
         if ((rc = dev_alloc(h, &h->d_peer_slots, ell.size()))) return rc;
         if ((rc = upload(h, h->d_peer_slots, ell))) return rc;
+        if (h->deep) {   // the same table for the neighbours' SECOND layer
+            std::vector<std::vector<uint32_t>> per2(nvb);
+            for (size_t k = 0; k < h->part.neigh.size(); k++)
+                for (size_t j = 0; j < h->part.neigh[k].send2_local.size(); j++) {
+                    const uint32_t api = static_cast<uint32_t>(h->part.neigh[k].send2_local[j]);
+                    const uint32_t dv = h->api2dev.empty() ? api : h->api2dev[api];
+                    if (dv >= nvb) return fail(h, TETSIM_ESTATE, "internal error: a sent particle is not a boundary particle");
+                    per2[dv].push_back((static_cast<uint32_t>(k) << 24) | static_cast<uint32_t>(j));
+                }
+            uint32_t cols2 = 1;
+            for (auto& v : per2) cols2 = std::max<uint32_t>(cols2, static_cast<uint32_t>(v.size()));
+            h->p2p_cols2 = cols2;
+            std::vector<uint32_t> ell2(static_cast<size_t>(cols2) * h->p2p_stride, 0xffffffffu);
+            for (uint32_t v = 0; v < nvb; v++) for (size_t c = 0; c < per2[v].size(); c++) ell2[c * h->p2p_stride + v] = per2[v][c];
+            if ((rc = dev_alloc(h, &h->d_peer_slots2, ell2.size()))) return rc;
+            if ((rc = upload(h, h->d_peer_slots2, ell2))) return rc;
+        }
     }
     P2PBlob b;
     std::memset(&b, 0, sizeof b);
     b.magic = kP2PMagic; b.rank = static_cast<uint32_t>(h->opt.part_index); b.part_count = static_cast<uint32_t>(h->opt.part_count);
     b.device = static_cast<uint32_t>(h->opt.device); b.pid = static_cast<uint64_t>(getpid());
     b.nv_owned = nvo; b.nv_local = h->pj.nv_local; b.n_neigh = static_cast<uint32_t>(h->neigh.size());
+    b.n_ghost1 = h->deep ? ng1 : 0xffffffffu;
     b.p_pred = reinterpret_cast<uint64_t>(h->pj.pos_pred); b.p_alt = reinterpret_cast<uint64_t>(h->ghost_alt); b.p_arrived = reinterpret_cast<uint64_t>(h->d_arrived);
     // (a handle can only be opened by ANOTHER process; failing to make one is not an error for ranks of one process)
     (void)hipIpcGetMemHandle(&b.h_pred, h->pj.pos_pred);
     (void)hipIpcGetMemHandle(&b.h_alt, h->ghost_alt);
     (void)hipIpcGetMemHandle(&b.h_arrived, h->d_arrived);
     (void)hipGetLastError();
-    for (size_t k = 0; k < h->neigh.size(); k++) { b.neigh[k].rank = h->neigh[k].rank; b.neigh[k].recv_start = h->neigh[k].recv_start; b.neigh[k].recv_count = h->neigh[k].recv_count; }
+    for (size_t k = 0; k < h->neigh.size(); k++) {
+        b.neigh[k].rank = h->neigh[k].rank; b.neigh[k].recv_start = h->neigh[k].recv_start; b.neigh[k].recv_count = h->neigh[k].recv_count;
+        if (h->deep) { b.neigh[k].recv2_start = h->part.neigh[k].recv2_start; b.neigh[k].recv2_count = h->part.neigh[k].recv2_count; }
+    }
     std::memset(blob, 0, TETSIM_P2P_BLOB_BYTES);
     std::memcpy(blob, &b, sizeof b);
     return 0;
@@ -668,9 +776,17 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
-    // both ghost buffers start from the ghosts as they are now (the last exchange of the previous transport, or the rest pose)
-    if (ng) HIPCHK(h, hipMemcpy(h->ghost_alt, h->pj.pos_pred + nvo, ng * sizeof(float4), hipMemcpyDeviceToDevice));
-    HIPCHK(h, hipMemset(h->d_arrived, 0, 2 * kMaxPeers * sizeof(uint32_t)));
+    const uint32_t ng1 = h->deep ? h->n_ghost1 : ng, ng2 = ng - ng1;
+    if (h->deep) {
+        // the first substep after the connection is an EVEN one of exchange set 0: its ghosts are the ghosts as they are now
+        if (ng1) HIPCHK(h, hipMemcpy(h->own_g1_even[0], h->pj.pos_pred + nvo, ng1 * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (ng1) HIPCHK(h, hipMemcpy(h->own_g1_final[0], h->pj.pos_final + nvo, ng1 * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (ng2) HIPCHK(h, hipMemcpy(h->own_g2_even[0], h->pj.pos_pred + nvo + ng1, ng2 * sizeof(float4), hipMemcpyDeviceToDevice));
+    } else if (ng) {
+        // both ghost buffers start from the ghosts as they are now (the last exchange of the previous transport, or the rest pose)
+        HIPCHK(h, hipMemcpy(h->ghost_alt, h->pj.pos_pred + nvo, ng * sizeof(float4), hipMemcpyDeviceToDevice));
+    }
+    HIPCHK(h, hipMemset(h->d_arrived, 0, kArrivedWords * sizeof(uint32_t)));
     const char* all = static_cast<const char*>(blobs);
     std::vector<PeerLink> links(h->neigh.size());
     for (size_t k = 0; k < h->neigh.size(); k++) {
@@ -678,14 +794,18 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
         P2PBlob pb;
         std::memcpy(&pb, all + static_cast<size_t>(h->loopback ? 0 : nb.rank) * TETSIM_P2P_BLOB_BYTES, sizeof pb);
         if (pb.magic != kP2PMagic || (!h->loopback && static_cast<int>(pb.rank) != nb.rank)) return fail(h, TETSIM_EINVAL, "bad peer blob for rank " + std::to_string(nb.rank));
-        if (!nb.send_count) continue;
+        const uint32_t send2 = h->deep ? static_cast<uint32_t>(h->part.neigh[k].send2_local.size()) : 0u;
+        if (!nb.send_count && !send2) continue;
+        if ((pb.n_ghost1 != 0xffffffffu) != h->deep) return fail(h, TETSIM_ESTATE, "ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank) + " disagree on the depth of the ghost region");
         // this rank's run in the neighbour's ghost range, and this rank's slot among the neighbour's neighbours
-        uint32_t start = 0, cnt = 0, slot = kMaxPeers;
-        if (h->loopback) { start = nb.recv_start; cnt = nb.recv_count; slot = static_cast<uint32_t>(k); }
-        else
+        uint32_t start = 0, cnt = 0, start2 = 0, cnt2 = 0, slot = kMaxPeers;
+        if (h->loopback) {
+            start = nb.recv_start; cnt = nb.recv_count; slot = static_cast<uint32_t>(k);
+            if (h->deep) { start2 = h->part.neigh[k].recv2_start; cnt2 = h->part.neigh[k].recv2_count; }
+        } else
             for (uint32_t j = 0; j < pb.n_neigh && j < kMaxPeers; j++)
-                if (pb.neigh[j].rank == h->opt.part_index) { start = pb.neigh[j].recv_start; cnt = pb.neigh[j].recv_count; slot = j; }
-        if (slot == kMaxPeers || cnt != nb.send_count) return fail(h, TETSIM_ESTATE, "asymmetric halo plan between ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank));
+                if (pb.neigh[j].rank == h->opt.part_index) { start = pb.neigh[j].recv_start; cnt = pb.neigh[j].recv_count; start2 = pb.neigh[j].recv2_start; cnt2 = pb.neigh[j].recv2_count; slot = j; }
+        if (slot == kMaxPeers || cnt != nb.send_count || cnt2 != send2) return fail(h, TETSIM_ESTATE, "asymmetric halo plan between ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank));
         float4 *pred = nullptr, *alt = nullptr;
         uint32_t* arr = nullptr;
         if (pb.pid == static_cast<uint64_t>(getpid())) {   // same process: plain pointers (peer access if the devices differ)
@@ -701,6 +821,18 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
             HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[1], pb.h_alt, hipIpcMemLazyEnablePeerAccess));
             HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[2], pb.h_arrived, hipIpcMemLazyEnablePeerAccess));
             pred = static_cast<float4*>(l.ipc[0]); alt = static_cast<float4*>(l.ipc[1]); arr = static_cast<uint32_t*>(l.ipc[2]);
+        }
+        if (h->deep) {
+            const size_t pg1 = pb.n_ghost1, pg2 = pb.nv_local - pb.nv_owned - pb.n_ghost1;
+            const size_t r1 = start - pb.nv_owned, r2 = start2 - pb.nv_owned - pb.n_ghost1;   // this rank's runs in the neighbour's layers
+            for (uint32_t st = 0; st < 2; st++) {
+                links[k].g1_even[st] = alt + st * pg1 + r1;
+                links[k].g1_final[st] = alt + (2 + st) * pg1 + r1;
+                links[k].g2_even[st] = alt + 4 * pg1 + st * pg2 + r2;
+                links[k].g2_odd[st] = alt + 4 * pg1 + (2 + st) * pg2 + r2;
+                for (uint32_t par = 0; par < 2; par++) links[k].arrived2[st][par] = arr + (st * 2 + par) * kMaxPeers + slot;
+            }
+            continue;
         }
         links[k].ghost[0] = pred + start;                       // even substeps read pos_pred's tail
         links[k].ghost[1] = alt + (start - pb.nv_owned);        // odd ones the second buffer

@@ -21,12 +21,14 @@ v, t = make_lattice(cells, nz=cells * 3)
 plane = (cells + 1) ** 2
 owner = np.minimum((np.arange(len(v)) // plane) // cells, 2).astype(np.int32)
 owner[(np.arange(len(v)) // plane) >= 2 * cells] = 2
-mid = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=3, part_index=1, vert_owner=owner, ref_fixed_bounds=False)
+DEEP = bool(os.environ.get("LOOPBACK_DEEP"))   # a two-layer ghost region: ghosts cross every other substep (needs the peer-to-peer halo)
+mid = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=3, part_index=1, vert_owner=owner, ref_fixed_bounds=False, deep_ghosts=DEEP)
 comm_init(mid, comm_unique_id(), 0, 1)
-if os.environ.get("LOOPBACK_P2P"):   # the peer-to-peer halo instead of RCCL's grouped send/recv (the rank stores into its own ghost ranges)
-    mid.simulateSubsteps(2, DT, PP)
+if os.environ.get("LOOPBACK_P2P") or DEEP:   # the peer-to-peer halo instead of RCCL's grouped send/recv (the rank stores into its own ghost ranges)
+    if not DEEP:
+        mid.simulateSubsteps(2, DT, PP)
     p2p_connect(mid, [p2p_export(mid)])
-TRANSPORT = "peer-to-peer stores" if comm_info(mid)["p2p"] else "RCCL send/recv"
+TRANSPORT = ("peer-to-peer, two-layer ghosts" if DEEP else "peer-to-peer stores") if comm_info(mid)["p2p"] else "RCCL send/recv"
 print("middle slab: %d owned particles, %d local tets (%d owned), %d neighbours" % (mid.info.owned_particles, mid.info.local_elems, mid.info.owned_elems, mid.info.num_neighbours))
 pr = mid.profile(2, DT, PP)
 print("interior tet kernel: %d of %d local tets (the rest, %.1f%%, are in halo-side tiles: they touch a ghost or a boundary particle)" % (
