@@ -17,6 +17,10 @@ import pytest
 # have version s + 1, the particle passes of substep s take the predictions to version s + 1
 PRED_B, PRED_I, PRED_G, PART_H, PART_I = "pred boundary", "pred interior", "pred ghost", "partial halo-side", "partial interior"
 PRED_G1 = "pred ghost (second buffer)"   # peer-to-peer halo: the ghosts of odd substeps
+# two-layer ghost regions: the first ghost layer's local predictions, the second-layer ghost tets' state, and the receive buffers
+# (even-substep data / the early, odd-substep data), two sets each
+G1_LOCAL, L2_STATE, EVEN_SET, ODD_SET = "pred first layer (local)", "second-layer tet state", ("even buffers set 0", "even buffers set 1"), ("odd buffer set 0", "odd buffer set 1")
+DEEP_BUFS = (G1_LOCAL, L2_STATE) + EVEN_SET + ODD_SET
 
 
 def rank_program(calls):
@@ -70,14 +74,15 @@ def explore(calls, mutate=None, program=None):
         progs = [mutate(p) for p in progs]
     queues = [progs[0][0], progs[0][1], progs[1][0], progs[1][1]]   # rank = q // 2
     total = sum(abs(n) for n in calls)
-    bufs = (PRED_B, PRED_I, PRED_G, PART_H, PART_I, PRED_G1)
+    bufs = (PRED_B, PRED_I, PRED_G, PART_H, PART_I, PRED_G1) + DEEP_BUFS
     version0 = tuple((0,) * len(bufs) for _ in range(2))           # [rank][buffer]
     # state: (pc per queue, running flag per queue, words per rank (G, V, D, A0, A1), versions)
-    start = ((0, 0, 0, 0), (False,) * 4, ((0,) * 5, (0,) * 5), version0)
+    start = ((0, 0, 0, 0), (False,) * 4, ((0,) * 9, (0,) * 9), version0)
     seen, stack = {start}, [start]
     bi = {b: i for i, b in enumerate(bufs)}
-    wi = {"G": 0, "V": 1, "D": 2, "A0": 3, "A1": 4}
+    wi = {"G": 0, "V": 1, "D": 2, "A0": 3, "A1": 4, "E0": 5, "E1": 6, "O0": 7, "O1": 8}
     p2p = program is not rank_program
+    deep = getattr(program, "deep", False)
 
     def where(r, name):   # (rank, plain name) of a buffer or word that may carry the peer prefix
         return (1 - r, name[len(PEER):]) if name.startswith(PEER) else (r, name)
@@ -93,7 +98,8 @@ def explore(calls, mutate=None, program=None):
             if any(w for r in words for w in r):
                 raise Violation("a word is still raised at the end: %r" % (words,))
             final_ghosts = (PRED_G1 if total & 1 else PRED_G) if p2p else PRED_G   # peer-to-peer: the buffer of the next substep's parity
-            if any(versions[r][bi[b]] != total for r in range(2) for b in (PRED_B, PRED_I, final_ghosts)):
+            check = (PRED_B, PRED_I) if deep else (PRED_B, PRED_I, final_ghosts)
+            if any(versions[r][bi[b]] != total for r in range(2) for b in check):
                 raise Violation("final versions %r" % (versions,))
             continue
         moves = []
@@ -300,3 +306,82 @@ def test_the_model_notices_a_broken_peer_to_peer_choreography(what, mutate):
     with pytest.raises(Violation):
         for calls in ([2], [3], [2, 2], [3, 3]):
             explore(calls, mutate, program=P2P)
+
+
+# ---- two-layer ghost region on the peer-to-peer halo (TETSIM_FLAG_DEEP_GHOSTS): ghosts cross every other substep ---------------------
+def rank_program_deep(calls, one_set=False, no_late_evolve_wait=False):
+    """Substep r, exchange e = r // 2, buffer set st = e & 1.  Even r reads the set's even buffers (version r) and leaves the second-layer
+    tet state and the local first-layer predictions at r + 1; odd r reads those predictions, stores the NEXT set's even buffers (r + 1)
+    into the peer, and then evolves the second-layer tets after the fact from the odd buffer (version r) the peer stored after ITS even
+    substep.  Words: E0 / E1 = "your even buffers of set 0 / 1 are full", O0 / O1 = the early message of set 0 / 1."""
+    main, halo = [], []
+    r = 0
+    sel = (lambda st: 0) if one_set else (lambda st: st)
+    pending = None   # an even substep's early-message raise, folded into the next kernel of the halo queue
+    for n in calls:
+        v_pending = False
+        for _ in range(n):
+            st = (r >> 1) & 1
+            main.append(("T_int(%d)" % r, {PRED_I: r}, {PART_I: r + 1}, "V" if v_pending else None, None, None, None))
+            if pending:
+                halo.append(("raise " + pending, {}, {}, PEER + pending, None, None, None))
+                pending = None
+            if v_pending:
+                halo.append(("wait V(%d)" % (r - 1), {}, {}, None, "V", None, None))
+            if r % 2 == 0:
+                if r > 0:
+                    halo.append(("wait E%d(%d)" % (sel(st), r), {}, {}, None, "E%d" % sel(st), None, None))
+                halo.append(("T_H+L2(%d)" % r, {PRED_B: r, PRED_I: r, EVEN_SET[sel(st)]: r, L2_STATE: r}, {PART_H: r + 1, L2_STATE: r + 1}, None, None, None, None))
+                halo.append(("P_b(%d)" % r, {PART_H: r + 1}, {PRED_B: r + 1, PEER + ODD_SET[sel(st)]: r + 1}, "G", None, None, None))
+                halo.append(("P_g1(%d)" % r, {PART_H: r + 1, EVEN_SET[sel(st)]: r}, {G1_LOCAL: r + 1}, None, None, None, None))
+                pending = "O%d" % sel(st)
+            else:
+                halo.append(("T_H(%d)" % r, {PRED_B: r, PRED_I: r, G1_LOCAL: r}, {PART_H: r + 1}, None, None, None, None))
+                halo.append(("P_b(%d)" % r, {PART_H: r + 1}, {PRED_B: r + 1, PEER + EVEN_SET[sel(st ^ 1)]: r + 1}, "G", None, None, None))
+                halo.append(("raise E%d" % sel(st ^ 1), {}, {}, PEER + "E%d" % sel(st ^ 1), None, None, None))
+                if not no_late_evolve_wait:
+                    halo.append(("wait O%d(%d)" % (sel(st), r), {}, {}, None, "O%d" % sel(st), None, None))
+                halo.append(("T_L2 late(%d)" % r, {G1_LOCAL: r, ODD_SET[sel(st)]: r, L2_STATE: r}, {L2_STATE: r + 1}, None, None, None, None))
+            main.append(("wait G(%d)" % r, {}, {}, None, "G", None, None))
+            main.append(("P_i(%d)" % r, {PART_H: r + 1, PART_I: r + 1}, {PRED_I: r + 1}, None, None, None, None))
+            v_pending = True
+            r += 1
+        main.append(("signal V(%d)" % (r - 1), {}, {}, "V", None, None, None))
+        if pending:
+            halo.append(("raise " + pending, {}, {}, PEER + pending, None, None, None))
+            pending = None
+        halo.append(("wait V(%d)" % (r - 1), {}, {}, None, "V", None, None))
+    # what stays raised at the end of a run is consumed by the next call: the early word after an even last substep, the even word after an odd one
+    total = sum(calls)
+    last_set = ((total - 1) >> 1) & 1
+    halo.append(("wait O%d(next call)" % sel(last_set), {}, {}, None, "O%d" % sel(last_set), None, None) if total % 2 else
+                ("wait E%d(next call)" % sel(last_set ^ 1), {}, {}, None, "E%d" % sel(last_set ^ 1), None, None))
+    return main, halo
+
+
+rank_program_deep.deep = True
+
+
+@pytest.mark.parametrize("calls", [[1], [2], [3], [4], [5], [2, 2], [1, 2, 1], [3, 2], [6]])
+def test_two_layer_ghost_choreography_every_interleaving_is_live_and_race_free(calls):
+    assert explore(calls, program=rank_program_deep) > 10 * sum(calls)
+
+
+def _variant(**kw):
+    def program(calls):
+        return rank_program_deep(calls, **kw)
+    program.deep = True
+    return program
+
+
+@pytest.mark.parametrize("what,program", [
+    # ONE set of buffers and words: a neighbour needs nothing from this rank for its odd substep, so it can store the next exchange's
+    # even buffers while this rank's tiles of the current even substep still read them
+    ("one set of buffers", _variant(one_set=True)),
+    # the second-layer tets must not be evolved before the neighbour's early message is there
+    ("late evolve without waiting for the early message", _variant(no_late_evolve_wait=True)),
+])
+def test_the_model_notices_a_broken_two_layer_choreography(what, program):
+    with pytest.raises(Violation):
+        for calls in ([2], [4], [5], [2, 2], [6]):
+            explore(calls, program=program)
