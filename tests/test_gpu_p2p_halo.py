@@ -185,11 +185,16 @@ def test_two_layer_ghost_region_tracks_the_monolithic_body_and_its_ghost_tets_tr
         v, t = load_mesh("dragon")
         v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])
         n, owner = 3, None
+        # (a gentle pull: yanking a Dragon vertex by a third of the body's size folds its tets over, the polar iteration settles on
+        # another branch from a rounding's difference, and ANY decomposition -- one ghost layer too -- is millimetres off the
+        # monolithic body at once: tools/deep_diag.py, profiles/r03_loopback.txt section 3)
+        pull = (0.02, 0.04)
     else:
         n = int(case[5:])
         cells = 16
         v, t = make_lattice(cells, y0=0.02)
         owner = np.minimum((np.arange(len(v)) // (cells + 1) ** 2) * n // (cells + 1), n - 1).astype(np.int32)
+        pull = (0.15, 0.3)
     parts = _deep_parts(v, t, n, owner)
     assert all(p.info.local_elems > q.info.local_elems for p, q in zip(parts, _parts(v, t, n, owner)))   # the second layer of ghost tets is there
     with pytest.raises(TetSimError):                                       # such a body steps through the peer-to-peer halo only
@@ -201,7 +206,7 @@ def test_two_layer_ghost_region_tracks_the_monolithic_body_and_its_ghost_tets_tr
     for k, n_sub in enumerate((20, 1, 7, 2, 20, 3, 5, 20)):              # odd call lengths: an exchange may straddle two calls
         if k == 2:
             for b in parts + [mono]:
-                b.setGrab(gid, [float(v[gid, 0]) + 0.15, float(v[gid, 1]) + 0.3, float(v[gid, 2])])
+                b.setGrab(gid, [float(v[gid, 0]) + pull[0], float(v[gid, 1]) + pull[1], float(v[gid, 2])])
         if k == 6:
             for b in parts + [mono]:
                 b.endGrab()
@@ -220,7 +225,7 @@ def test_two_layer_ghost_region_tracks_the_monolithic_body_and_its_ghost_tets_tr
     for b in parts:
         for gt, q in zip(b.localTets[:b.info.owned_elems] if False else b.localTets, b.quats):
             owner_q.setdefault(int(gt), []).append(q)
-    worst = max(float(np.abs(np.array(qs) - qs[0]).max()) for qs in owner_q.values() if len(qs) > 1)
+    worst = max(float(min(np.abs(np.array(qs) - qs[0]).max(), np.abs(np.array(qs[1:]) + qs[0]).max())) for qs in owner_q.values() if len(qs) > 1)   # (q and -q are one rotation)
     assert sum(len(qs) > 1 for qs in owner_q.values()) > 50
     within("polar fast two-layer ghosts %s ghost-tet quaternions vs owners @%d" % (case, total), worst, 2e-4)
     with pytest.raises(TetSimError):                                       # ... and cannot change dt

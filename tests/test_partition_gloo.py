@@ -180,7 +180,7 @@ def _worker_deep(rank, world, port, kind, nsteps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world,nsteps", [("slab", 2, 30), ("slab", 3, 30), ("dragon", 2, 24), ("slab", 3, 11)])
+@pytest.mark.parametrize("kind,world,nsteps", [("slab", 2, 30), ("slab", 3, 30), ("dragon", 2, 24), ("dragon", 3, 12), ("slab", 3, 11)])
 def test_two_layer_ghosts_exchanged_every_other_substep_equal_single_process(kind, world, nsteps, tmp_path):
     from oracle import OraclePJ
     mp.spawn(_worker_deep, args=(world, _free_port(), kind, nsteps, str(tmp_path)), nprocs=world, join=True)
