@@ -12,7 +12,7 @@ import json, sys
 v, line = sys.argv[1], sys.argv[2]
 try:
     d = json.loads(line); r = d["roofline"]
-    print("%-44s value %8.1f  ms/frame %.4f  tet %.2f us  particle %.2f us  frac %.4f" % (v, d["value"], d["ms_per_step"], r["kernel_us"], r["vertex_kernel_us"], r["frac"]))
+    print("%-44s value %8.1f  ms/frame %.4f  tet %.2f us  particle %.2f us  frac %.4f  substep frac %.4f" % (v, d["value"], d["ms_per_step"], r["kernel_us"], r["vertex_kernel_us"], r["frac"], r["substep_frac"]))
 except Exception as e:
     print("%-44s FAILED %s" % (v, str(e)[:80]))
 PY
