@@ -84,13 +84,6 @@ struct PJBlk {
     // two-layer ghost regions: ghosts [nv_owned, nv_owned + n_ghost1) come from ghost_alt, the second layer from ghost2
     const float4* ghost2 = nullptr;
     uint32_t n_ghost1 = 0xffffffffu;
-    // Tile-finished particle pass (pjb_tet_finish_kernel): particles in groups of 64 consecutive ids; a tile that has stored its
-    // partial sums counts itself in on every group it contributes to, and the tile that completes a group's count runs the particle
-    // update for it -- no particle kernel, no launch boundary between the two halves of a substep.
-    const uint32_t* fin_off = nullptr;       // [nb+1] per tile: range into fin_tgt
-    const uint32_t* fin_tgt = nullptr;       // group | (number of tiles contributing to it) << 24
-    uint32_t* fin_count = nullptr;           // [groups] arrivals of the current substep (the finisher puts it back to 0)
-    uint32_t* fin_stat = nullptr;            // [0]: partial sums that had not landed when their group's count was complete (re-read), [1]: gave up
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
@@ -143,7 +136,6 @@ void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const ui
 void nh_launch_post_predict_list_fast(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
 // in its queue is done" -- a signal kernel folded into its successor
-void pjb_launch_tet_finish(hipStream_t s, const PJBlk& d, uint32_t substep_in_call, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr, uint32_t* raise_word = nullptr);
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)

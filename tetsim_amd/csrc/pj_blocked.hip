@@ -90,48 +90,6 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
 
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
-// ---- tile-finished particle pass -----------------------------------------------------------------------------
-// One lane finishes one particle INSIDE the tet kernel: the particle kernel's arithmetic (pjb_vertex_body below: same lists, same
-// order of additions, same pjb_vertex_update), run by whichever tile was the last to deliver a partial sum to the particle's group
-// of 64.  The sums were written in this very launch by other workgroups, possibly on other XCDs: they are read from the memory side
-// (dev_store.h: load_coherent) and carry the substep's sequence number in their fourth float.  Every tile that reads a particle's
-// prediction has delivered its sums before the particle is finished, so writing the next prediction in place races with nobody.
-__device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const uint32_t v, const uint32_t seq) {
-    if (v >= d.nv_owned) return;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t* col = d.vp_ell + v;
-    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 8u) {
-        uint32_t idx[8];
-        float4 g[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
-        uint32_t late = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) g[j] = idx[j] != 0xffffffffu ? load_coherent(d.partial, idx[j]) : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seq));
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) late |= (__float_as_uint(g[j].w) != seq ? 1u : 0u) << j;
-        if (__builtin_amdgcn_ballot_w64(late != 0u) != 0ull) {   // (not seen on MI355X; bounded)
-            if (late) __hip_atomic_fetch_add(d.fin_stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t trip = 0; late && trip < (1u << 20); trip++) {
-#pragma unroll
-                for (uint32_t j = 0; j < 8u; j++)
-                    if ((late >> j) & 1u) {
-                        g[j] = load_coherent(d.partial, idx[j]);
-                        if (__float_as_uint(g[j].w) == seq) late &= ~(1u << j);
-                    }
-            }
-            if (late) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
-        if (__all(idx[7] == 0xffffffffu)) break;
-    }
-    const VertexOut o = pjb_vertex_update(xyz(acc), d.wsum[v], xyz(d.fin_in[v]), *d.params, v);
-    store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
-    store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
-    store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
-}
-
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
@@ -154,11 +112,8 @@ __device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const uint32_t v
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 // kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
-// kFinish: the particle pass rides in this kernel (tile-finished particle pass, below): partial sums carry the substep's sequence
-// number, the tile counts itself in on the particle groups it contributes to and finishes the groups whose count it completes
-template <bool kLean, bool kFused, bool kAlt = false, bool kFinish = false>
-__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
-                                             [[maybe_unused]] uint32_t seq_s = 0u) {
+template <bool kLean, bool kFused, bool kAlt = false>
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -215,13 +170,6 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) src[j] = (j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;   // (uniform)
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
-    }
-    [[maybe_unused]] uint32_t fin_n = 0, fin_t = 0, seq = 0;
-    if constexpr (kFinish) {   // (requested with the first round trip; used after the reduction)
-        const uint32_t f0 = d.fin_off[b];
-        fin_n = d.fin_off[b + 1] - f0;
-        fin_t = d.fin_tgt[f0 + (tid < fin_n ? tid : 0u)];
-        seq = d.params->epoch + seq_s;
     }
     const uchar4 li = d.tet_lidx[e];
     const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
@@ -329,34 +277,9 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
             acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
         }
-        if constexpr (kFinish) acc.w = __uint_as_float(seq);
         store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
-    if constexpr (kFinish) {
-        // 4. count this tile in on every particle group it contributes to; finish the groups whose count it completes.
-        // The partial sums above are write-through stores: once vmcnt says they are acknowledged they are at the memory side, where
-        // the finisher -- any workgroup, on any XCD -- reads them with cache-bypassing loads.  Should a sum not be there all the
-        // same, its sequence number gives it away and it is read again (counted in fin_stat[0]).
-        uint32_t* const s_fin = reinterpret_cast<uint32_t*>(s_pos);   // (the staged positions were last read by the solve, two barriers ago)
-        uint32_t& s_nfin = s_fin[kTile];
-        if (tid == 0) s_nfin = 0u;
-#ifndef TETSIM_FIN_NOWAIT
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#endif
-        __syncthreads();
-        if (tid < fin_n) {
-            const uint32_t g = fin_t & 0xffffffu, expect = fin_t >> 24;
-            const uint32_t old = __hip_atomic_fetch_add(d.fin_count + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1u == expect) {
-                __hip_atomic_store(d.fin_count + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody else touches it before the next launch)
-                s_fin[atomicAdd(&s_nfin, 1u)] = g;
-            }
-        }
-        __syncthreads();
-        const uint32_t n_fin = s_nfin;
-        for (uint32_t k = tid >> 6; k < n_fin; k += kTile / 64u) pjb_finish_lane(d, s_fin[k] * 64u + (tid & 63u), seq);
-    }
 #undef TETSIM_STAMP
 }
 
@@ -392,13 +315,6 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                           uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-// ... finishing the particles too (tile-finished particle pass): the whole substep is this one launch
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_finish_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t seq_s TETSIM_DBG_PARAM) {
-    pjb_tet_body<false, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s);
-}
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_finish_kernel_constant_rest(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t seq_s TETSIM_DBG_PARAM) {
-    pjb_tet_body<true, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -789,13 +705,6 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
-}
-void pjb_launch_tet_finish(hipStream_t s, const PJBlk& d, uint32_t substep_in_call, hipEvent_t e0, hipEvent_t e1) {
-    if (d.nb == 0) return;
-    const uint32_t per_xcd = (d.nb + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_finish_kernel_constant_rest : pjb_tet_finish_kernel;
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, d.nb, per_xcd, substep_in_call TETSIM_DBG_LAUNCH);
-    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, d.nb, per_xcd, substep_in_call TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;

@@ -144,12 +144,6 @@ void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e) {
         h->fin_in_b = false;
     }
 }
-// One substep of a body with the tile-finished particle pass: ONE launch (pj_blocked.hip: pjb_tet_finish_kernel); its partial sums carry
-// the sequence number DevParams::epoch + the substep's index inside the call.  e[0..1]: the kernel's begin / end events.
-void pj_finish_substep(tetsim_body* h, bool first, hipEvent_t* e) {
-    if (first) h->fuse_step = 0;
-    pjb_launch_tet_finish(h->stream, h->blk, h->fuse_step++, e ? e[0] : nullptr, e ? e[1] : nullptr);
-}
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
     else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
@@ -181,8 +175,6 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
             if (rc) return rc;
         } else if (h->fused) {
             pj_fused_substep(h, first, last, nullptr);
-        } else if (h->finish) {
-            pj_finish_substep(h, first, nullptr);
         } else {
             pj_tet(h);
             pj_vertex(h, 0, h->pj.nv_owned);
@@ -587,19 +579,6 @@ int tetsim_sync(tetsim_handle h) {
             h->graphs.clear();
             return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "
                                         "the state since then is invalid; this body falls back to one kernel per substep");
-        }
-    }
-    if (h->d_fin_stat) {   // tile-finished particle pass: a finisher never saw a partial sum it had been told was there (never in a correct run)
-        uint32_t st[2] = {0, 0};
-        HIPCHK(h, hipMemcpy(st, h->d_fin_stat, sizeof st, hipMemcpyDeviceToHost));
-        if (st[1]) {
-            HIPCHK(h, hipMemset(h->d_fin_stat, 0, sizeof st));
-            if (h->blk.fin_count) HIPCHK(h, hipMemset(h->blk.fin_count, 0, ((h->pj.nv_owned + 63u) / 64u) * sizeof(uint32_t)));
-            h->finish = false;   // tet kernel + particle kernel from now on
-            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-            h->graphs.clear();
-            return fail(h, TETSIM_EHIP, "tile-finished particle pass: a partial sum never became visible to the tile finishing its particle; the state since then is "
-                                        "invalid; this body falls back to a tet kernel and a particle kernel per substep");
         }
     }
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted

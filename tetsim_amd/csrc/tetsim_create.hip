@@ -321,51 +321,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 h->info.fused_particle_pass = 2u;
             }
         }
-        // Tile-finished particle pass (pj_blocked.hip: pjb_tet_finish_kernel): unpartitioned bodies too large for the fused / frame
-        // kernels.  Particles in groups of 64 consecutive ids (particles and tiles are both in Morton order: a group is touched by
-        // a handful of neighbouring tiles); per tile the groups it contributes to, with the number of tiles each group waits for.
-        // TETSIM_TILE_FINISH=0 keeps the tet kernel + particle kernel substep (development A/B).
-        // TETSIM_TILE_FINISH=1 uses it for ANY unpartitioned blocked body, instead of the fused / frame kernels (tests: small bodies).
-        const char* const fin_env = getenv("TETSIM_TILE_FINISH");   // (read per body: tests build both kinds in one process)
-        const bool allow_finish = !(fin_env && fin_env[0] == '0'), force_finish = fin_env && fin_env[0] == '1';
-        if (allow_finish && (!h->fused || force_finish) && !h->partitioned && nvo == nvl && ntl > 0 && B.every_owned_particle_has_a_partial) {
-            const uint32_t groups = (nvo + 63u) / 64u;
-            std::vector<uint32_t> expect(groups, 0u), fin_off(B.num_blocks + 1u, 0u), fin_tgt;
-            std::vector<std::vector<uint32_t>> of_tile(B.num_blocks);
-            bool ok = groups < (1u << 24);
-            for (uint32_t b = 0; b < B.num_blocks && ok; b++) {
-                std::vector<uint32_t>& g = of_tile[b];
-                for (uint32_t u = B.blk_vert_off[b]; u < B.blk_vert_off[b + 1]; u++) {
-                    // (a slot without entries -- every corner of the particle in this tile dropped by the incidence cap -- still
-                    // stores a partial sum, +0, which the particle's list may or may not name: count the tile in either way)
-                    const uint32_t v = static_cast<uint32_t>(B.blk_verts[u]);
-                    if (v < nvo) g.push_back(v / 64u);
-                }
-                std::sort(g.begin(), g.end());
-                g.erase(std::unique(g.begin(), g.end()), g.end());
-                for (uint32_t x : g) expect[x]++;
-                fin_off[b + 1] = fin_off[b] + static_cast<uint32_t>(g.size());
-                ok = g.size() <= kBlockTile;
-            }
-            for (uint32_t x = 0; x < groups && ok; x++) ok = expect[x] >= 1u && expect[x] <= 255u;
-            if (ok) {
-                fin_tgt.reserve(fin_off.back());
-                for (uint32_t b = 0; b < B.num_blocks; b++) for (uint32_t x : of_tile[b]) fin_tgt.push_back(x | (expect[x] << 24));
-                uint32_t *dfo, *dft;
-                if ((rc = dev_alloc(h, &dfo, fin_off.size()))) return rc;
-                if ((rc = dev_alloc(h, &dft, std::max<size_t>(fin_tgt.size(), 1)))) return rc;
-                if ((rc = dev_alloc(h, &k.fin_count, groups))) return rc;
-                if ((rc = dev_alloc(h, &h->d_fin_stat, 2))) return rc;
-                if ((rc = upload(h, dfo, fin_off))) return rc;
-                if ((rc = upload(h, dft, fin_tgt))) return rc;
-                HIPCHK(h, hipMemset(k.fin_count, 0, groups * sizeof(uint32_t)));
-                HIPCHK(h, hipMemset(h->d_fin_stat, 0, 2 * sizeof(uint32_t)));
-                k.fin_off = dfo; k.fin_tgt = dft; k.fin_stat = h->d_fin_stat;
-                h->finish = true;
-                h->fused = h->frame = false;
-                h->info.fused_particle_pass = 3u;
-            }
-        }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
         if ((rc = upload(h, bv, B.blk_verts))) return rc;
