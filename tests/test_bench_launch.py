@@ -104,3 +104,29 @@ def test_headline_guard_prints_the_headline_when_an_optional_leg_hangs():
     code2 = code.replace("time.sleep(30)", "b.GUARD.disarm(); time.sleep(1.5)").replace("print('never reached')", "print('reached')")
     r = subprocess.run([sys.executable, "-c", code2, "0"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip() == "reached"
+
+
+def test_the_headline_of_an_n_rank_run_is_the_faster_transport_only_when_validated():
+    """bench.py promote_p2p: the peer-to-peer halo's figures replace the RCCL run's on the headline line only if that run was validated
+    (bit-equal positions, finite, the same number of timed frames, no error) AND faster; the RCCL figures stay beside them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_promote", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+
+    def line():
+        return {"value": 100.0, "unit": "M tet-solves/s", "ms_per_step": 8.0, "config": {"parallelism": "z-slab domain decomposition x8, RCCL ghost halo per substep"},
+                "multi_gpu": {"halo": "rccl", "ranks_ms_per_step": {"min": 7.9, "max": 8.0}}}
+    good = {"value": 125.0, "unit": "M tet-solves/s", "ms_per_step": 6.4, "steps": 20, "bit_equal_to_rccl_run": True, "finite": True,
+            "ranks_ms_per_step": {"min": 6.3, "max": 6.4}}
+    out = line()
+    assert b.promote_p2p(out, dict(good), 20, 8) is True
+    assert out["value"] == 125.0 and out["ms_per_step"] == 6.4 and out["multi_gpu"]["halo"].startswith("p2p") and "peer-to-peer" in out["config"]["parallelism"]
+    assert out["multi_gpu"]["rccl_halo"] == {"value": 100.0, "unit": "M tet-solves/s", "ms_per_step": 8.0, "ranks_ms_per_step": {"min": 7.9, "max": 8.0}}
+    assert out["multi_gpu"]["ranks_ms_per_step"] == {"min": 6.3, "max": 6.4}
+    for bad in (dict(good, bit_equal_to_rccl_run=False), dict(good, finite=False), dict(good, error="rank 3: TetSimError"), dict(good, steps=19),
+                dict(good, value=99.0), dict(good, value=None), {"error": "no peer access"}, None):
+        out = line()
+        assert b.promote_p2p(out, bad, 20, 8) is False and out == line()
+    out = line()
+    assert b.promote_p2p(out, dict(good), 20, 8, mode="rccl") is False and out == line()
