@@ -65,6 +65,28 @@ def test_neohookean_line_on_request():
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["substep_alg_bytes_per_tet"] > 56
 
 
+def _mock_rccl():
+    here = os.path.join(ROOT, "tests", "mock_rccl")
+    lib = os.path.join(here, "libmock_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(here, "mock_rccl.cpp")):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-std=c++17", os.path.join(here, "mock_rccl.cpp"), "-o", lib],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    return lib
+
+
+def test_a_failed_n_rank_run_is_repeated_with_more_conservative_halo_settings():
+    """bench.py's retry ladder (headline_with_retries): a failure on ANY rank is voted on, every rank closes its body, and all of them
+    rebuild -- new communicator, new body -- with the halo path enqueued eagerly; the line carries the attempts.  The failure is
+    injected on rank 1 after the first rung's timed region (TETSIM_BENCH_TEST_FAIL_FIRST_RUNG)."""
+    d = _run(["--fake-ranks", "3", "--cells", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+             env={"TETSIM_RCCL_LIB": _mock_rccl(), "TETSIM_BENCH_TEST_FAIL_FIRST_RUNG": "1"})
+    assert REQUIRED <= set(d) and d["n_gpus"] == 3 and d["value"] > 0
+    att = d["multi_gpu"]["halo_attempts"]
+    assert len(att) == 2 and att[0]["ok"] is False and att[1]["ok"] is True and "eagerly" in att[1]["halo"]
+    assert d["multi_gpu"]["rccl_ranks"] == 3
+
+
 @pytest.mark.parametrize("extra", [[], ["--profile-ranks"], ["--scaling", "strong"], ["--config5", "on", "--config5-cells", "18"]])
 def test_multi_rank_code_path_with_thread_ranks(extra):
     here = os.path.join(ROOT, "tests", "mock_rccl")

@@ -160,6 +160,8 @@ struct tetsim_body {
     PJBlk blk;             // blocked formulation (FAST unless TETSIM_FLAG_GATHER_FORMULATION)
     bool blocked = false;
     // fused particle pass (unpartitioned blocked bodies): tetsim_step_n runs  tet | fused x (n-1) | particle  instead of n x (tet | particle)
+    bool halo_use_flags = true;       // TETSIM_HALO_SYNC (read when the body is created): false = "events", the older event-synchronised halo path
+    bool halo_use_graph = true;       // TETSIM_HALO_GRAPH (likewise): false = the halo path stays eager
     bool fused = false;
     // persistent frame kernel (pjb_frame_kernel): tetsim_step_n runs ONE launch per call; fused bodies of few enough tiles
     bool frame = false;

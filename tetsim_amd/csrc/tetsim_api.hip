@@ -518,7 +518,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         // capture); afterwards the n substeps -- both streams, the grouped send/recv included -- are one captured graph:
         // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
         // critical path.  TETSIM_HALO_GRAPH=0 keeps everything eager.
-        static const bool use_graph = [] { const char* e = getenv("TETSIM_HALO_GRAPH"); return !(e && e[0] == '0'); }();
+        const bool use_graph = h->halo_use_graph;
         const bool own_rank = h->group.empty() && (h->comm || h->p2p);   // one rank per process: RCCL and / or the peer-to-peer halo
         if (own_rank && use_graph && h->halo_warm && !h->halo_graph_broken && uses_flag_sync(h)) {
             // flag path: the two streams' chains as two captured linear graphs, replayed side by side -- if the streams are served

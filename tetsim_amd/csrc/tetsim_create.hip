@@ -12,6 +12,13 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     uint32_t nvl = nv, nvo = nv, nvb = 0, ntl = nt;
     h->partitioned = o.part_count > 1;
     h->deep = h->partitioned && (o.flags & TETSIM_FLAG_DEEP_GHOSTS);
+    {   // how this body's halo is synchronised and replayed: read per body, so that a caller can rebuild a body more conservatively
+        // after a transport failure (bench.py's N > 1 retry ladder) without restarting the process
+        const char* sy = getenv("TETSIM_HALO_SYNC");
+        const char* gr = getenv("TETSIM_HALO_GRAPH");
+        h->halo_use_flags = !(sy && sy[0] == 'e');
+        h->halo_use_graph = !(gr && gr[0] == '0');
+    }
     if ((o.flags & TETSIM_FLAG_DEEP_GHOSTS) && !(h->partitioned && h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION)))
         return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_DEEP_GHOSTS needs a partitioned POLAR_JACOBI body in the blocked FAST formulation");
     uint32_t nvg1 = 0;   // first-layer ghosts that this partition advances itself (two-layer ghost regions)

@@ -119,9 +119,8 @@ uint32_t halo_timeout_ms(const tetsim_body* h) {
 bool has_transport(const tetsim_body* h) { return !h->neigh.empty() && (h->comm || !h->group.empty() || h->p2p); }
 // blocked bodies with a transport and halo-side tiles step through the flag-synchronised two-queue path (enqueue_phase_a)
 bool uses_flag_sync(const tetsim_body* h) {
-    static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();
     static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
-    return use_flags && !one_stream && has_transport(h) && h->blocked && h->blk.nb > h->blk.nb_interior;
+    return h->halo_use_flags && !one_stream && has_transport(h) && h->blocked && h->blk.nb > h->blk.nb_interior;
 }
 
 // Host cost matters here: a substep is ~42 us of GPU work and every launch / event call costs 1.5-4 us, so the eager
@@ -137,8 +136,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
-        static const bool use_flags = [] { const char* e = getenv("TETSIM_HALO_SYNC"); return !(e && e[0] == 'e'); }();  // "events" = the older path
-        if (nbnd && !one_stream && use_flags) {
+        if (nbnd && !one_stream && h->halo_use_flags) {   // (TETSIM_HALO_SYNC=events at creation: the older path below)
             // Two queues, synchronised through device words instead of events (a cross-stream event costs ~15 us eagerly and ~6 us
             // as a graph edge here, and a substep has two hand-overs on its critical path):
             //   main stream:  interior tiles(s) [raises V(s-1)] -> wait G(s) -> interior particles(s)
