@@ -90,6 +90,66 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
 
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
+// ---- one launch per substep: particle workgroups behind the tile workgroups -------------------------------------
+// One lane finishes one particle INSIDE the substep's launch: the particle kernel's arithmetic (pjb_vertex_body below: same lists,
+// same order of additions, same pjb_vertex_update).  The sums were written in this very launch by other workgroups, possibly on other
+// XCDs: they are read from the memory side (dev_store.h: load_coherent) and carry the substep's sequence number in their fourth
+// float -- a sum that has not landed yet gives itself away and is read again.  Every tile that reads a particle's prediction has
+// delivered its sums before the particle is finished, so writing the next prediction in place races with nobody.
+// What a particle wave can ask for BEFORE its tiles are done (constants and the previous substep's results): requested, then the
+// wave waits -- the finish itself is one dependent trip (the sums), not two.
+struct FinishPre { uint32_t idx[9]; float wsum; float4 prev; uint32_t v; bool live; };
+__device__ __forceinline__ FinishPre pjb_finish_prefetch(const PJBlk& d, const uint32_t v_in) {
+    FinishPre p;
+    p.live = v_in < d.nv_owned;
+    p.v = p.live ? v_in : 0u;
+    const uint32_t* col = d.vp_ell + p.v;
+#pragma unroll
+    for (uint32_t j = 0; j < 9u; j++) p.idx[j] = (j < d.vp_cols) ? col[static_cast<size_t>(j) * d.nv_pad] : 0xffffffffu;   // (host: vp_cols <= 9 for these bodies)
+    p.wsum = d.wsum[p.v];
+    p.prev = d.fin_in[p.v];
+    return p;
+}
+__device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre& p, const uint32_t seq) {
+    float4 g[9];
+    uint32_t late = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 9u; j++) g[j] = p.idx[j] != 0xffffffffu ? load_coherent(d.partial, p.idx[j]) : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seq));
+#pragma unroll
+    for (uint32_t j = 0; j < 9u; j++) late |= (__float_as_uint(g[j].w) != seq ? 1u : 0u) << j;
+    if (__builtin_amdgcn_ballot_w64(late != 0u) != 0ull) {
+        // the tile's word overtook some of its sums (nothing orders them at the memory side): look again, politely
+        if (late) __hip_atomic_fetch_add(d.fin_stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t trip = 0; __builtin_amdgcn_ballot_w64(late != 0u) != 0ull && trip < (1u << 16); trip++) {
+            __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+            for (uint32_t j = 0; j < 9u; j++)
+                if ((late >> j) & 1u) {
+                    g[j] = load_coherent(d.partial, p.idx[j]);
+                    if (__float_as_uint(g[j].w) == seq) late &= ~(1u << j);
+                }
+        }
+        if (late) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the particle kernel's additions, one for one: eight columns, then -- if anybody in the wave has a ninth sum -- eight more
+    // (the ninth and seven times +0)
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
+    if (!__all(p.idx[7] == 0xffffffffu) && d.vp_cols > 8u) {
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 g8 = p.idx[8] != 0xffffffffu ? g[8] : z;
+        acc.x += g8.x; acc.y += g8.y; acc.z += g8.z;
+#pragma unroll
+        for (uint32_t j = 1; j < 8u; j++) { acc.x += z.x; acc.y += z.y; acc.z += z.z; }
+    }
+    if (!p.live) return;
+    const VertexOut o = pjb_vertex_update(xyz(acc), p.wsum, xyz(p.prev), *d.params, p.v);
+    store_wt(d.fin_out, p.v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
+    store_wt(d.vel, p.v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+    store_wt(d.pos_pred, p.v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+}
+
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
@@ -112,8 +172,11 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 // kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
-template <bool kLean, bool kFused, bool kAlt = false>
-__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+// kFinish: the tile of a one-launch substep (pjb_substep_kernel): its partial sums carry the substep's sequence number, and it says
+// "they are out" in tile_done[tile] for the particle workgroups that follow the tiles in the same grid
+template <bool kLean, bool kFused, bool kAlt = false, bool kFinish = false>
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
+                                             [[maybe_unused]] uint32_t seq_s = 0u) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -125,7 +188,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
 #ifdef TETSIM_ABLATION  // per-tile phase timestamps (TETSIM_DEBUG_TRACE): development build only
-#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = kFinish ? static_cast<unsigned long long>(wall_clock64()) : __builtin_amdgcn_s_memtime(); } while (0)
     if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
 #else
 #define TETSIM_STAMP(i) do { } while (0)
@@ -171,6 +234,8 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         for (uint32_t j = 0; j < 8u; j++) src[j] = (j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;   // (uniform)
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
     }
+    [[maybe_unused]] uint32_t seq = 0;
+    if constexpr (kFinish) seq = d.params->epoch + seq_s;
     const uchar4 li = d.tet_lidx[e];
     const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
     const float4 q_old = d.quat[e];
@@ -277,9 +342,17 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
             acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
         }
+        if constexpr (kFinish) acc.w = __uint_as_float(seq);
         store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
+    if constexpr (kFinish) {
+        // 4. "this tile's partial sums of substep seq are out": one word, written through like the sums.  Nothing orders it behind
+        // them at the memory side (other waves' stores, other channels) -- the reader checks every sum's own sequence number; the word
+        // only says when looking is worth it.  The tile does not wait for anything here: it leaves, its slot is free.
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(d.tile_done + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #undef TETSIM_STAMP
 }
 
@@ -315,6 +388,83 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                           uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+// ---- the whole substep as ONE launch: tile workgroups, then particle workgroups, in one grid ------------------------------------
+// Blocks [0, tile_blocks) are the tet kernel's tiles (same mapping, same code, kFinish).  Behind them come the particle workgroups:
+// four waves each, a wave per group of 64 consecutive particles.  Workgroups are dispatched in index order, so a particle workgroup
+// only gets a slot once every tile has been dispatched: it takes no slot from a tile, it runs in the slots the tet kernel's last
+// (partial) round leaves idle and in those its tiles free as they finish, and every tile it can wait for is already running or done
+// -- no deadlock; the wait is bounded all the same.  A wave polls ONE word per tile its group depends on (one lane each, coherent
+// loads, s_sleep in between), then finishes its 64 particles (pjb_finish_lane).  Groups are mapped to XCDs like tiles: the k-th
+// particle workgroup of XCD x takes groups from the x-th eighth of the particles, ascending -- the order in which that XCD's tiles
+// finish.  No particle kernel, no launch boundary between the halves of a substep, and the particle pass overlaps the tet pass's tail.
+template <bool kLean>
+__device__ __forceinline__ void pjb_substep_body(const PJBlk& d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t seq_s,
+                                                 uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    const uint32_t tile_blocks = tiles_per_xcd * 8u;
+    if (blockIdx.x < tile_blocks) {
+        pjb_tet_body<kLean, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s);
+        return;
+    }
+    const uint32_t dbg_mode = timeout_ms >> 28;   // TEMPORARY diagnosis: 1 = particle workgroups leave at once, 2 = wait but do not finish
+    timeout_ms &= 0x0fffffffu;
+    if (dbg_mode == 1u) return;
+    const uint32_t vk = blockIdx.x - tile_blocks;                       // (tile_blocks is a multiple of 8: block vk runs on XCD vk % 8)
+    const uint32_t quad = (vk & 7u) * quads_per_xcd + (vk >> 3);
+    const uint32_t g = quad * (kTile / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (g >= d.n_groups) return;
+    const uint32_t seq = d.params->epoch + seq_s;
+#ifdef TETSIM_ABLATION   // development build: this wave's timeline behind the tiles' rows (TETSIM_DEBUG_TRACE, tools/trace_substep.py)
+#define VG_STAMP(i) do { if (d.trace && lane == 0) d.trace[8ull * (d.nb + g) + (i)] = static_cast<unsigned long long>(wall_clock64()); } while (0)   // (one clock for all XCDs, 10 ns)
+#else
+#define VG_STAMP(i) do { } while (0)
+#endif
+    VG_STAMP(0);
+    const FinishPre pre = pjb_finish_prefetch(d, g * 64u + lane);
+    const uint32_t o0 = d.vg_off[g], nd = d.vg_off[g + 1] - o0;
+    const long long limit = 100000ll * timeout_ms;   // 100 MHz ticks; 0 = unbounded
+    const long long w0 = limit ? wall_clock64() : 0ll;
+    // First ONE word, at leisure: the host lists the tile that is dispatched last first, and while that one is not out there is
+    // no point in asking about the others -- 2,744 waves polling ten words each every quarter of a microsecond are ~7 TB/s worth of
+    // requests at the memory side (measured: the substep took 42 us instead of 39).
+    {
+        const uint32_t last_tile = d.vg_tiles[o0];
+        while (__hip_atomic_load(d.tile_done + last_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(8);   // ~0.25 us: with the load's own trip a wave asks every ~2 us -- 2,744 waves, ~1.3 requests per ns at most
+            if (limit && wall_clock64() - w0 > limit) {
+                if (lane == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+    }
+    VG_STAMP(1);
+    for (uint32_t base = 0; base < nd; base += 64u) {   // (64 tiles at a time; a group of the lattice depends on ~10)
+        const bool mine = base + lane < nd;
+        const uint32_t tile = mine ? d.vg_tiles[o0 + base + lane] : 0u;
+        bool pending = mine;
+        while (true) {
+            if (pending) pending = __hip_atomic_load(d.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq;
+            if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (limit && wall_clock64() - w0 > limit) {
+                if (lane == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+    }
+    VG_STAMP(2);
+    if (dbg_mode == 2u) return;
+    pjb_finish_lane(d, pre, seq);
+    VG_STAMP(3);
+#undef VG_STAMP
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_substep_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t seq_s,
+                                                            uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    pjb_substep_body<false>(d, tile_count, tiles_per_xcd, quads_per_xcd, seq_s, timeout_ms TETSIM_DBG_ARG);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_substep_kernel_constant_rest(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd,
+                                                                          uint32_t seq_s, uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    pjb_substep_body<true>(d, tile_count, tiles_per_xcd, quads_per_xcd, seq_s, timeout_ms TETSIM_DBG_ARG);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -705,6 +855,17 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+}
+void pjb_launch_substep(hipStream_t s, const PJBlk& d, uint32_t substep_in_call, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
+    if (d.nb == 0) return;
+    const uint32_t per_xcd = (d.nb + 7u) / 8u;
+    const uint32_t quads = (d.n_groups + kTile / 64u - 1u) / (kTile / 64u), quads_per_xcd = (quads + 7u) / 8u;
+    const dim3 grid((per_xcd + quads_per_xcd) * 8u);
+    auto* kernel = d.lean ? pjb_substep_kernel_constant_rest : pjb_substep_kernel;
+    static const uint32_t dbg_mode = [] { const char* e = getenv("TETSIM_DEBUG_SUBSTEP_MODE"); return e ? static_cast<uint32_t>(atoi(e)) & 15u : 0u; }();
+    timeout_ms = (timeout_ms & 0x0fffffffu) | (dbg_mode << 28);
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, e0, e1, 0, d, d.nb, per_xcd, quads_per_xcd, substep_in_call, timeout_ms TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, d, d.nb, per_xcd, quads_per_xcd, substep_in_call, timeout_ms TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;

@@ -328,6 +328,48 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 h->info.fused_particle_pass = 2u;
             }
         }
+        // One launch per substep (pj_blocked.hip: pjb_substep_kernel): unpartitioned bodies too large for the fused / frame kernels.
+        // Particles in groups of 64 consecutive ids (particles and tiles are both in Morton order: a group is fed by a handful of
+        // neighbouring tiles); per group, the tiles that hold a slot for one of its particles -- the tiles its wave waits for.
+        // TETSIM_ONE_LAUNCH_SUBSTEP=0 keeps the tet kernel + particle kernel substep (development A/B); =1 uses the one-launch substep
+        // for ANY unpartitioned blocked body, instead of the fused / frame kernels (tests: small bodies).
+        const char* const one_env = getenv("TETSIM_ONE_LAUNCH_SUBSTEP");   // (read per body: tests build both kinds in one process)
+        const bool allow_one = !(one_env && one_env[0] == '0'), force_one = one_env && one_env[0] == '1';
+        if (allow_one && (!h->fused || force_one) && !h->partitioned && nvo == nvl && ntl > 0 && B.every_owned_particle_has_a_partial && B.max_partials <= 9) {
+            const uint32_t groups = (nvo + 63u) / 64u;
+            std::vector<std::vector<uint32_t>> of_group(groups);
+            for (uint32_t b = 0; b < B.num_blocks; b++)
+                for (uint32_t u = B.blk_vert_off[b]; u < B.blk_vert_off[b + 1]; u++) {
+                    const uint32_t v = static_cast<uint32_t>(B.blk_verts[u]);
+                    if (v < nvo && (of_group[v / 64u].empty() || of_group[v / 64u].back() != b)) of_group[v / 64u].push_back(b);   // (b ascends)
+                }
+            std::vector<uint32_t> vg_off(groups + 1u, 0u), vg_tiles;
+            bool ok = true;
+            for (uint32_t g = 0; g < groups; g++) {
+                ok = ok && !of_group[g].empty();   // (a group no tile feeds would never be finished; cannot happen when every particle has a partial sum)
+                // the tile dispatched LAST first (pjb_substep_kernel polls that one alone before it asks about the others): tile b is
+                // the (b % per_xcd)-th of its XCD's sequence (pj_blocked.hip: xcd_tile)
+                const uint32_t per_xcd = (B.num_blocks + 7u) / 8u;
+                std::stable_sort(of_group[g].begin(), of_group[g].end(), [&](uint32_t a, uint32_t c) { return a % per_xcd > c % per_xcd; });
+                vg_tiles.insert(vg_tiles.end(), of_group[g].begin(), of_group[g].end());
+                vg_off[g + 1] = static_cast<uint32_t>(vg_tiles.size());
+            }
+            if (ok) {
+                uint32_t *dvo, *dvt;
+                if ((rc = dev_alloc(h, &dvo, vg_off.size()))) return rc;
+                if ((rc = dev_alloc(h, &dvt, std::max<size_t>(vg_tiles.size(), 1)))) return rc;
+                if ((rc = dev_alloc(h, &k.tile_done, B.num_blocks))) return rc;
+                if ((rc = dev_alloc(h, &h->d_fin_stat, 4))) return rc;
+                if ((rc = upload(h, dvo, vg_off))) return rc;
+                if ((rc = upload(h, dvt, vg_tiles))) return rc;
+                HIPCHK(h, hipMemset(k.tile_done, 0, B.num_blocks * sizeof(uint32_t)));   // (sequence numbers start at 65537: 0 never matches)
+                HIPCHK(h, hipMemset(h->d_fin_stat, 0, 4 * sizeof(uint32_t)));
+                k.vg_off = dvo; k.vg_tiles = dvt; k.fin_stat = h->d_fin_stat; k.n_groups = groups;
+                h->finish = true;
+                h->fused = h->frame = false;
+                h->info.fused_particle_pass = 3u;
+            }
+        }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
         if ((rc = upload(h, bv, B.blk_verts))) return rc;
@@ -345,8 +387,9 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
         if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
-            if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
-            HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));
+            const size_t rows = static_cast<size_t>(B.num_blocks) + k.n_groups;   // (one-launch substep: a row per particle group behind the tiles')
+            if ((rc = dev_alloc(h, &k.trace, 8ull * rows))) return rc;
+            HIPCHK(h, hipMemset(k.trace, 0, 8ull * rows * sizeof(unsigned long long)));
         }
     } else {
         if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;
