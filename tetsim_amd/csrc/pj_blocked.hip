@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd)
 // staging of the tet kernel (same function, same contraction: the two must agree bit for bit -- tetsim_step runs the former,
 // tetsim_step_n the latter).  acc = sum of V*goal, wsum = sum of V (a constant), prev = end of the previous substep.
 struct VertexOut { f3 p, vel, pred; };
+// (Every multiply-add below is spelled out: with -ffp-contract=fast the compiler decides per call site which products to fuse, and this
+// function is inlined into four kernels whose results must agree bit for bit.  The spelling is the one the particle kernel has always
+// compiled to.)
 __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 prev, const DevParams& P, uint32_t v) {
     const float rw = __builtin_amdgcn_rcpf(wsum);
     f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
@@ -73,18 +76,19 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
     p.z = fminf(fmaxf(p.z, P.lo[2]), P.hi[2]);
     if (p.y < 0.0f) {
         p.y = 0.0f;
-        const f3 F = prev - p;
+        const float Fx = prev.x - p.x, Fz = prev.z - p.z;
         const float fr = fminf(1.0f, P.dt * P.friction);
-        p.x += F.x * fr;
-        p.z += F.z * fr;
+        p.x = fmaf(Fx, fr, p.x);
+        p.z = fmaf(Fz, fr, p.z);
     }
     // P7, :364-372, then P1 + P2 of the next substep
     const float dt = P.dt;
     const float rdt = __builtin_amdgcn_rcpf(dt);
     VertexOut o;
     o.p = p;
-    o.vel = (p - prev) * rdt + F3(0.0f, P.gravity, 0.0f) * dt;
-    o.pred = p + o.vel * dt;
+    const float gx = dt * 0.0f, gy = dt * P.gravity, gz = dt * 0.0f;   // F3(0, gravity, 0) * dt
+    o.vel = F3(fmaf(rdt, p.x - prev.x, gx), fmaf(rdt, p.y - prev.y, gy), fmaf(rdt, p.z - prev.z, gz));
+    o.pred = F3(fmaf(dt, o.vel.x, p.x), fmaf(dt, o.vel.y, p.y), fmaf(dt, o.vel.z, p.z));
     return o;
 }
 
@@ -96,58 +100,75 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 // XCDs: they are read from the memory side (dev_store.h: load_coherent) and carry the substep's sequence number in their fourth
 // float -- a sum that has not landed yet gives itself away and is read again.  Every tile that reads a particle's prediction has
 // delivered its sums before the particle is finished, so writing the next prediction in place races with nobody.
-// What a particle wave can ask for BEFORE its tiles are done (constants and the previous substep's results): requested, then the
-// wave waits -- the finish itself is one dependent trip (the sums), not two.
-struct FinishPre { uint32_t idx[9]; float wsum; float4 prev; uint32_t v; bool live; };
+// What a particle wave can ask for BEFORE its tiles are done (constants): requested, then the wave waits -- the finish itself is one
+// dependent trip (the sums and the previous position), not two.  Register budget: the kernel must stay within 64 VGPRs (8 waves per
+// SIMD, the tiles' occupancy): list entries become byte offsets at once, absent ones alias the first entry and are masked out.
+struct FinishPre { uint32_t off[9]; uint32_t valid; float wsum; uint32_t v; bool live; };
 __device__ __forceinline__ FinishPre pjb_finish_prefetch(const PJBlk& d, const uint32_t v_in) {
     FinishPre p;
     p.live = v_in < d.nv_owned;
     p.v = p.live ? v_in : 0u;
     const uint32_t* col = d.vp_ell + p.v;
+    p.valid = 0u;
 #pragma unroll
-    for (uint32_t j = 0; j < 9u; j++) p.idx[j] = (j < d.vp_cols) ? col[static_cast<size_t>(j) * d.nv_pad] : 0xffffffffu;   // (host: vp_cols <= 9 for these bodies)
+    for (uint32_t j = 0; j < 9u; j++) {   // (host: vp_cols <= 9 for these bodies)
+        const uint32_t idx = (j < d.vp_cols) ? col[static_cast<size_t>(j) * d.nv_pad] : 0xffffffffu;
+        p.valid |= (idx != 0xffffffffu ? 1u : 0u) << j;
+        p.off[j] = idx != 0xffffffffu ? idx : 0u;
+    }
     p.wsum = d.wsum[p.v];
-    p.prev = d.fin_in[p.v];
     return p;
 }
-__device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre& p, const uint32_t seq) {
+__device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre& p, const uint32_t seq, const bool first_of_launch) {
+    // one trip: the partial sums of this substep (sequence number seq) and the particle's previous position (seq - 1 if this
+    // group's wave of the previous substep ran in this very launch -- it may not have been through when a prefetch would have asked)
     float4 g[9];
+#pragma unroll
+    for (uint32_t j = 0; j < 9u; j++) g[j] = load_coherent(d.partial, p.off[j]);
+    float4 pv = load_coherent(d.fin_in, p.v);
     uint32_t late = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < 9u; j++) g[j] = p.idx[j] != 0xffffffffu ? load_coherent(d.partial, p.idx[j]) : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seq));
-#pragma unroll
     for (uint32_t j = 0; j < 9u; j++) late |= (__float_as_uint(g[j].w) != seq ? 1u : 0u) << j;
+    late &= p.valid;
+    if (!first_of_launch && __float_as_uint(pv.w) != seq - 1u) late |= 1u << 9;
     if (__builtin_amdgcn_ballot_w64(late != 0u) != 0ull) {
-        // the tile's word overtook some of its sums (nothing orders them at the memory side): look again, politely
+        // a word overtook some of the data it announces (nothing orders them at the memory side): look again, politely
         if (late) __hip_atomic_fetch_add(d.fin_stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t trip = 0; __builtin_amdgcn_ballot_w64(late != 0u) != 0ull && trip < (1u << 16); trip++) {
             __builtin_amdgcn_s_sleep(4);
 #pragma unroll
             for (uint32_t j = 0; j < 9u; j++)
                 if ((late >> j) & 1u) {
-                    g[j] = load_coherent(d.partial, p.idx[j]);
+                    g[j] = load_coherent(d.partial, p.off[j]);
                     if (__float_as_uint(g[j].w) == seq) late &= ~(1u << j);
                 }
+            if ((late >> 9) & 1u) {
+                pv = load_coherent(d.fin_in, p.v);
+                if (__float_as_uint(pv.w) == seq - 1u) late &= ~(1u << 9);
+            }
         }
         if (late) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // the particle kernel's additions, one for one: eight columns, then -- if anybody in the wave has a ninth sum -- eight more
-    // (the ninth and seven times +0)
+    // the particle kernel's additions, one for one: eight columns (an absent one adds +0), then -- if anybody in the wave has a
+    // ninth sum -- eight more (the ninth and seven times +0)
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
-    if (!__all(p.idx[7] == 0xffffffffu) && d.vp_cols > 8u) {
-        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float4 g8 = p.idx[8] != 0xffffffffu ? g[8] : z;
-        acc.x += g8.x; acc.y += g8.y; acc.z += g8.z;
+    for (uint32_t j = 0; j < 8u; j++) {
+        const bool on = (p.valid >> j) & 1u;
+        acc.x += on ? g[j].x : 0.0f; acc.y += on ? g[j].y : 0.0f; acc.z += on ? g[j].z : 0.0f;
+    }
+    if (!__all(((p.valid >> 7) & 1u) == 0u) && d.vp_cols > 8u) {
+        const bool on = (p.valid >> 8) & 1u;
+        acc.x += on ? g[8].x : 0.0f; acc.y += on ? g[8].y : 0.0f; acc.z += on ? g[8].z : 0.0f;
+        const float z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0));   // (+0 the compiler cannot fold: x + 0 is not x for x = -0)
 #pragma unroll
-        for (uint32_t j = 1; j < 8u; j++) { acc.x += z.x; acc.y += z.y; acc.z += z.z; }
+        for (uint32_t j = 1; j < 8u; j++) { acc.x += z; acc.y += z; acc.z += z; }
     }
     if (!p.live) return;
-    const VertexOut o = pjb_vertex_update(xyz(acc), p.wsum, xyz(p.prev), *d.params, p.v);
-    store_wt(d.fin_out, p.v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
+    const VertexOut o = pjb_vertex_update(xyz(acc), p.wsum, xyz(pv), *d.params, p.v);
+    store_wt(d.fin_out, p.v, make_float4(o.p.x, o.p.y, o.p.z, __uint_as_float(seq)));   // (w: which substep's result this is)
     store_wt(d.vel, p.v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
-    store_wt(d.pos_pred, p.v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
+    store_wt(d.pos_pred, p.v, make_float4(o.pred.x, o.pred.y, o.pred.z, __uint_as_float(seq)));
 }
 
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
@@ -176,19 +197,21 @@ __device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre&
 // "they are out" in tile_done[tile] for the particle workgroups that follow the tiles in the same grid
 template <bool kLean, bool kFused, bool kAlt = false, bool kFinish = false>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
-                                             [[maybe_unused]] uint32_t seq_s = 0u) {
+                                             [[maybe_unused]] uint32_t seq_s = 0u, [[maybe_unused]] uint32_t blk = 0u, [[maybe_unused]] bool first_of_launch = true,
+                                             [[maybe_unused]] uint32_t timeout_ms = 0u) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
     __shared__ float s_gz[4 * kTile];
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
-    const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
+    const uint32_t rel = kFinish ? blk : xcd_tile(blockIdx.x, tiles_per_xcd);   // (kFinish: the caller's schedule names the tile)
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
 #ifdef TETSIM_ABLATION  // per-tile phase timestamps (TETSIM_DEBUG_TRACE): development build only
-#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = kFinish ? static_cast<unsigned long long>(wall_clock64()) : __builtin_amdgcn_s_memtime(); } while (0)
+// (kFinish: one clock for all XCDs; of a launch of several substeps the one with index 10 -- mid-pipeline -- or the only one)
+#define TETSIM_STAMP(i) do { if (d.trace && tid == 0 && (!kFinish || seq_s == 10u || first_of_launch)) d.trace[8ull * b + (i)] = kFinish ? static_cast<unsigned long long>(wall_clock64()) : __builtin_amdgcn_s_memtime(); } while (0)
     if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
 #else
 #define TETSIM_STAMP(i) do { } while (0)
@@ -234,15 +257,69 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         for (uint32_t j = 0; j < 8u; j++) src[j] = (j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;   // (uniform)
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
     }
-    [[maybe_unused]] uint32_t seq = 0;
-    if constexpr (kFinish) seq = d.params->epoch + seq_s;
+    [[maybe_unused]] uint32_t seq = 0, dep_n = 0, dep_g = 0;
+    if constexpr (kFinish) {
+        seq = d.params->epoch + seq_s;
+        const uint32_t f0 = d.tg_off[b];
+        dep_n = d.tg_off[b + 1] - f0;
+        dep_g = d.tg_groups[f0 + (tid < dep_n ? tid : 0u)];
+    }
     const uchar4 li = d.tet_lidx[e];
-    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
-    const float4 q_old = d.quat[e];
     const float V = d.vol[e];
     const uint2 ent_row = d.lc_ent[e];
+    float4 ra, rb, rc, q_old;
     float4 pos_stage;
-    if constexpr (kFused) {
+    if constexpr (kFinish) {
+        // Substeps after the first of a launch: the predictions come from particle waves of THIS launch, and this tile's own record
+        // from the workgroup that solved the tile one substep ago -- which may still be running when this one is dispatched.  Wait
+        // until every group this tile's particles belong to has been finished for the previous substep (one word per group, one
+        // lane each; those groups waited for this tile's previous incarnation among others), THEN ask for the record and the
+        // predictions, from the memory side like everything that crosses workgroups inside a launch.  Each prediction carries its
+        // substep's sequence number; one that has not landed yet is read again.
+        if (!first_of_launch) {
+            if (tid < 64u) {   // the first wave asks, the others wait at the barrier
+                const long long limit = 100000ll * timeout_ms, w0 = limit ? wall_clock64() : 0ll;
+                for (uint32_t base = 0; base < dep_n; base += 64u) {
+                    bool pending = base + tid < dep_n;
+                    const uint32_t grp = base == 0u ? dep_g : (pending ? d.tg_groups[d.tg_off[b] + base + tid] : 0u);
+                    while (true) {
+                        if (pending) pending = static_cast<int32_t>(__hip_atomic_load(d.group_done + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (seq - 1u)) < 0;
+                        if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(8);
+                        if (limit && wall_clock64() - w0 > limit) {   // (the error word says the state is invalid from here on; going on keeps the launch finite)
+                            if (tid == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#if defined(TETSIM_CALL_PLAIN_RECORD)
+            ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e]; q_old = d.quat[e];
+#elif defined(TETSIM_CALL_L2_RECORD)
+            ra = load_l2(d.rest_a, e); rb = load_l2(d.rest_b, e); rc = load_l2(d.rest_c, e); q_old = load_l2(d.quat, e);
+#else
+            ra = load_coherent(d.rest_a, e); rb = load_coherent(d.rest_b, e); rc = load_coherent(d.rest_c, e);
+            q_old = load_coherent(d.quat, e);
+#endif
+            pos_stage = load_coherent(d.pos_pred, vid);
+            uint32_t trips = 0;
+            while (__builtin_amdgcn_ballot_w64(__float_as_uint(pos_stage.w) != seq - 1u) != 0ull && trips++ < (1u << 16)) {
+                if (trips == 1u && __float_as_uint(pos_stage.w) != seq - 1u) __hip_atomic_fetch_add(d.fin_stat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(4);
+                if (__float_as_uint(pos_stage.w) != seq - 1u) pos_stage = load_coherent(d.pos_pred, vid);
+            }
+        } else {
+            ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e];
+            q_old = d.quat[e];
+            pos_stage = d.pos_pred[vid];
+        }
+    } else {
+        ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e];
+        q_old = d.quat[e];
+    }
+    if constexpr (kFinish) {
+    } else if constexpr (kFused) {
         // (a ghost would keep its received prediction; fused bodies have none)
         f3 g[8];
 #pragma unroll
@@ -350,6 +427,9 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         // 4. "this tile's partial sums of substep seq are out": one word, written through like the sums.  Nothing orders it behind
         // them at the memory side (other waves' stores, other channels) -- the reader checks every sum's own sequence number; the word
         // only says when looking is worth it.  The tile does not wait for anything here: it leaves, its slot is free.
+#ifndef TETSIM_CALL_NO_ACK
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's write-through stores (record, partial sums) are acknowledged
+#endif
         __syncthreads();
         if (tid == 0) __hip_atomic_store(d.tile_done + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -389,33 +469,43 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJB
                                                                           uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
-// ---- the whole substep as ONE launch: tile workgroups, then particle workgroups, in one grid ------------------------------------
-// Blocks [0, tile_blocks) are the tet kernel's tiles (same mapping, same code, kFinish).  Behind them come the particle workgroups:
-// four waves each, a wave per group of 64 consecutive particles.  Workgroups are dispatched in index order, so a particle workgroup
-// only gets a slot once every tile has been dispatched: it takes no slot from a tile, it runs in the slots the tet kernel's last
-// (partial) round leaves idle and in those its tiles free as they finish, and every tile it can wait for is already running or done
-// -- no deadlock; the wait is bounded all the same.  A wave polls ONE word per tile its group depends on (one lane each, coherent
-// loads, s_sleep in between), then finishes its 64 particles (pjb_finish_lane).  Groups are mapped to XCDs like tiles: the k-th
-// particle workgroup of XCD x takes groups from the x-th eighth of the particles, ascending -- the order in which that XCD's tiles
-// finish.  No particle kernel, no launch boundary between the halves of a substep, and the particle pass overlaps the tet pass's tail.
+// ---- a whole tetsim_step_n call as ONE launch: per substep tile workgroups, then particle workgroups, all in one grid ---------------
+// Substep s owns blocks [s * B, (s + 1) * B): first the tet kernel's tiles (same mapping, same code, kFinish), behind them the particle
+// workgroups -- four waves each, a wave per group of 64 consecutive particles.  Nothing synchronises the grid as a whole; a block waits
+// for exactly what it needs, and only for blocks in front of it:
+//   * a particle wave waits until every tile that feeds its group has said "my partial sums of substep s are out" (tile_done[tile]),
+//     then runs the particle kernel's arithmetic for its 64 particles (pjb_finish_lane) and says so (group_done[group]);
+//   * a tile of substep s > first waits until every group its particles belong to is finished for s - 1, then reads their predictions.
+// Workgroups are dispatched in index order (per XCD; B is a multiple of 8, so a tile and a group keep their XCD from substep to
+// substep), so whatever a block waits for has been dispatched before it: the block with the lowest index that is not complete either
+// runs with everything it needs, or is next in its XCD's queue with free slots in front of it -- no deadlock, and every wait is bounded
+// all the same.  A particle workgroup takes no slot from a tile of its own substep (they are all dispatched before it); it runs in the
+// slots the last, partial round of tiles leaves idle, beside the tail of its substep's tiles and the head of the next substep's.
+// The launch boundaries of a substep and the serialisation they enforce (every particle after every tile, every tile after every
+// particle) are gone; what orders the work is data.  Words and data are written through and read from the memory side; every datum
+// carries its substep's sequence number (partial sums, predictions), a word only says when looking is worth it.
+// Hazards without a grid-wide barrier: a tile overwrites its partial sums of s - 1 only after the groups that read them are finished
+// (it waits for exactly those); a wave overwrites a prediction of s - 1 only after every tile that reads it has delivered its sums of s
+// (it waits for exactly those); a tile's own record is touched by nobody else.
 template <bool kLean>
-__device__ __forceinline__ void pjb_substep_body(const PJBlk& d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t seq_s,
-                                                 uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    const uint32_t tile_blocks = tiles_per_xcd * 8u;
-    if (blockIdx.x < tile_blocks) {
-        pjb_tet_body<kLean, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s);
+__device__ __forceinline__ void pjb_call_body(const PJBlk& d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t first_s,
+                                              uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    // the schedule (host, tetsim_create.hip): per XCD a sequence of `period` items per substep -- a tile, or a quad of particle groups
+    const uint32_t period = tiles_per_xcd + quads_per_xcd, per_substep = period * 8u;
+    const uint32_t s_rel = blockIdx.x / per_substep, r = blockIdx.x - s_rel * per_substep;
+    const uint32_t item = d.sched[(r & 7u) * period + (r >> 3)];        // (block r of a substep runs on XCD r % 8)
+    const uint32_t seq_s = first_s + s_rel;
+    if (item == 0xffffffffu) return;
+    if (!(item & 0x80000000u)) {
+        pjb_tet_body<kLean, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s, item, s_rel == 0u, timeout_ms);
         return;
     }
-    const uint32_t dbg_mode = timeout_ms >> 28;   // TEMPORARY diagnosis: 1 = particle workgroups leave at once, 2 = wait but do not finish
-    timeout_ms &= 0x0fffffffu;
-    if (dbg_mode == 1u) return;
-    const uint32_t vk = blockIdx.x - tile_blocks;                       // (tile_blocks is a multiple of 8: block vk runs on XCD vk % 8)
-    const uint32_t quad = (vk & 7u) * quads_per_xcd + (vk >> 3);
+    const uint32_t quad = item & 0x7fffffffu;
     const uint32_t g = quad * (kTile / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (g >= d.n_groups) return;
     const uint32_t seq = d.params->epoch + seq_s;
 #ifdef TETSIM_ABLATION   // development build: this wave's timeline behind the tiles' rows (TETSIM_DEBUG_TRACE, tools/trace_substep.py)
-#define VG_STAMP(i) do { if (d.trace && lane == 0) d.trace[8ull * (d.nb + g) + (i)] = static_cast<unsigned long long>(wall_clock64()); } while (0)   // (one clock for all XCDs, 10 ns)
+#define VG_STAMP(i) do { if (d.trace && lane == 0 && (seq_s == 10u || s_rel == 0u)) d.trace[8ull * (d.nb + g) + (i)] = static_cast<unsigned long long>(wall_clock64()); } while (0)   // (one clock for all XCDs, 10 ns)
 #else
 #define VG_STAMP(i) do { } while (0)
 #endif
@@ -424,28 +514,14 @@ __device__ __forceinline__ void pjb_substep_body(const PJBlk& d, uint32_t tile_c
     const uint32_t o0 = d.vg_off[g], nd = d.vg_off[g + 1] - o0;
     const long long limit = 100000ll * timeout_ms;   // 100 MHz ticks; 0 = unbounded
     const long long w0 = limit ? wall_clock64() : 0ll;
-    // First ONE word, at leisure: the host lists the tile that is dispatched last first, and while that one is not out there is
-    // no point in asking about the others -- 2,744 waves polling ten words each every quarter of a microsecond are ~7 TB/s worth of
-    // requests at the memory side (measured: the substep took 42 us instead of 39).
-    {
-        const uint32_t last_tile = d.vg_tiles[o0];
-        while (__hip_atomic_load(d.tile_done + last_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            __builtin_amdgcn_s_sleep(8);   // ~0.25 us: with the load's own trip a wave asks every ~2 us -- 2,744 waves, ~1.3 requests per ns at most
-            if (limit && wall_clock64() - w0 > limit) {
-                if (lane == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;
-            }
-        }
-    }
-    VG_STAMP(1);
     for (uint32_t base = 0; base < nd; base += 64u) {   // (64 tiles at a time; a group of the lattice depends on ~10)
         const bool mine = base + lane < nd;
         const uint32_t tile = mine ? d.vg_tiles[o0 + base + lane] : 0u;
         bool pending = mine;
         while (true) {
-            if (pending) pending = __hip_atomic_load(d.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq;
+            if (pending) pending = static_cast<int32_t>(__hip_atomic_load(d.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0;
             if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(8);   // ~0.25 us on top of the load's own trip
             if (limit && wall_clock64() - w0 > limit) {
                 if (lane == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
@@ -453,18 +529,21 @@ __device__ __forceinline__ void pjb_substep_body(const PJBlk& d, uint32_t tile_c
         }
     }
     VG_STAMP(2);
-    if (dbg_mode == 2u) return;
-    pjb_finish_lane(d, pre, seq);
+    pjb_finish_lane(d, pre, seq, s_rel == 0u);
+#ifndef TETSIM_CALL_NO_ACK
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): positions, velocities, predictions acknowledged
+#endif
+    if (lane == 0) __hip_atomic_store(d.group_done + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     VG_STAMP(3);
 #undef VG_STAMP
 }
-__global__ __launch_bounds__(kTile, 2) void pjb_substep_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t seq_s,
-                                                            uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    pjb_substep_body<false>(d, tile_count, tiles_per_xcd, quads_per_xcd, seq_s, timeout_ms TETSIM_DBG_ARG);
+__global__ __launch_bounds__(kTile, 8) void pjb_call_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t first_s,
+                                                         uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    pjb_call_body<false>(d, tile_count, tiles_per_xcd, quads_per_xcd, first_s, timeout_ms TETSIM_DBG_ARG);
 }
-__global__ __launch_bounds__(kTile, 2) void pjb_substep_kernel_constant_rest(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd,
-                                                                          uint32_t seq_s, uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    pjb_substep_body<true>(d, tile_count, tiles_per_xcd, quads_per_xcd, seq_s, timeout_ms TETSIM_DBG_ARG);
+__global__ __launch_bounds__(kTile, 8) void pjb_call_kernel_constant_rest(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd,
+                                                                       uint32_t first_s, uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    pjb_call_body<true>(d, tile_count, tiles_per_xcd, quads_per_xcd, first_s, timeout_ms TETSIM_DBG_ARG);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -856,16 +935,14 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
-void pjb_launch_substep(hipStream_t s, const PJBlk& d, uint32_t substep_in_call, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
-    if (d.nb == 0) return;
+void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t first_substep, uint32_t n_substeps, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
+    if (d.nb == 0 || n_substeps == 0) return;
     const uint32_t per_xcd = (d.nb + 7u) / 8u;
     const uint32_t quads = (d.n_groups + kTile / 64u - 1u) / (kTile / 64u), quads_per_xcd = (quads + 7u) / 8u;
-    const dim3 grid((per_xcd + quads_per_xcd) * 8u);
-    auto* kernel = d.lean ? pjb_substep_kernel_constant_rest : pjb_substep_kernel;
-    static const uint32_t dbg_mode = [] { const char* e = getenv("TETSIM_DEBUG_SUBSTEP_MODE"); return e ? static_cast<uint32_t>(atoi(e)) & 15u : 0u; }();
-    timeout_ms = (timeout_ms & 0x0fffffffu) | (dbg_mode << 28);
-    if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, e0, e1, 0, d, d.nb, per_xcd, quads_per_xcd, substep_in_call, timeout_ms TETSIM_DBG_LAUNCH);
-    else hipLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, d, d.nb, per_xcd, quads_per_xcd, substep_in_call, timeout_ms TETSIM_DBG_LAUNCH);
+    const dim3 grid((per_xcd + quads_per_xcd) * 8u * n_substeps);
+    auto* kernel = d.lean ? pjb_call_kernel_constant_rest : pjb_call_kernel;
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, e0, e1, 0, d, d.nb, per_xcd, quads_per_xcd, first_substep, timeout_ms TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, d, d.nb, per_xcd, quads_per_xcd, first_substep, timeout_ms TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;

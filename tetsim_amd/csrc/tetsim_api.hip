@@ -149,7 +149,7 @@ void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e) {
 // kernel's begin / end events.
 void pj_finish_substep(tetsim_body* h, bool first, hipEvent_t* e) {
     if (first) h->fuse_step = 0;
-    pjb_launch_substep(h->stream, h->blk, h->fuse_step++, halo_timeout_ms(h), e ? e[0] : nullptr, e ? e[1] : nullptr);
+    pjb_launch_call(h->stream, h->blk, h->fuse_step++, 1u, halo_timeout_ms(h), e ? e[0] : nullptr, e ? e[1] : nullptr);
 }
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
@@ -182,7 +182,7 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
             if (rc) return rc;
         } else if (h->fused) {
             pj_fused_substep(h, first, last, nullptr);
-        } else if (h->finish) {
+        } else if (h->finish && !getenv("TETSIM_DEBUG_CALL_SPLIT")) {
             pj_finish_substep(h, first, nullptr);
         } else {
             pj_tet(h);
@@ -265,6 +265,12 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
         pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    } else if (h->finish) {
+        // large unpartitioned bodies: the whole call is ONE launch too -- tile and particle workgroups of all n substeps in one grid,
+        // ordered by data instead of launch boundaries (pj_blocked.hip: pjb_call_kernel)
+        pjb_launch_call(h->stream, h->blk, 0u, n, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else

@@ -39,8 +39,8 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             if ((rc = enqueue_phase_a(h, &ev[4 * i])) || (rc = enqueue_phase_b(h))) break;
         } else if (pjs && h->fused) {   // tet | fused x (n-1) | particle: what tetsim_step_n runs
             pj_fused_substep(h, i == 0, i + 1 == n, &ev[4 * i]);
-        } else if (pjs && h->finish) {   // one launch per substep: the tet kernel finishes the particles too
-            pj_finish_substep(h, i == 0, &ev[4 * i]);
+        } else if (pjs && h->finish) {   // ONE launch for the n substeps, as tetsim_step_n runs it (tile and particle workgroups in one grid)
+            if (i == 0) pjb_launch_call(h->stream, h->blk, 0u, n, halo_timeout_ms(h), ev[0], ev[1]);
         } else if (pjs) {
             pj_tet(h, ev[4 * i], ev[4 * i + 1]);
             pj_vertex(h, 0, h->pj.nv_owned, ev[4 * i + 2], ev[4 * i + 3]);
@@ -68,8 +68,8 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             if (i > 0) { HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1])); out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET]++; }
             if (i + 1 == n) { HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3])); out->kernel_ms[TETSIM_K_VERTEX] += b; out->launches[TETSIM_K_VERTEX]++; }
         } else if (pjs && h->finish && !halo) {
-            HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
-            out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET]++;
+            // TETSIM_K_TET = the one launch; `launches` counts its SUBSTEPS, so that kernel_ms / launches is the time per substep
+            if (i == 0) { HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1])); out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET] += n; }
         } else if (pjs) {
             HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
             HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));

@@ -12,7 +12,10 @@ b = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast")
 assert b.info.fused_particle_pass == 3
 dt = (1 / 60) / 20
 b.simulateSubsteps(20, dt, pp); b.sync()
-for _ in range(3): b.simulate(dt, pp)
+if len(sys.argv) > 1 and sys.argv[1] == "single":
+    for _ in range(3): b.simulate(dt, pp)          # the last launch is ONE substep
+else:
+    b.simulateSubsteps(20, dt, pp)                  # the last launch is 20 substeps: the rows hold the LAST substep's stamps
 b.sync(); b.close()
 tr = np.fromfile("/tmp/substep_trace.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
 groups = (len(v) + 63) // 64
@@ -23,11 +26,14 @@ pc = lambda a: tuple(int(x) for x in np.percentile(a, [0, 10, 50, 90, 100]))
 print("tile start            min %7d p10 %7d median %7d p90 %7d max %7d" % pc(tiles[:, 0] - t0))
 print("tile end              min %7d p10 %7d median %7d p90 %7d max %7d" % pc(tiles[:, 6] - t0))
 print("tile life             min %7d p10 %7d median %7d p90 %7d max %7d" % pc(tiles[:, 6] - tiles[:, 0]))
-names = ["wave start", "last tile's word seen", "all tiles' words seen", "particles finished"]
-for i, n in enumerate(names):
-    print("%-22s min %7d p10 %7d median %7d p90 %7d max %7d" % ((n,) + pc(vg[:, i] - t0)))
-for i in range(3):
-    print("  %-40s median %7d p90 %7d max %7d" % (names[i] + " -> " + names[i + 1], np.median(vg[:, i + 1] - vg[:, i]), np.percentile(vg[:, i + 1] - vg[:, i], 90), (vg[:, i + 1] - vg[:, i]).max()))
+tn = ["start", "staged (wait + loads)", "after barrier", "solved", "stores issued", "after barrier 2", "end"]
+for i in range(6):
+    print("  tile %-32s median %7d p90 %7d max %7d" % (tn[i] + " -> " + tn[i + 1], np.median(tiles[:, i + 1] - tiles[:, i]), np.percentile(tiles[:, i + 1] - tiles[:, i], 90), (tiles[:, i + 1] - tiles[:, i]).max()))
+names = ["wave start", "-", "all tiles' words seen", "particles finished"]
+for i in (0, 2, 3):
+    print("%-22s min %7d p10 %7d median %7d p90 %7d max %7d" % ((names[i],) + pc(vg[:, i] - t0)))
+for i, j in ((0, 2), (2, 3)):
+    print("  %-40s median %7d p90 %7d max %7d" % (names[i] + " -> " + names[j], np.median(vg[:, j] - vg[:, i]), np.percentile(vg[:, j] - vg[:, i], 90), (vg[:, j] - vg[:, i]).max()))
 span = max(vg[:, 3].max(), tiles[:, 6].max()) - t0
 for f in np.linspace(0, 1, 13):
     tt = t0 + f * span
