@@ -166,7 +166,7 @@ def other_configs():
         body.close()
         return {"value": round(len(t) * n_sub * frames / el / 1e6, 2), "unit": "M tet-solves/s", "ms_per_frame": round(el / frames * 1e3, 4),
                 "us_per_substep": round(el / frames / n_sub * 1e6, 2), "frames": frames,
-                "launches_per_substep": (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3), 3: 1}[mode]}
+                "launches_per_substep": (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3)}[mode]}
 
     # config 1: Dragon, the reference's CPU solver (Neo-Hookean Gauss-Seidel), 10 substeps per frame
     c1 = {"workload": "Dragon (%d tets, %d particles), Neo-Hookean XPBD Gauss-Seidel, 10 substeps/frame" % (len(dtets), len(dv))}
@@ -220,7 +220,7 @@ def other_configs():
         el = time.perf_counter() - t0
         c4[key] = {"value": round(len(t) * SUBSTEPS * 20 / el / 1e6, 1), "unit": "M tet-solves/s", "ms_per_frame": round(el / 20 * 1e3, 4),
                    "mean_abs_detF_minus_1_after_1_5_30_frames": res,
-                   "launches_per_substep": (body.info.num_levels + (0 if body.info.fused_particle_pass else 1)) if body.info.num_levels else {0: 2, 3: 1}.get(int(body.info.fused_particle_pass), 1)}
+                   "launches_per_substep": (body.info.num_levels + (0 if body.info.fused_particle_pass else 1)) if body.info.num_levels else 2}
         body.close()
     out["config4_lattice_1m_neohookean_gs_vs_jacobi"] = c4
     return out
@@ -638,8 +638,6 @@ def beyond_mall(args, device, copy_peak, cells=110, frames=10):
     tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)
     b_alg = tet_bytes + VERTEX_BYTES * len(v) / len(t)
     tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
-    if not pr["vertex_launches"]:   # tile-finished particle pass: one launch per substep carries the particle rows too
-        tet_bytes = b_alg
     ach = tet_bytes * pr["tets_per_tet_launch"] / (tet_us * 1e-6) / 1e9
     res = {"workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles), same solver and kernels, %d frames of %d substeps" % (cells, len(t), len(v), frames, SUBSTEPS),
            "value": round(value, 1), "unit": "M tet-solves/s", "ms_per_step": round(el / frames * 1e3, 4), "finite": finite,
@@ -1002,10 +1000,7 @@ def run(args, rank, world, local_rank, ranks):
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3 if pr["vertex_launches"] else 0.0
         units = pr["tets_per_tet_launch"]
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
-        mode = int(body.info.fused_particle_pass)
-        if mode == 3:     # tile-finished particle pass: the substep is ONE launch, the tet kernel does the particle rows too
-            kname, tet_bytes = "pjb_tet_finish_kernel", b_alg
-        elif mode:        # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
+        if body.info.fused_particle_pass:   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
             kname, tet_bytes = "pjb_tet_fused_kernel", b_alg
         achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
         traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None

@@ -174,8 +174,6 @@ struct tetsim_body {
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
     bool v_pending = false;           // flag path: the interior particles of the last enqueued substep are not signalled yet (flush_v)
     uint32_t fuse_step = 0;           // substep index inside the current run (enqueue_substep)
-    bool finish = false;              // one-launch substep: tile workgroups + particle workgroups in one grid, pjb_substep_kernel (large unpartitioned bodies)
-    uint32_t* d_fin_stat = nullptr;   // [4] its particle waves' statistics: sums re-read, waits given up (tetsim_sync reports those)
     bool fin_in_b = false;            // the latest end-of-substep positions are in pos_final_b (only between the kernels of one call)
     std::vector<int32_t> tet_perm;  // blocked: device tet position -> local tet index
     // Particles are renumbered on the device (Morton order inside the interior segment) for locality; the API keeps
@@ -293,7 +291,6 @@ struct HostProfScope {
 void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e);   // one substep of a fused body (tet | fused x (n-1) | particle)
-void pj_finish_substep(tetsim_body* h, bool first, hipEvent_t* e);
 void pj_repredict(tetsim_body* h);
 void nh_sweep(tetsim_body* h, bool fold = false);   // fold: first touchers do the particle pass between two substeps
 // first / last: position inside a run of substeps enqueued back to back with one dt

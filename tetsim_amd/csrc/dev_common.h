@@ -84,18 +84,6 @@ struct PJBlk {
     // two-layer ghost regions: ghosts [nv_owned, nv_owned + n_ghost1) come from ghost_alt, the second layer from ghost2
     const float4* ghost2 = nullptr;
     uint32_t n_ghost1 = 0xffffffffu;
-    // One launch per substep (pjb_substep_kernel): behind the tile workgroups the grid carries PARTICLE workgroups, one wave per group
-    // of 64 consecutive particles; a wave waits until every tile its group depends on has said "my partial sums of this substep are
-    // out" (tile_done[tile] == the substep's sequence number), then runs the particle kernel's arithmetic for the group.
-    const uint32_t* vg_off = nullptr;        // [groups+1] per particle group: range into vg_tiles
-    const uint32_t* vg_tiles = nullptr;      // the tiles that deliver a partial sum to a particle of the group
-    uint32_t* tile_done = nullptr;           // [nb] sequence number of the last substep whose partial sums the tile has stored
-    const uint32_t* tg_off = nullptr;        // [nb+1] per tile: range into tg_groups
-    const uint32_t* tg_groups = nullptr;     // the particle groups the tile's particles belong to (what its NEXT substep waits for)
-    const uint32_t* sched = nullptr;         // [8][tiles_per_xcd + quads_per_xcd] the order in which each XCD meets its tiles and particle quads
-    uint32_t* group_done = nullptr;          // [groups] sequence number of the last substep the group's particles have been finished for
-    uint32_t* fin_stat = nullptr;            // [0]: partial sums re-read because they had not landed yet, [1]: waits given up (error), [2..3]: polls
-    uint32_t n_groups = 0;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
 };
@@ -148,7 +136,6 @@ void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const ui
 void nh_launch_post_predict_list_fast(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
 // in its queue is done" -- a signal kernel folded into its successor
-void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t first_substep, uint32_t n_substeps, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr, uint32_t* raise_word = nullptr);
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)

@@ -64,8 +64,8 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd)
 // tetsim_step_n the latter).  acc = sum of V*goal, wsum = sum of V (a constant), prev = end of the previous substep.
 struct VertexOut { f3 p, vel, pred; };
 // (Every multiply-add below is spelled out: with -ffp-contract=fast the compiler decides per call site which products to fuse, and this
-// function is inlined into four kernels whose results must agree bit for bit.  The spelling is the one the particle kernel has always
-// compiled to.)
+// function is inlined into several kernels whose results must agree bit for bit -- a fourth call site (profiles/r03_tile_finish.txt)
+// came out an ulp off.  The spelling is the one the particle kernel has always compiled to.)
 __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 prev, const DevParams& P, uint32_t v) {
     const float rw = __builtin_amdgcn_rcpf(wsum);
     f3 p = F3(acc.x * rw, acc.y * rw, acc.z * rw);  // 0 * inf = NaN for a particle without tets, as in the reference
@@ -94,83 +94,6 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
 
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
-// ---- one launch per substep: particle workgroups behind the tile workgroups -------------------------------------
-// One lane finishes one particle INSIDE the substep's launch: the particle kernel's arithmetic (pjb_vertex_body below: same lists,
-// same order of additions, same pjb_vertex_update).  The sums were written in this very launch by other workgroups, possibly on other
-// XCDs: they are read from the memory side (dev_store.h: load_coherent) and carry the substep's sequence number in their fourth
-// float -- a sum that has not landed yet gives itself away and is read again.  Every tile that reads a particle's prediction has
-// delivered its sums before the particle is finished, so writing the next prediction in place races with nobody.
-// What a particle wave can ask for BEFORE its tiles are done (constants): requested, then the wave waits -- the finish itself is one
-// dependent trip (the sums and the previous position), not two.  Register budget: the kernel must stay within 64 VGPRs (8 waves per
-// SIMD, the tiles' occupancy): list entries become byte offsets at once, absent ones alias the first entry and are masked out.
-struct FinishPre { uint32_t off[9]; uint32_t valid; float wsum; uint32_t v; bool live; };
-__device__ __forceinline__ FinishPre pjb_finish_prefetch(const PJBlk& d, const uint32_t v_in) {
-    FinishPre p;
-    p.live = v_in < d.nv_owned;
-    p.v = p.live ? v_in : 0u;
-    const uint32_t* col = d.vp_ell + p.v;
-    p.valid = 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < 9u; j++) {   // (host: vp_cols <= 9 for these bodies)
-        const uint32_t idx = (j < d.vp_cols) ? col[static_cast<size_t>(j) * d.nv_pad] : 0xffffffffu;
-        p.valid |= (idx != 0xffffffffu ? 1u : 0u) << j;
-        p.off[j] = idx != 0xffffffffu ? idx : 0u;
-    }
-    p.wsum = d.wsum[p.v];
-    return p;
-}
-__device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre& p, const uint32_t seq, const bool first_of_launch) {
-    // one trip: the partial sums of this substep (sequence number seq) and the particle's previous position (seq - 1 if this
-    // group's wave of the previous substep ran in this very launch -- it may not have been through when a prefetch would have asked)
-    float4 g[9];
-#pragma unroll
-    for (uint32_t j = 0; j < 9u; j++) g[j] = load_coherent(d.partial, p.off[j]);
-    float4 pv = load_coherent(d.fin_in, p.v);
-    uint32_t late = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 9u; j++) late |= (__float_as_uint(g[j].w) != seq ? 1u : 0u) << j;
-    late &= p.valid;
-    if (!first_of_launch && __float_as_uint(pv.w) != seq - 1u) late |= 1u << 9;
-    if (__builtin_amdgcn_ballot_w64(late != 0u) != 0ull) {
-        // a word overtook some of the data it announces (nothing orders them at the memory side): look again, politely
-        if (late) __hip_atomic_fetch_add(d.fin_stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t trip = 0; __builtin_amdgcn_ballot_w64(late != 0u) != 0ull && trip < (1u << 16); trip++) {
-            __builtin_amdgcn_s_sleep(4);
-#pragma unroll
-            for (uint32_t j = 0; j < 9u; j++)
-                if ((late >> j) & 1u) {
-                    g[j] = load_coherent(d.partial, p.off[j]);
-                    if (__float_as_uint(g[j].w) == seq) late &= ~(1u << j);
-                }
-            if ((late >> 9) & 1u) {
-                pv = load_coherent(d.fin_in, p.v);
-                if (__float_as_uint(pv.w) == seq - 1u) late &= ~(1u << 9);
-            }
-        }
-        if (late) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // the particle kernel's additions, one for one: eight columns (an absent one adds +0), then -- if anybody in the wave has a
-    // ninth sum -- eight more (the ninth and seven times +0)
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (uint32_t j = 0; j < 8u; j++) {
-        const bool on = (p.valid >> j) & 1u;
-        acc.x += on ? g[j].x : 0.0f; acc.y += on ? g[j].y : 0.0f; acc.z += on ? g[j].z : 0.0f;
-    }
-    if (!__all(((p.valid >> 7) & 1u) == 0u) && d.vp_cols > 8u) {
-        const bool on = (p.valid >> 8) & 1u;
-        acc.x += on ? g[8].x : 0.0f; acc.y += on ? g[8].y : 0.0f; acc.z += on ? g[8].z : 0.0f;
-        const float z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0));   // (+0 the compiler cannot fold: x + 0 is not x for x = -0)
-#pragma unroll
-        for (uint32_t j = 1; j < 8u; j++) { acc.x += z; acc.y += z; acc.z += z; }
-    }
-    if (!p.live) return;
-    const VertexOut o = pjb_vertex_update(xyz(acc), p.wsum, xyz(pv), *d.params, p.v);
-    store_wt(d.fin_out, p.v, make_float4(o.p.x, o.p.y, o.p.z, __uint_as_float(seq)));   // (w: which substep's result this is)
-    store_wt(d.vel, p.v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
-    store_wt(d.pos_pred, p.v, make_float4(o.pred.x, o.pred.y, o.pred.z, __uint_as_float(seq)));
-}
-
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
 // Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
@@ -193,25 +116,20 @@ __device__ __forceinline__ void pjb_finish_lane(const PJBlk& d, const FinishPre&
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 // kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
-// kFinish: the tile of a one-launch substep (pjb_substep_kernel): its partial sums carry the substep's sequence number, and it says
-// "they are out" in tile_done[tile] for the particle workgroups that follow the tiles in the same grid
-template <bool kLean, bool kFused, bool kAlt = false, bool kFinish = false>
-__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
-                                             [[maybe_unused]] uint32_t seq_s = 0u, [[maybe_unused]] uint32_t blk = 0u, [[maybe_unused]] bool first_of_launch = true,
-                                             [[maybe_unused]] uint32_t timeout_ms = 0u) {
+template <bool kLean, bool kFused, bool kAlt = false>
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
     __shared__ float s_gz[4 * kTile];
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
-    const uint32_t rel = kFinish ? blk : xcd_tile(blockIdx.x, tiles_per_xcd);   // (kFinish: the caller's schedule names the tile)
+    const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
 #ifdef TETSIM_ABLATION  // per-tile phase timestamps (TETSIM_DEBUG_TRACE): development build only
-// (kFinish: one clock for all XCDs; of a launch of several substeps the one with index 10 -- mid-pipeline -- or the only one)
-#define TETSIM_STAMP(i) do { if (d.trace && tid == 0 && (!kFinish || seq_s == 10u || first_of_launch)) d.trace[8ull * b + (i)] = kFinish ? static_cast<unsigned long long>(wall_clock64()) : __builtin_amdgcn_s_memtime(); } while (0)
+#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
 #else
 #define TETSIM_STAMP(i) do { } while (0)
@@ -257,69 +175,13 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         for (uint32_t j = 0; j < 8u; j++) src[j] = (j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;   // (uniform)
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
     }
-    [[maybe_unused]] uint32_t seq = 0, dep_n = 0, dep_g = 0;
-    if constexpr (kFinish) {
-        seq = d.params->epoch + seq_s;
-        const uint32_t f0 = d.tg_off[b];
-        dep_n = d.tg_off[b + 1] - f0;
-        dep_g = d.tg_groups[f0 + (tid < dep_n ? tid : 0u)];
-    }
     const uchar4 li = d.tet_lidx[e];
+    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
+    const float4 q_old = d.quat[e];
     const float V = d.vol[e];
     const uint2 ent_row = d.lc_ent[e];
-    float4 ra, rb, rc, q_old;
     float4 pos_stage;
-    if constexpr (kFinish) {
-        // Substeps after the first of a launch: the predictions come from particle waves of THIS launch, and this tile's own record
-        // from the workgroup that solved the tile one substep ago -- which may still be running when this one is dispatched.  Wait
-        // until every group this tile's particles belong to has been finished for the previous substep (one word per group, one
-        // lane each; those groups waited for this tile's previous incarnation among others), THEN ask for the record and the
-        // predictions, from the memory side like everything that crosses workgroups inside a launch.  Each prediction carries its
-        // substep's sequence number; one that has not landed yet is read again.
-        if (!first_of_launch) {
-            if (tid < 64u) {   // the first wave asks, the others wait at the barrier
-                const long long limit = 100000ll * timeout_ms, w0 = limit ? wall_clock64() : 0ll;
-                for (uint32_t base = 0; base < dep_n; base += 64u) {
-                    bool pending = base + tid < dep_n;
-                    const uint32_t grp = base == 0u ? dep_g : (pending ? d.tg_groups[d.tg_off[b] + base + tid] : 0u);
-                    while (true) {
-                        if (pending) pending = static_cast<int32_t>(__hip_atomic_load(d.group_done + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (seq - 1u)) < 0;
-                        if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
-                        __builtin_amdgcn_s_sleep(8);
-                        if (limit && wall_clock64() - w0 > limit) {   // (the error word says the state is invalid from here on; going on keeps the launch finite)
-                            if (tid == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            break;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-#if defined(TETSIM_CALL_PLAIN_RECORD)
-            ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e]; q_old = d.quat[e];
-#elif defined(TETSIM_CALL_L2_RECORD)
-            ra = load_l2(d.rest_a, e); rb = load_l2(d.rest_b, e); rc = load_l2(d.rest_c, e); q_old = load_l2(d.quat, e);
-#else
-            ra = load_coherent(d.rest_a, e); rb = load_coherent(d.rest_b, e); rc = load_coherent(d.rest_c, e);
-            q_old = load_coherent(d.quat, e);
-#endif
-            pos_stage = load_coherent(d.pos_pred, vid);
-            uint32_t trips = 0;
-            while (__builtin_amdgcn_ballot_w64(__float_as_uint(pos_stage.w) != seq - 1u) != 0ull && trips++ < (1u << 16)) {
-                if (trips == 1u && __float_as_uint(pos_stage.w) != seq - 1u) __hip_atomic_fetch_add(d.fin_stat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_s_sleep(4);
-                if (__float_as_uint(pos_stage.w) != seq - 1u) pos_stage = load_coherent(d.pos_pred, vid);
-            }
-        } else {
-            ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e];
-            q_old = d.quat[e];
-            pos_stage = d.pos_pred[vid];
-        }
-    } else {
-        ra = d.rest_a[e]; rb = d.rest_b[e]; rc = d.rest_c[e];
-        q_old = d.quat[e];
-    }
-    if constexpr (kFinish) {
-    } else if constexpr (kFused) {
+    if constexpr (kFused) {
         // (a ghost would keep its received prediction; fused bodies have none)
         f3 g[8];
 #pragma unroll
@@ -419,20 +281,9 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
             acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
         }
-        if constexpr (kFinish) acc.w = __uint_as_float(seq);
         store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
-    if constexpr (kFinish) {
-        // 4. "this tile's partial sums of substep seq are out": one word, written through like the sums.  Nothing orders it behind
-        // them at the memory side (other waves' stores, other channels) -- the reader checks every sum's own sequence number; the word
-        // only says when looking is worth it.  The tile does not wait for anything here: it leaves, its slot is free.
-#ifndef TETSIM_CALL_NO_ACK
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's write-through stores (record, partial sums) are acknowledged
-#endif
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(d.tile_done + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 #undef TETSIM_STAMP
 }
 
@@ -468,82 +319,6 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                           uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-// ---- a whole tetsim_step_n call as ONE launch: per substep tile workgroups, then particle workgroups, all in one grid ---------------
-// Substep s owns blocks [s * B, (s + 1) * B): first the tet kernel's tiles (same mapping, same code, kFinish), behind them the particle
-// workgroups -- four waves each, a wave per group of 64 consecutive particles.  Nothing synchronises the grid as a whole; a block waits
-// for exactly what it needs, and only for blocks in front of it:
-//   * a particle wave waits until every tile that feeds its group has said "my partial sums of substep s are out" (tile_done[tile]),
-//     then runs the particle kernel's arithmetic for its 64 particles (pjb_finish_lane) and says so (group_done[group]);
-//   * a tile of substep s > first waits until every group its particles belong to is finished for s - 1, then reads their predictions.
-// Workgroups are dispatched in index order (per XCD; B is a multiple of 8, so a tile and a group keep their XCD from substep to
-// substep), so whatever a block waits for has been dispatched before it: the block with the lowest index that is not complete either
-// runs with everything it needs, or is next in its XCD's queue with free slots in front of it -- no deadlock, and every wait is bounded
-// all the same.  A particle workgroup takes no slot from a tile of its own substep (they are all dispatched before it); it runs in the
-// slots the last, partial round of tiles leaves idle, beside the tail of its substep's tiles and the head of the next substep's.
-// The launch boundaries of a substep and the serialisation they enforce (every particle after every tile, every tile after every
-// particle) are gone; what orders the work is data.  Words and data are written through and read from the memory side; every datum
-// carries its substep's sequence number (partial sums, predictions), a word only says when looking is worth it.
-// Hazards without a grid-wide barrier: a tile overwrites its partial sums of s - 1 only after the groups that read them are finished
-// (it waits for exactly those); a wave overwrites a prediction of s - 1 only after every tile that reads it has delivered its sums of s
-// (it waits for exactly those); a tile's own record is touched by nobody else.
-template <bool kLean>
-__device__ __forceinline__ void pjb_call_body(const PJBlk& d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t first_s,
-                                              uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    // the schedule (host, tetsim_create.hip): per XCD a sequence of `period` items per substep -- a tile, or a quad of particle groups
-    const uint32_t period = tiles_per_xcd + quads_per_xcd, per_substep = period * 8u;
-    const uint32_t s_rel = blockIdx.x / per_substep, r = blockIdx.x - s_rel * per_substep;
-    const uint32_t item = d.sched[(r & 7u) * period + (r >> 3)];        // (block r of a substep runs on XCD r % 8)
-    const uint32_t seq_s = first_s + s_rel;
-    if (item == 0xffffffffu) return;
-    if (!(item & 0x80000000u)) {
-        pjb_tet_body<kLean, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, seq_s, item, s_rel == 0u, timeout_ms);
-        return;
-    }
-    const uint32_t quad = item & 0x7fffffffu;
-    const uint32_t g = quad * (kTile / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (g >= d.n_groups) return;
-    const uint32_t seq = d.params->epoch + seq_s;
-#ifdef TETSIM_ABLATION   // development build: this wave's timeline behind the tiles' rows (TETSIM_DEBUG_TRACE, tools/trace_substep.py)
-#define VG_STAMP(i) do { if (d.trace && lane == 0 && (seq_s == 10u || s_rel == 0u)) d.trace[8ull * (d.nb + g) + (i)] = static_cast<unsigned long long>(wall_clock64()); } while (0)   // (one clock for all XCDs, 10 ns)
-#else
-#define VG_STAMP(i) do { } while (0)
-#endif
-    VG_STAMP(0);
-    const FinishPre pre = pjb_finish_prefetch(d, g * 64u + lane);
-    const uint32_t o0 = d.vg_off[g], nd = d.vg_off[g + 1] - o0;
-    const long long limit = 100000ll * timeout_ms;   // 100 MHz ticks; 0 = unbounded
-    const long long w0 = limit ? wall_clock64() : 0ll;
-    for (uint32_t base = 0; base < nd; base += 64u) {   // (64 tiles at a time; a group of the lattice depends on ~10)
-        const bool mine = base + lane < nd;
-        const uint32_t tile = mine ? d.vg_tiles[o0 + base + lane] : 0u;
-        bool pending = mine;
-        while (true) {
-            if (pending) pending = static_cast<int32_t>(__hip_atomic_load(d.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0;
-            if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
-            __builtin_amdgcn_s_sleep(8);   // ~0.25 us on top of the load's own trip
-            if (limit && wall_clock64() - w0 > limit) {
-                if (lane == 0) __hip_atomic_fetch_add(d.fin_stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;
-            }
-        }
-    }
-    VG_STAMP(2);
-    pjb_finish_lane(d, pre, seq, s_rel == 0u);
-#ifndef TETSIM_CALL_NO_ACK
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): positions, velocities, predictions acknowledged
-#endif
-    if (lane == 0) __hip_atomic_store(d.group_done + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    VG_STAMP(3);
-#undef VG_STAMP
-}
-__global__ __launch_bounds__(kTile, 8) void pjb_call_kernel(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd, uint32_t first_s,
-                                                         uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    pjb_call_body<false>(d, tile_count, tiles_per_xcd, quads_per_xcd, first_s, timeout_ms TETSIM_DBG_ARG);
-}
-__global__ __launch_bounds__(kTile, 8) void pjb_call_kernel_constant_rest(PJBlk d, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t quads_per_xcd,
-                                                                       uint32_t first_s, uint32_t timeout_ms TETSIM_DBG_PARAM) {
-    pjb_call_body<true>(d, tile_count, tiles_per_xcd, quads_per_xcd, first_s, timeout_ms TETSIM_DBG_ARG);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -934,15 +709,6 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
-}
-void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t first_substep, uint32_t n_substeps, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
-    if (d.nb == 0 || n_substeps == 0) return;
-    const uint32_t per_xcd = (d.nb + 7u) / 8u;
-    const uint32_t quads = (d.n_groups + kTile / 64u - 1u) / (kTile / 64u), quads_per_xcd = (quads + 7u) / 8u;
-    const dim3 grid((per_xcd + quads_per_xcd) * 8u * n_substeps);
-    auto* kernel = d.lean ? pjb_call_kernel_constant_rest : pjb_call_kernel;
-    if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, e0, e1, 0, d, d.nb, per_xcd, quads_per_xcd, first_substep, timeout_ms TETSIM_DBG_LAUNCH);
-    else hipLaunchKernelGGL(kernel, grid, dim3(kTile), 0, s, d, d.nb, per_xcd, quads_per_xcd, first_substep, timeout_ms TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;

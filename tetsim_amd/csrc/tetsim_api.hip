@@ -144,13 +144,6 @@ void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e) {
         h->fin_in_b = false;
     }
 }
-// One substep of a body with the one-launch substep (pj_blocked.hip: pjb_substep_kernel: tile workgroups, then particle workgroups, in
-// one grid); its partial sums carry the sequence number DevParams::epoch + the substep's index inside the call.  e[0..1]: the
-// kernel's begin / end events.
-void pj_finish_substep(tetsim_body* h, bool first, hipEvent_t* e) {
-    if (first) h->fuse_step = 0;
-    pjb_launch_call(h->stream, h->blk, h->fuse_step++, 1u, halo_timeout_ms(h), e ? e[0] : nullptr, e ? e[1] : nullptr);
-}
 void pj_repredict(tetsim_body* h) {
     if (h->blocked) pjb_launch_repredict(h->stream, h->blk);
     else h->fast ? pj_launch_repredict_fast(h->stream, h->pj) : pj_launch_repredict_precise(h->stream, h->pj);
@@ -182,8 +175,6 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
             if (rc) return rc;
         } else if (h->fused) {
             pj_fused_substep(h, first, last, nullptr);
-        } else if (h->finish && !getenv("TETSIM_DEBUG_CALL_SPLIT")) {
-            pj_finish_substep(h, first, nullptr);
         } else {
             pj_tet(h);
             pj_vertex(h, 0, h->pj.nv_owned);
@@ -265,12 +256,6 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
         pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
-    } else if (h->finish) {
-        // large unpartitioned bodies: the whole call is ONE launch too -- tile and particle workgroups of all n substeps in one grid,
-        // ordered by data instead of launch boundaries (pj_blocked.hip: pjb_call_kernel)
-        pjb_launch_call(h->stream, h->blk, 0u, n, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else
@@ -477,13 +462,8 @@ void tetsim_destroy(tetsim_handle h) {
     (void)hipSetDevice(h->opt.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->d_fin_stat && getenv("TETSIM_DEBUG_TRACE")) {   // development: how often a particle wave had to look twice
-        uint32_t st[4] = {0, 0, 0, 0};
-        if (hipMemcpy(st, h->d_fin_stat, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[tetsim] one-launch substep: %u lanes re-read a partial sum that had not landed, %u waits given up\n", st[0], st[1]);
-    }
     if (h->blk.trace && getenv("TETSIM_DEBUG_TRACE")) {
-        std::vector<unsigned long long> tr(8ull * (static_cast<size_t>(h->blk.nb) + h->blk.n_groups));
+        std::vector<unsigned long long> tr(8ull * h->blk.nb);
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
     }
@@ -599,18 +579,6 @@ int tetsim_sync(tetsim_handle h) {
             h->graphs.clear();
             return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "
                                         "the state since then is invalid; this body falls back to one kernel per substep");
-        }
-    }
-    if (h->d_fin_stat) {   // one-launch substep: a particle wave gave up waiting for a tile, or never saw a partial sum (never in a correct run)
-        uint32_t st[4] = {0, 0, 0, 0};
-        HIPCHK(h, hipMemcpy(st, h->d_fin_stat, sizeof st, hipMemcpyDeviceToHost));
-        if (st[1]) {
-            HIPCHK(h, hipMemset(h->d_fin_stat, 0, sizeof st));
-            h->finish = false;   // tet kernel + particle kernel from now on
-            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-            h->graphs.clear();
-            return fail(h, TETSIM_EHIP, "one-launch substep: a particle workgroup waited in vain for a tile's partial sums; the state since then is invalid; this body "
-                                        "falls back to a tet kernel and a particle kernel per substep");
         }
     }
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted

@@ -328,140 +328,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 h->info.fused_particle_pass = 2u;
             }
         }
-        // One launch per CALL (pj_blocked.hip: pjb_call_kernel): unpartitioned bodies too large for the fused / frame kernels.
-        // Particles in groups of 64 consecutive ids (particles and tiles are both in Morton order: a group is fed by a handful of
-        // neighbouring tiles); per group, the tiles that hold a slot for one of its particles -- the tiles its wave waits for.
-        // TETSIM_ONE_LAUNCH_SUBSTEP=0 keeps the tet kernel + particle kernel substep (development A/B); =1 uses the one-launch substep
-        // for ANY unpartitioned blocked body, instead of the fused / frame kernels (tests: small bodies).
-        const char* const one_env = getenv("TETSIM_ONE_LAUNCH_SUBSTEP");   // (read per body: tests build both kinds in one process)
-        const bool allow_one = !(one_env && one_env[0] == '0'), force_one = one_env && one_env[0] == '1';
-        if (allow_one && (!h->fused || force_one) && !h->partitioned && nvo == nvl && ntl > 0 && B.every_owned_particle_has_a_partial && B.max_partials <= 9) {
-            const uint32_t groups = (nvo + 63u) / 64u;
-            std::vector<std::vector<uint32_t>> of_group(groups);
-            for (uint32_t b = 0; b < B.num_blocks; b++)
-                for (uint32_t u = B.blk_vert_off[b]; u < B.blk_vert_off[b + 1]; u++) {
-                    const uint32_t v = static_cast<uint32_t>(B.blk_verts[u]);
-                    if (v < nvo && (of_group[v / 64u].empty() || of_group[v / 64u].back() != b)) of_group[v / 64u].push_back(b);   // (b ascends)
-                }
-            std::vector<uint32_t> vg_off(groups + 1u, 0u), vg_tiles;
-            bool ok = true;
-            for (uint32_t g = 0; g < groups; g++) {
-                ok = ok && !of_group[g].empty();   // (a group no tile feeds would never be finished; cannot happen when every particle has a partial sum)
-                // the tile dispatched LAST first (pjb_substep_kernel polls that one alone before it asks about the others): tile b is
-                // the (b % per_xcd)-th of its XCD's sequence (pj_blocked.hip: xcd_tile)
-                const uint32_t per_xcd = (B.num_blocks + 7u) / 8u;
-                std::stable_sort(of_group[g].begin(), of_group[g].end(), [&](uint32_t a, uint32_t c) { return a % per_xcd > c % per_xcd; });
-                vg_tiles.insert(vg_tiles.end(), of_group[g].begin(), of_group[g].end());
-                vg_off[g + 1] = static_cast<uint32_t>(vg_tiles.size());
-            }
-            // ... and per tile the groups its particles belong to (what the tile's next substep waits for)
-            std::vector<uint32_t> tg_off(B.num_blocks + 1u, 0u), tg_groups;
-            for (uint32_t b = 0; b < B.num_blocks; b++) {
-                std::vector<uint32_t> gs;
-                for (uint32_t u = B.blk_vert_off[b]; u < B.blk_vert_off[b + 1]; u++) {
-                    const uint32_t v = static_cast<uint32_t>(B.blk_verts[u]);
-                    if (v < nvo) gs.push_back(v / 64u);
-                }
-                std::sort(gs.begin(), gs.end());
-                gs.erase(std::unique(gs.begin(), gs.end()), gs.end());
-                tg_groups.insert(tg_groups.end(), gs.begin(), gs.end());
-                tg_off[b + 1] = static_cast<uint32_t>(tg_groups.size());
-            }
-            if (ok) {
-                uint32_t *dto, *dtg;
-                if ((rc = dev_alloc(h, &dto, tg_off.size()))) return rc;
-                if ((rc = dev_alloc(h, &dtg, std::max<size_t>(tg_groups.size(), 1)))) return rc;
-                if ((rc = dev_alloc(h, &k.group_done, groups))) return rc;
-                if ((rc = upload(h, dto, tg_off))) return rc;
-                if ((rc = upload(h, dtg, tg_groups))) return rc;
-                HIPCHK(h, hipMemset(k.group_done, 0, groups * sizeof(uint32_t)));
-                k.tg_off = dto; k.tg_groups = dtg;
-                // The schedule: workgroups are dispatched in index order, block r of a substep on XCD r % 8.  What it must achieve:
-                // a tile of substep s + 1 needs the groups of its particles finished for s, and those need every tile that touches
-                // them -- the tile's SPATIAL NEIGHBOURS of substep s.  So the distance, in dispatch order, between a tile and its
-                // neighbours bounds how far two consecutive substeps can overlap: in Morton order a neighbour across a fold of the
-                // curve is hundreds of tiles away (measured: 54 us per substep, tiles waiting in their slots).  Each XCD therefore
-                // SWEEPS its eighth of the tiles (a compact region: an octant of the box) along one axis, layer by layer -- a
-                // neighbour is at most a layer (~60 tiles) away -- and regions on either side of the body's mid-plane sweep towards
-                // each other, so that two regions meet their common face at the same moment of the sweep.
-                // The quad of particle groups that follows a stretch of tiles is put `lag` tiles BEHIND the last tile of this XCD
-                // that feeds it -- about one residency round (256 workgroups per XCD): its tiles are done when it gets a slot, and
-                // it holds the slot for its own ~4 us only.  TETSIM_DEBUG_SCHED_LAG / _SWEEP=0 override (development).
-                {
-                    const uint32_t per_xcd = (B.num_blocks + 7u) / 8u;
-                    const uint32_t quads = (groups + 3u) / 4u, quads_per_xcd = (quads + 7u) / 8u, period = per_xcd + quads_per_xcd;
-                    const char* le = getenv("TETSIM_DEBUG_SCHED_LAG");
-                    const char* se = getenv("TETSIM_DEBUG_SCHED_SWEEP");
-                    const uint32_t lag = le ? static_cast<uint32_t>(strtoul(le, nullptr, 10)) : 288u;
-                    const bool sweep = !(se && se[0] == '0');
-                    // tile centroids (mean of the tile's particles), the axis of largest extent, the mid-plane
-                    std::vector<float> cen(3ull * B.num_blocks, 0.0f);
-                    float lo3[3] = {1e30f, 1e30f, 1e30f}, hi3[3] = {-1e30f, -1e30f, -1e30f};
-                    for (uint32_t b = 0; b < B.num_blocks; b++) {
-                        double acc3[3] = {0, 0, 0};
-                        const uint32_t u0 = B.blk_vert_off[b], u1 = B.blk_vert_off[b + 1];
-                        for (uint32_t u = u0; u < u1; u++) {
-                            const float4 q = pos[static_cast<uint32_t>(B.blk_verts[u])];
-                            acc3[0] += q.x; acc3[1] += q.y; acc3[2] += q.z;
-                        }
-                        for (int c = 0; c < 3; c++) {
-                            cen[3ull * b + c] = static_cast<float>(acc3[c] / std::max(1u, u1 - u0));
-                            lo3[c] = std::min(lo3[c], cen[3ull * b + c]); hi3[c] = std::max(hi3[c], cen[3ull * b + c]);
-                        }
-                    }
-                    int axis = 0;
-                    for (int c = 1; c < 3; c++) if (hi3[c] - lo3[c] > hi3[axis] - lo3[axis]) axis = c;
-                    const float mid = 0.5f * (lo3[axis] + hi3[axis]);
-                    std::vector<uint32_t> sched(8ull * period, 0xffffffffu);
-                    for (uint32_t x = 0; x < 8u; x++) {
-                        std::vector<uint32_t> order;
-                        double zsum = 0.0;
-                        for (uint32_t i = 0; i < per_xcd; i++) {
-                            const uint32_t b = x * per_xcd + i;
-                            if (b < B.num_blocks) { order.push_back(b); zsum += cen[3ull * b + axis]; }
-                        }
-                        if (sweep && !order.empty()) {
-                            const bool up = zsum / static_cast<double>(order.size()) < mid;   // below the mid-plane: sweep towards it
-                            std::stable_sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t c2) {
-                                const float za = cen[3ull * a2 + axis], zc = cen[3ull * c2 + axis];
-                                return up ? za < zc : za > zc;
-                            });
-                        }
-                        std::vector<uint32_t> where(per_xcd, 0u);   // position of each of this XCD's tiles in its sweep
-                        for (uint32_t k2 = 0; k2 < order.size(); k2++) where[order[k2] - x * per_xcd] = k2;
-                        std::vector<std::pair<uint64_t, uint32_t>> items;
-                        for (uint32_t k2 = 0; k2 < order.size(); k2++) items.push_back({static_cast<uint64_t>(k2) * 2u, order[k2]});
-                        for (uint32_t q = 0; q < quads_per_xcd; q++) {
-                            const uint32_t quad = x * quads_per_xcd + q;
-                            if (quad >= quads) continue;
-                            uint32_t last = 0;
-                            for (uint32_t g = quad * 4u; g < std::min(groups, quad * 4u + 4u); g++)
-                                for (uint32_t b : of_group[g]) if (b / per_xcd == x) last = std::max(last, where[b % per_xcd]);
-                            items.push_back({static_cast<uint64_t>(std::min(last + lag, per_xcd)) * 2u + 1u, 0x80000000u | quad});
-                        }
-                        std::stable_sort(items.begin(), items.end(), [](const auto& a2, const auto& c2) { return a2.first < c2.first; });
-                        for (size_t k2 = 0; k2 < items.size(); k2++) sched[static_cast<size_t>(x) * period + k2] = items[k2].second;
-                    }
-                    uint32_t* dsc;
-                    if ((rc = dev_alloc(h, &dsc, sched.size()))) return rc;
-                    if ((rc = upload(h, dsc, sched))) return rc;
-                    k.sched = dsc;
-                }
-                uint32_t *dvo, *dvt;
-                if ((rc = dev_alloc(h, &dvo, vg_off.size()))) return rc;
-                if ((rc = dev_alloc(h, &dvt, std::max<size_t>(vg_tiles.size(), 1)))) return rc;
-                if ((rc = dev_alloc(h, &k.tile_done, B.num_blocks))) return rc;
-                if ((rc = dev_alloc(h, &h->d_fin_stat, 4))) return rc;
-                if ((rc = upload(h, dvo, vg_off))) return rc;
-                if ((rc = upload(h, dvt, vg_tiles))) return rc;
-                HIPCHK(h, hipMemset(k.tile_done, 0, B.num_blocks * sizeof(uint32_t)));   // (sequence numbers start at 65537: 0 never matches)
-                HIPCHK(h, hipMemset(h->d_fin_stat, 0, 4 * sizeof(uint32_t)));
-                k.vg_off = dvo; k.vg_tiles = dvt; k.fin_stat = h->d_fin_stat; k.n_groups = groups;
-                h->finish = true;
-                h->fused = h->frame = false;
-                h->info.fused_particle_pass = 3u;
-            }
-        }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;
         if ((rc = upload(h, bvo, B.blk_vert_off))) return rc;
         if ((rc = upload(h, bv, B.blk_verts))) return rc;
@@ -479,9 +345,8 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
         if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
-            const size_t rows = static_cast<size_t>(B.num_blocks) + k.n_groups;   // (one-launch substep: a row per particle group behind the tiles')
-            if ((rc = dev_alloc(h, &k.trace, 8ull * rows))) return rc;
-            HIPCHK(h, hipMemset(k.trace, 0, 8ull * rows * sizeof(unsigned long long)));
+            if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
+            HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));
         }
     } else {
         if ((rc = dev_alloc(h, &d.tet_idx, ntl))) return rc;

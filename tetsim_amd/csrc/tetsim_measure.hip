@@ -39,8 +39,6 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             if ((rc = enqueue_phase_a(h, &ev[4 * i])) || (rc = enqueue_phase_b(h))) break;
         } else if (pjs && h->fused) {   // tet | fused x (n-1) | particle: what tetsim_step_n runs
             pj_fused_substep(h, i == 0, i + 1 == n, &ev[4 * i]);
-        } else if (pjs && h->finish) {   // ONE launch for the n substeps, as tetsim_step_n runs it (tile and particle workgroups in one grid)
-            if (i == 0) pjb_launch_call(h->stream, h->blk, 0u, n, halo_timeout_ms(h), ev[0], ev[1]);
         } else if (pjs) {
             pj_tet(h, ev[4 * i], ev[4 * i + 1]);
             pj_vertex(h, 0, h->pj.nv_owned, ev[4 * i + 2], ev[4 * i + 3]);
@@ -67,9 +65,6 @@ int tetsim_profile(tetsim_handle h, uint32_t n, double dt, const TetSimParams* p
             // not counted), TETSIM_K_VERTEX = the one particle kernel that ends the call
             if (i > 0) { HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1])); out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET]++; }
             if (i + 1 == n) { HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3])); out->kernel_ms[TETSIM_K_VERTEX] += b; out->launches[TETSIM_K_VERTEX]++; }
-        } else if (pjs && h->finish && !halo) {
-            // TETSIM_K_TET = the one launch; `launches` counts its SUBSTEPS, so that kernel_ms / launches is the time per substep
-            if (i == 0) { HIPCHK(h, hipEventElapsedTime(&a, ev[0], ev[1])); out->kernel_ms[TETSIM_K_TET] += a; out->launches[TETSIM_K_TET] += n; }
         } else if (pjs) {
             HIPCHK(h, hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]));
             HIPCHK(h, hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
@@ -99,13 +94,11 @@ int tetsim_time_kernels(tetsim_handle h, uint32_t reps, double dt, const TetSimP
     if ((rc = ensure_prediction(h, dt))) return rc;
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     auto tet_once = [&]() {
-        if (pjs && h->finish) { pj_finish_substep(h, true, nullptr); return 1u; }
         if (pjs) { pj_tet(h); return 1u; }
         nh_sweep(h);
         return static_cast<uint32_t>(h->level_off.size() - 1);
     };
     auto vert_once = [&]() {
-        if (pjs && h->finish) return 0u;   // (no particle kernel: TETSIM_K_VERTEX stays 0 launches)
         if (pjs) { pj_vertex(h, 0, h->pj.nv_owned); return 1u; }
         h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
         h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
