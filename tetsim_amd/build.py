@@ -36,6 +36,8 @@ UNITS = {
     "tetsim_measure.hip": ["-ffp-contract=off"],
     "tetsim_create.hip": ["-ffp-contract=off"],
     "tetsim_halo.hip": ["-ffp-contract=off"],
+    "tetsim_comm.hip": ["-ffp-contract=off"],
+    "tetsim_p2p.hip": ["-ffp-contract=off"],
     "tetsim_host.cpp": ["-ffp-contract=off", "-x", "hip"],
     "pj_precise.hip": ["-ffp-contract=off"],
     "pj_fast.hip": ["-ffp-contract=fast"],

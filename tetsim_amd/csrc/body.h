@@ -5,7 +5,9 @@
 //   tetsim_visual.hip  embedded visual mesh (skinning, vertex normals), grab (pin, nearest-particle query)
 //   tetsim_measure.hip measurement: per-kernel profile, kernel timing loops, device copy bandwidth
 //   tetsim_create.hip  construction of the two solvers' device state (host preprocessing -> uploads)
-//   tetsim_halo.hip    multi-GPU: halo choreography (two queues, flag or event synchronised), RCCL / in-process transports
+//   tetsim_halo.hip    multi-GPU: per-substep halo choreography (two queues, flag or event synchronised), in-process group stepping
+//   tetsim_comm.hip    multi-GPU set-up: RCCL communicator, self-test and probe, halo plan
+//   tetsim_p2p.hip     peer-to-peer halo: export / connect (HIP IPC mappings of the neighbours' ghost ranges)
 //   tetsim_host.cpp    host-only entry points: preprocessing, partition plans, the .tetsim container
 //
 // There is NO CPU fallback: every compute entry point needs a working HIP device and fails with

@@ -78,7 +78,7 @@ struct PJBlk {
     const uint32_t* blk_maxsrc = nullptr;    // [nb] longest such list in the tile
     uint32_t ns_pad = 0;
     const DevParams* params = nullptr;
-    // peer-to-peer halo (tetsim_halo.hip): the neighbours store their boundary predictions straight into this rank's ghost range,
+    // peer-to-peer halo (tetsim_p2p.hip, tetsim_halo.hip): the neighbours store their boundary predictions straight into this rank's ghost range,
     // double buffered by substep parity -- pos_pred's own tail on even substeps, ghost_alt on odd ones (pjb_tet_kernel_alt)
     const float4* ghost_alt = nullptr;       // [nv_local - nv_owned]
     // two-layer ghost regions: ghosts [nv_owned, nv_owned + n_ghost1) come from ghost_alt, the second layer from ghost2

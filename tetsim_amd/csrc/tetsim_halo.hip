@@ -1,4 +1,5 @@
-// tetsim_halo.hip -- multi-GPU: the per-substep halo of partitioned POLAR_JACOBI bodies and its C ABI.
+// tetsim_halo.hip -- multi-GPU: the per-substep halo choreography of partitioned POLAR_JACOBI bodies and the stepping of
+// in-process groups.  Communicator set-up and probes: tetsim_comm.hip; peer-to-peer halo (export / connect): tetsim_p2p.hip.
 #include "body.h"
 
 #include <unistd.h>
@@ -439,412 +440,6 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
 }  // namespace tetsim
 
 extern "C" {
-
-// ---- multi-GPU -----------------------------------------------------------------------------------------------
-int tetsim_comm_unique_id(void* id128) {
-    if (!id128) return fail(nullptr, TETSIM_EINVAL, "null id buffer");
-    if (!g_rccl.load()) return fail(nullptr, TETSIM_ECOMM, g_rccl.err);
-    ncclUniqueId id;
-    ncclResult_t r = g_rccl.GetUniqueId(&id);
-    if (r != ncclSuccess) return fail(nullptr, TETSIM_ECOMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
-    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
-    std::memcpy(id128, &id, sizeof(id));
-    return 0;
-}
-
-int tetsim_comm_init(tetsim_handle h, const void* id128, int32_t rank, int32_t nranks) {
-    if (!h || !id128) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "halo exchange exists only for POLAR_JACOBI");
-    // Measurement aid: TETSIM_DEBUG_LOOPBACK_HALO=1 + nranks == 1 on a PARTITIONED body makes every neighbour this rank itself:
-    // the real RCCL send/recv kernels then run in the real choreography on one GPU (ghosts receive this rank's own interface
-    // values, so the physics is meaningless -- timing and liveness only).
-    const char* lb = getenv("TETSIM_DEBUG_LOOPBACK_HALO");
-    if (lb && lb[0] == '1' && nranks == 1 && rank == 0 && h->opt.part_count > 1) {
-        for (auto& nb : h->neigh)
-            if (nb.send_count != nb.recv_count) return fail(h, TETSIM_ESTATE, "loopback halo needs equal send and receive counts per neighbour (use equal slabs)");
-        h->loopback = true;
-        fprintf(stderr, "[tetsim] WARNING: TETSIM_DEBUG_LOOPBACK_HALO: partition %d exchanges halos with ITSELF; results are not physics\n", h->opt.part_index);
-    } else if (nranks != h->opt.part_count || rank != h->opt.part_index) return fail(h, TETSIM_EINVAL, "rank/nranks must equal part_index/part_count");
-    if (!g_rccl.load()) return fail(h, TETSIM_ECOMM, g_rccl.err);
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof(id));
-    ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, id, rank);
-    if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail(h, r, "ncclCommInitRank"); }
-    h->comm_rank = rank;
-    h->comm_size = nranks;
-    { int rc = create_halo_stream(h); if (rc) return rc; }
-    // Connection set-up happens on the first transfer between two ranks and can take seconds; do it here, with the real
-    // message sizes on scratch buffers and a host-side wait, so that the stepping path (whose device-side waits are
-    // bounded, TETSIM_HALO_TIMEOUT_MS) never sees it.  Collective: every rank of the communicator is inside this call.
-    size_t most = 0;
-    for (auto& nb : h->neigh) most = std::max<size_t>(most, std::max(nb.send_count, nb.recv_count));
-    if (most) {
-        float4 *src = nullptr, *dst = nullptr;
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), most * sizeof(float4)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), most * h->neigh.size() * sizeof(float4)));
-        int rc = TETSIM_OK;
-        if (hipMemsetAsync(src, 0, most * sizeof(float4), h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up memset failed");
-        r = rc ? ncclSuccess : g_rccl.GroupStart();
-        size_t k = 0;
-        for (auto& nb : h->neigh) {
-            const int peer = h->loopback ? h->comm_rank : nb.rank;
-            if (!rc && r == ncclSuccess && nb.send_count) r = g_rccl.Send(src, 4ull * nb.send_count, ncclFloat, peer, h->comm, h->comm_stream);
-            if (!rc && r == ncclSuccess && nb.recv_count) r = g_rccl.Recv(dst + most * k, 4ull * nb.recv_count, ncclFloat, peer, h->comm, h->comm_stream);
-            k++;
-        }
-        if (!rc && r == ncclSuccess) r = g_rccl.GroupEnd();
-        if (!rc && r != ncclSuccess) rc = rccl_fail(h, r, "halo warm-up send/recv");
-        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "halo warm-up did not complete");
-        (void)hipFree(src);
-        (void)hipFree(dst);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-int tetsim_comm_info(tetsim_handle h, TetSimCommInfo* out) {
-    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
-    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
-    std::memset(out, 0, sizeof(*out));
-    int n = 0, r = -1;
-    ncclResult_t e = g_rccl.CommCount(h->comm, &n);
-    if (e == ncclSuccess) e = g_rccl.CommUserRank(h->comm, &r);
-    if (e != ncclSuccess) return rccl_fail(h, e, "ncclCommCount / ncclCommUserRank");
-    out->rccl_ranks = n;
-    out->rccl_rank = r;
-    out->neighbours = static_cast<uint32_t>(h->neigh.size());
-    for (const NeighDev& nb : h->neigh) {
-        out->send_bytes_per_substep += 16ull * nb.send_count;
-        out->recv_bytes_per_substep += 16ull * nb.recv_count;
-        out->max_message_bytes = std::max<uint64_t>(out->max_message_bytes, 16ull * std::max(nb.send_count, nb.recv_count));
-    }
-    out->loopback = h->loopback ? 1 : 0;
-    out->p2p = h->p2p ? 1 : 0;
-    return 0;
-}
-
-int tetsim_comm_selftest(tetsim_handle h) {
-    if (!h) return TETSIM_EINVAL;
-    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    constexpr size_t kN = 256;  // floats
-    float *src = nullptr, *dst = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), kN * sizeof(float)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), kN * sizeof(float)));
-    std::vector<float> host(kN), back(kN, 0.0f);
-    for (size_t i = 0; i < kN; i++) host[i] = static_cast<float>(i) * 0.5f + static_cast<float>(h->comm_rank);
-    int rc = TETSIM_OK;
-    if (hipMemcpy(src, host.data(), kN * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(dst, 0, kN * sizeof(float)) != hipSuccess) rc = fail(h, TETSIM_EHIP, "selftest upload failed");
-    if (!rc) {
-        ncclResult_t r = g_rccl.GroupStart();
-        if (r == ncclSuccess) r = g_rccl.Send(src, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
-        if (r == ncclSuccess) r = g_rccl.Recv(dst, kN, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
-        if (r == ncclSuccess) r = g_rccl.GroupEnd();
-        if (r != ncclSuccess) rc = rccl_fail(h, r, "selftest send/recv");
-    }
-    if (!rc && (hipStreamSynchronize(h->comm_stream) != hipSuccess ||
-                hipMemcpy(back.data(), dst, kN * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
-        rc = fail(h, TETSIM_EHIP, "selftest download failed");
-    if (!rc && back != host) rc = fail(h, TETSIM_ECOMM, "selftest: received bytes differ from the bytes sent");
-    (void)hipFree(src);
-    (void)hipFree(dst);
-    return rc;
-}
-
-// Measurement helper (multi-GPU design input): cost of ONE grouped ncclSend+ncclRecv of `bytes` to this rank itself,
-// issued `reps` times back to back -- eagerly (use_graph = 0) or captured `per_graph` at a time into a HIP graph and
-// replayed (use_graph = 1).  host_us = host time spent issuing, per group; total_us = wall time to completion, per group.
-int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph, double* host_us, double* total_us) {
-    if (!h || !host_us || !total_us || reps == 0 || bytes < 4) return fail(h, TETSIM_EINVAL, "bad argument");
-    if (!h->comm) return fail(h, TETSIM_ESTATE, "no communicator (call tetsim_comm_init first)");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    const size_t n = bytes / sizeof(float);
-    float *src = nullptr, *dst = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&src), n * sizeof(float)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&dst), n * sizeof(float)));
-    std::vector<float> host(n), back(n, 0.0f);
-    for (size_t i = 0; i < n; i++) host[i] = static_cast<float>(i % 977) + 0.25f;
-    int rc = TETSIM_OK;
-    if (hipMemcpy(src, host.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, n * sizeof(float)) != hipSuccess)
-        rc = fail(h, TETSIM_EHIP, "probe upload failed");
-    auto group = [&]() -> ncclResult_t {
-        ncclResult_t r = g_rccl.GroupStart();
-        if (r == ncclSuccess) r = g_rccl.Send(src, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
-        if (r == ncclSuccess) r = g_rccl.Recv(dst, n, ncclFloat, h->comm_rank, h->comm, h->comm_stream);
-        if (r == ncclSuccess) r = g_rccl.GroupEnd();
-        return r;
-    };
-    using clk = std::chrono::steady_clock;
-    if (!rc) {  // warm-up (connection setup happens on first use)
-        ncclResult_t r = group();
-        if (r != ncclSuccess) rc = rccl_fail(h, r, "probe warm-up");
-        else if (hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe warm-up sync failed");
-    }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    if (!rc && use_graph) {
-        if (per_graph == 0) per_graph = 1;
-        if (hipStreamBeginCapture(h->comm_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: begin capture failed");
-        for (uint32_t i = 0; !rc && i < per_graph; i++) {
-            ncclResult_t r = group();
-            if (r != ncclSuccess) rc = rccl_fail(h, r, "probe: send/recv under stream capture");
-        }
-        hipError_t e = hipStreamEndCapture(h->comm_stream, &graph);
-        if (!rc && e != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("probe: end capture: ") + hipGetErrorString(e));
-        if (!rc && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph instantiate failed");
-    }
-    if (!rc) {
-        (void)hipMemset(dst, 0, n * sizeof(float));
-        (void)hipDeviceSynchronize();
-        const auto t0 = clk::now();
-        uint32_t done = 0;
-        if (use_graph) {
-            for (; done < reps && !rc; done += per_graph)
-                if (hipGraphLaunch(exec, h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe: graph launch failed");
-        } else {
-            for (; done < reps && !rc; done++) {
-                ncclResult_t r = group();
-                if (r != ncclSuccess) rc = rccl_fail(h, r, "probe send/recv");
-            }
-        }
-        const auto t1 = clk::now();
-        if (!rc && hipStreamSynchronize(h->comm_stream) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe sync failed");
-        const auto t2 = clk::now();
-        if (!rc) {
-            *host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / done;
-            *total_us = std::chrono::duration<double, std::micro>(t2 - t0).count() / done;
-            if (hipMemcpy(back.data(), dst, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, TETSIM_EHIP, "probe download failed");
-            else if (back != host) rc = fail(h, TETSIM_ECOMM, "probe: received bytes differ from the bytes sent");
-        }
-    }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipFree(src);
-    (void)hipFree(dst);
-    return rc;
-}
-
-int tetsim_get_halo_plan(tetsim_handle h, int32_t* neigh, int32_t* send_counts, int32_t* recv_counts, int32_t* send_ids, int32_t* recv_ids) {
-    if (!h) return TETSIM_EINVAL;
-    size_t so = 0, ro = 0;
-    for (size_t i = 0; i < h->neigh.size(); i++) {
-        const NeighDev& nb = h->neigh[i];
-        if (neigh) neigh[i] = nb.rank;
-        if (send_counts) send_counts[i] = static_cast<int32_t>(nb.send_count);
-        if (recv_counts) recv_counts[i] = static_cast<int32_t>(nb.recv_count);
-        if (send_ids) std::copy(nb.send_global.begin(), nb.send_global.end(), send_ids + so);
-        if (recv_ids) std::copy(nb.recv_global.begin(), nb.recv_global.end(), recv_ids + ro);
-        so += nb.send_global.size();
-        ro += nb.recv_global.size();
-    }
-    return 0;
-}
-
-int tetsim_halo_export(tetsim_handle h, uint32_t n, float* out_xyzw) {
-    if (!h || !out_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    NeighDev& nb = h->neigh[n];
-    if (!nb.send_count) return 0;
-    util_launch_gather4(h->stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out_xyzw, nb.send_buf, nb.send_count * sizeof(float4), hipMemcpyDeviceToHost));
-    return 0;
-}
-int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
-    if (!h || !in_xyzw || n >= h->neigh.size()) return fail(h, TETSIM_EINVAL, "bad neighbour slot");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    NeighDev& nb = h->neigh[n];
-    if (!nb.recv_count) return 0;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(h->pj.pos_pred + nb.recv_start, in_xyzw, nb.recv_count * sizeof(float4), hipMemcpyHostToDevice));
-    return 0;
-}
-
-// ---- peer-to-peer halo ---------------------------------------------------------------------------------------------------
-namespace {
-struct P2PBlob {   // what a rank tells the others about its buffers (TETSIM_P2P_BLOB_BYTES)
-    uint32_t magic, rank, part_count, device;
-    uint64_t pid;
-    uint32_t nv_owned, nv_local, n_neigh, n_ghost1;             // n_ghost1: 0xffffffff = one ghost layer
-    hipIpcMemHandle_t h_pred, h_alt, h_arrived;                 // IPC handles of pos_pred / ghost_alt / the "arrived" words
-    uint64_t p_pred, p_alt, p_arrived;                          // ... and the plain pointers (ranks of the same process)
-    struct { int32_t rank; uint32_t recv_start, recv_count, recv2_start, recv2_count; } neigh[kMaxPeers];
-};
-constexpr uint32_t kArrivedWords = 4 * kMaxPeers;               // [set][parity][neighbour]; one-layer bodies use the first 2 * kMaxPeers as [parity][neighbour]
-static_assert(sizeof(P2PBlob) <= TETSIM_P2P_BLOB_BYTES, "blob too large");
-constexpr uint32_t kP2PMagic = 0x50325054u;
-}  // namespace
-
-int tetsim_halo_p2p_export(tetsim_handle h, void* blob) {
-    if (!h || !blob) return fail(h, TETSIM_EINVAL, "null argument");
-    if (!h->partitioned || !h->blocked || h->blk.nb == h->blk.nb_interior)
-        return fail(h, TETSIM_ESTATE, "the peer-to-peer halo needs a partitioned POLAR_JACOBI body in the blocked FAST formulation with halo-side tiles");
-    if (h->neigh.size() > kMaxPeers) return fail(h, TETSIM_ESTATE, "the peer-to-peer halo supports at most 8 neighbours per partition");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
-    const uint32_t ng1 = h->deep ? h->n_ghost1 : ng, ng2 = ng - ng1;
-    if (!h->ghost_alt) {
-        int rc;
-        // one ghost layer: the second (odd-substep) ghost buffer.  Two layers: the eight receive buffers in one allocation,
-        // [g1_even x2 | g1_final x2 | g2_even x2 | g2_odd x2]
-        if ((rc = dev_alloc(h, &h->ghost_alt, h->deep ? 4ull * ng1 + 4ull * ng2 : ng))) return rc;
-        if (h->deep)
-            for (uint32_t st = 0; st < 2; st++) {
-                h->own_g1_even[st] = h->ghost_alt + static_cast<size_t>(st) * ng1;
-                h->own_g1_final[st] = h->ghost_alt + (2ull + st) * ng1;
-                h->own_g2_even[st] = h->ghost_alt + 4ull * ng1 + static_cast<size_t>(st) * ng2;
-                h->own_g2_odd[st] = h->ghost_alt + 4ull * ng1 + (2ull + st) * ng2;
-            }
-        if ((rc = dev_alloc(h, &h->d_arrived, kArrivedWords))) return rc;
-        HIPCHK(h, hipMemset(h->d_arrived, 0, kArrivedWords * sizeof(uint32_t)));
-        // where each boundary particle goes: (neighbour, position in that neighbour's ghost run for this rank), ELL by particle
-        const uint32_t nvb = h->pj.nv_boundary;
-        std::vector<std::vector<uint32_t>> per(nvb);
-        for (size_t k = 0; k < h->neigh.size(); k++)
-            for (size_t j = 0; j < h->neigh[k].send_local.size(); j++) {
-                const uint32_t api = static_cast<uint32_t>(h->neigh[k].send_local[j]);
-                const uint32_t dv = h->api2dev.empty() ? api : h->api2dev[api];
-                if (dv >= nvb) return fail(h, TETSIM_ESTATE, "internal error: a sent particle is not a boundary particle");
-                per[dv].push_back((static_cast<uint32_t>(k) << 24) | static_cast<uint32_t>(j));
-            }
-        uint32_t cols = 1;
-        for (auto& v : per) cols = std::max<uint32_t>(cols, static_cast<uint32_t>(v.size()));
-        h->p2p_cols = cols; h->p2p_stride = std::max(nvb, 1u);
-        std::vector<uint32_t> ell(static_cast<size_t>(cols) * h->p2p_stride, 0xffffffffu);
-        for (uint32_t v = 0; v < nvb; v++) for (size_t c = 0; c < per[v].size(); c++) ell[c * h->p2p_stride + v] = per[v][c];
-        if ((rc = dev_alloc(h, &h->d_peer_slots, ell.size()))) return rc;
-        if ((rc = upload(h, h->d_peer_slots, ell))) return rc;
-        if (h->deep) {   // the same table for the neighbours' SECOND layer
-            std::vector<std::vector<uint32_t>> per2(nvb);
-            for (size_t k = 0; k < h->part.neigh.size(); k++)
-                for (size_t j = 0; j < h->part.neigh[k].send2_local.size(); j++) {
-                    const uint32_t api = static_cast<uint32_t>(h->part.neigh[k].send2_local[j]);
-                    const uint32_t dv = h->api2dev.empty() ? api : h->api2dev[api];
-                    if (dv >= nvb) return fail(h, TETSIM_ESTATE, "internal error: a sent particle is not a boundary particle");
-                    per2[dv].push_back((static_cast<uint32_t>(k) << 24) | static_cast<uint32_t>(j));
-                }
-            uint32_t cols2 = 1;
-            for (auto& v : per2) cols2 = std::max<uint32_t>(cols2, static_cast<uint32_t>(v.size()));
-            h->p2p_cols2 = cols2;
-            std::vector<uint32_t> ell2(static_cast<size_t>(cols2) * h->p2p_stride, 0xffffffffu);
-            for (uint32_t v = 0; v < nvb; v++) for (size_t c = 0; c < per2[v].size(); c++) ell2[c * h->p2p_stride + v] = per2[v][c];
-            if ((rc = dev_alloc(h, &h->d_peer_slots2, ell2.size()))) return rc;
-            if ((rc = upload(h, h->d_peer_slots2, ell2))) return rc;
-        }
-    }
-    P2PBlob b;
-    std::memset(&b, 0, sizeof b);
-    b.magic = kP2PMagic; b.rank = static_cast<uint32_t>(h->opt.part_index); b.part_count = static_cast<uint32_t>(h->opt.part_count);
-    b.device = static_cast<uint32_t>(h->opt.device); b.pid = static_cast<uint64_t>(getpid());
-    b.nv_owned = nvo; b.nv_local = h->pj.nv_local; b.n_neigh = static_cast<uint32_t>(h->neigh.size());
-    b.n_ghost1 = h->deep ? ng1 : 0xffffffffu;
-    b.p_pred = reinterpret_cast<uint64_t>(h->pj.pos_pred); b.p_alt = reinterpret_cast<uint64_t>(h->ghost_alt); b.p_arrived = reinterpret_cast<uint64_t>(h->d_arrived);
-    // (a handle can only be opened by ANOTHER process; failing to make one is not an error for ranks of one process)
-    (void)hipIpcGetMemHandle(&b.h_pred, h->pj.pos_pred);
-    (void)hipIpcGetMemHandle(&b.h_alt, h->ghost_alt);
-    (void)hipIpcGetMemHandle(&b.h_arrived, h->d_arrived);
-    (void)hipGetLastError();
-    for (size_t k = 0; k < h->neigh.size(); k++) {
-        b.neigh[k].rank = h->neigh[k].rank; b.neigh[k].recv_start = h->neigh[k].recv_start; b.neigh[k].recv_count = h->neigh[k].recv_count;
-        if (h->deep) { b.neigh[k].recv2_start = h->part.neigh[k].recv2_start; b.neigh[k].recv2_count = h->part.neigh[k].recv2_count; }
-    }
-    std::memset(blob, 0, TETSIM_P2P_BLOB_BYTES);
-    std::memcpy(blob, &b, sizeof b);
-    return 0;
-}
-
-int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) {
-    if (!h || !blobs) return fail(h, TETSIM_EINVAL, "null argument");
-    if (!h->ghost_alt) return fail(h, TETSIM_ESTATE, "call tetsim_halo_p2p_export first");
-    // Transports it can follow: RCCL (connect after tetsim_comm_init; RCCL keeps carrying the refresh after a dt change), an
-    // in-process group (after its first tetsim_group_step_n), or none at all -- ranks in different processes that exchange the
-    // blobs themselves; such a body cannot change dt between calls (nothing would refresh the ghosts).
-    {
-        const char* sy = getenv("TETSIM_HALO_SYNC");
-        const char* os = getenv("TETSIM_DEBUG_ONE_STREAM");
-        if ((sy && sy[0] == 'e') || (os && os[0] == '1')) return fail(h, TETSIM_ESTATE, "the peer-to-peer halo rides on the two-queue flag path (TETSIM_HALO_SYNC=events / TETSIM_DEBUG_ONE_STREAM exclude it)");
-    }
-    if (!h->comm_stream) { int rc = create_halo_stream(h); if (rc) return rc; }
-    h->timeout_ms = 0;
-    h->timeout_ms = halo_timeout_ms(h);
-    if (!(h->loopback && count == 1) && count != static_cast<uint32_t>(h->opt.part_count)) return fail(h, TETSIM_EINVAL, "one blob per partition, in rank order");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-    const uint32_t nvo = h->pj.nv_owned, ng = h->pj.nv_local - nvo;
-    const uint32_t ng1 = h->deep ? h->n_ghost1 : ng, ng2 = ng - ng1;
-    if (h->deep) {
-        // the first substep after the connection is an EVEN one of exchange set 0: its ghosts are the ghosts as they are now
-        if (ng1) HIPCHK(h, hipMemcpy(h->own_g1_even[0], h->pj.pos_pred + nvo, ng1 * sizeof(float4), hipMemcpyDeviceToDevice));
-        if (ng1) HIPCHK(h, hipMemcpy(h->own_g1_final[0], h->pj.pos_final + nvo, ng1 * sizeof(float4), hipMemcpyDeviceToDevice));
-        if (ng2) HIPCHK(h, hipMemcpy(h->own_g2_even[0], h->pj.pos_pred + nvo + ng1, ng2 * sizeof(float4), hipMemcpyDeviceToDevice));
-    } else if (ng) {
-        // both ghost buffers start from the ghosts as they are now (the last exchange of the previous transport, or the rest pose)
-        HIPCHK(h, hipMemcpy(h->ghost_alt, h->pj.pos_pred + nvo, ng * sizeof(float4), hipMemcpyDeviceToDevice));
-    }
-    HIPCHK(h, hipMemset(h->d_arrived, 0, kArrivedWords * sizeof(uint32_t)));
-    const char* all = static_cast<const char*>(blobs);
-    std::vector<PeerLink> links(h->neigh.size());
-    for (size_t k = 0; k < h->neigh.size(); k++) {
-        const NeighDev& nb = h->neigh[k];
-        P2PBlob pb;
-        std::memcpy(&pb, all + static_cast<size_t>(h->loopback ? 0 : nb.rank) * TETSIM_P2P_BLOB_BYTES, sizeof pb);
-        if (pb.magic != kP2PMagic || (!h->loopback && static_cast<int>(pb.rank) != nb.rank)) return fail(h, TETSIM_EINVAL, "bad peer blob for rank " + std::to_string(nb.rank));
-        const uint32_t send2 = h->deep ? static_cast<uint32_t>(h->part.neigh[k].send2_local.size()) : 0u;
-        if (!nb.send_count && !send2) continue;
-        if ((pb.n_ghost1 != 0xffffffffu) != h->deep) return fail(h, TETSIM_ESTATE, "ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank) + " disagree on the depth of the ghost region");
-        // this rank's run in the neighbour's ghost range, and this rank's slot among the neighbour's neighbours
-        uint32_t start = 0, cnt = 0, start2 = 0, cnt2 = 0, slot = kMaxPeers;
-        if (h->loopback) {
-            start = nb.recv_start; cnt = nb.recv_count; slot = static_cast<uint32_t>(k);
-            if (h->deep) { start2 = h->part.neigh[k].recv2_start; cnt2 = h->part.neigh[k].recv2_count; }
-        } else
-            for (uint32_t j = 0; j < pb.n_neigh && j < kMaxPeers; j++)
-                if (pb.neigh[j].rank == h->opt.part_index) { start = pb.neigh[j].recv_start; cnt = pb.neigh[j].recv_count; start2 = pb.neigh[j].recv2_start; cnt2 = pb.neigh[j].recv2_count; slot = j; }
-        if (slot == kMaxPeers || cnt != nb.send_count || cnt2 != send2) return fail(h, TETSIM_ESTATE, "asymmetric halo plan between ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank));
-        float4 *pred = nullptr, *alt = nullptr;
-        uint32_t* arr = nullptr;
-        if (pb.pid == static_cast<uint64_t>(getpid())) {   // same process: plain pointers (peer access if the devices differ)
-            pred = reinterpret_cast<float4*>(pb.p_pred); alt = reinterpret_cast<float4*>(pb.p_alt); arr = reinterpret_cast<uint32_t*>(pb.p_arrived);
-            if (static_cast<int>(pb.device) != h->opt.device) {
-                const hipError_t e = hipDeviceEnablePeerAccess(static_cast<int>(pb.device), 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(h, TETSIM_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-                (void)hipGetLastError();
-            }
-        } else {
-            PeerLink& l = links[k];
-            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[0], pb.h_pred, hipIpcMemLazyEnablePeerAccess));
-            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[1], pb.h_alt, hipIpcMemLazyEnablePeerAccess));
-            HIPCHK(h, hipIpcOpenMemHandle(&l.ipc[2], pb.h_arrived, hipIpcMemLazyEnablePeerAccess));
-            pred = static_cast<float4*>(l.ipc[0]); alt = static_cast<float4*>(l.ipc[1]); arr = static_cast<uint32_t*>(l.ipc[2]);
-        }
-        if (h->deep) {
-            const size_t pg1 = pb.n_ghost1, pg2 = pb.nv_local - pb.nv_owned - pb.n_ghost1;
-            const size_t r1 = start - pb.nv_owned, r2 = start2 - pb.nv_owned - pb.n_ghost1;   // this rank's runs in the neighbour's layers
-            for (uint32_t st = 0; st < 2; st++) {
-                links[k].g1_even[st] = alt + st * pg1 + r1;
-                links[k].g1_final[st] = alt + (2 + st) * pg1 + r1;
-                links[k].g2_even[st] = alt + 4 * pg1 + st * pg2 + r2;
-                links[k].g2_odd[st] = alt + 4 * pg1 + (2 + st) * pg2 + r2;
-                for (uint32_t par = 0; par < 2; par++) links[k].arrived2[st][par] = arr + (st * 2 + par) * kMaxPeers + slot;
-            }
-            continue;
-        }
-        links[k].ghost[0] = pred + start;                       // even substeps read pos_pred's tail
-        links[k].ghost[1] = alt + (start - pb.nv_owned);        // odd ones the second buffer
-        links[k].arrived[0] = arr + slot;
-        links[k].arrived[1] = arr + kMaxPeers + slot;
-    }
-    h->links = std::move(links);
-    h->p2p = true;
-    h->p2p_round = 0;
-    h->p2p_raise_pending = false;
-    h->halo_warm = false;     // the first call after the connection runs eagerly (its first substep has no "arrived" to wait for)
-    drop_flag_graphs(h);
-    return 0;
-}
 
 int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
     if (!hs || count == 0) return TETSIM_EINVAL;
