@@ -106,12 +106,15 @@ def explore(calls, mutate=None, program=None):
         for q in range(4):
             if pcs[q] == len(queues[q]):
                 continue
-            name, reads, writes, raises, waits, xfer, join = queues[q][pcs[q]]
+            name, reads, writes, raises, waits, xfer, join = queues[q][pcs[q]][:7]
+            extra = queues[q][pcs[q]][7] if len(queues[q][pcs[q]]) > 7 else {}
             r = q // 2
             if not running[q]:
                 # ---- START
                 if waits is not None and not words[r][wi[waits]]:
                     continue                                   # the wait kernel spins: model it as "cannot complete yet"
+                if extra.get("await") and not words[r][wi[extra["await"]]]:
+                    continue                                   # a kernel whose waves look at the word themselves: no wave gets past its first instruction
                 if join is not None and pcs[r * 2 + 1] < join:
                     continue                                   # behind an event recorded on the halo queue
                 if xfer is not None:
@@ -126,7 +129,8 @@ def explore(calls, mutate=None, program=None):
         if not moves:
             raise Violation("deadlock at %s" % [queues[q][pcs[q]][0] if pcs[q] < len(queues[q]) else "-" for q in range(4)])
         for kind, q in moves:
-            name, reads, writes, raises, waits, xfer, join = queues[q][pcs[q]]
+            name, reads, writes, raises, waits, xfer, join = queues[q][pcs[q]][:7]
+            extra = queues[q][pcs[q]][7] if len(queues[q][pcs[q]]) > 7 else {}
             r = q // 2
             npcs, nrun, nwords, nver = list(pcs), list(running), [list(w) for w in words], [list(v) for v in versions]
             if kind == "start":
@@ -149,6 +153,10 @@ def explore(calls, mutate=None, program=None):
                         nwords[r][wi[waits]] = 0               # consumed (wait kernels are modelled as atomic)
                         npcs[q] += 1
                     else:
+                        if extra.get("clear"):                 # put back a word whose waiters were the waves of the kernel in front
+                            if not nwords[r][wi[extra["clear"]]]:
+                                raise Violation("%s clears %s, which is not raised" % (name, extra["clear"]))
+                            nwords[r][wi[extra["clear"]]] = 0
                         for word in ((raises,) if isinstance(raises, str) else (raises or ())):
                             wr, wn = where(r, word)
                             if nwords[wr][wi[wn]]:
@@ -226,10 +234,13 @@ def test_the_model_notices_a_broken_choreography(what, mutate):
 # ---- peer-to-peer halo (tetsim_halo_p2p_connect): no transfer; the boundary-particle kernel stores into the PEER's ghost buffer of the
 # next substep's parity, the wait kernel in front of the halo-side tiles raises the peer's "arrived" word of that parity as it starts and
 # waits for its own ------------------------------------------------------------------------------------------------------------------
-def rank_program_p2p(calls, raise_in_own_kernel=False):
+def rank_program_p2p(calls, raise_in_own_kernel=False, fold=False):
     """As rank_program, for a connected body.  Substep s reads ghost buffer s & 1; P_b(s) also writes the peer's buffer (s + 1) & 1; the
     words A0 / A1 ("arrived", by parity) live at the receiver.  raise_in_own_kernel: partitions of one process give the raise a kernel of
-    its own right behind P_b (tetsim_group_step_n), one rank per process folds it into the next wait kernel / the flush."""
+    its own right behind P_b (tetsim_group_step_n), one rank per process folds it into the next wait kernel / the flush.
+    fold (tetsim_halo.hip: interior_particles, the default of a connected body): no `wait G` kernel -- the interior particle kernel's
+    waves look at G themselves (an 8th element {"await": word}) and nobody consumes it there; the main queue's NEXT operation -- the
+    interior tiles of the next substep, or the flush's signal -- puts it back as it starts ({"clear": word}), in front of its raise."""
     main, halo = [], []
     s = 0
     gb = lambda k: PRED_G1 if k & 1 else PRED_G
@@ -243,7 +254,7 @@ def rank_program_p2p(calls, raise_in_own_kernel=False):
             halo.append(("X(refresh %d)" % call, {PRED_B: s}, {}, None, None, ("refresh", call, s, gb(s)), None))   # RCCL / copies, into the current parity's buffer
         v_pending = False
         for _ in range(n):
-            main.append(("T_int(%d)" % s, {PRED_I: s}, {PART_I: s + 1}, "V" if v_pending else None, None, None, None))
+            main.append(("T_int(%d)" % s, {PRED_I: s}, {PART_I: s + 1}, "V" if v_pending else None, None, None, None) + (({"clear": "G"},) if fold and v_pending else ()))
             # the wait kernel: raises (as it starts), then V, then the peer's "arrived" of this parity
             if pending:
                 halo.append(("raise A%d" % (s & 1), {}, {}, PEER + "A%d" % (s & 1), None, None, None))
@@ -258,11 +269,14 @@ def rank_program_p2p(calls, raise_in_own_kernel=False):
             if raise_in_own_kernel:
                 halo.append(("raise A%d" % ((s + 1) & 1), {}, {}, PEER + "A%d" % ((s + 1) & 1), None, None, None))
                 pending = False
-            main.append(("wait G(%d)" % s, {}, {}, None, "G", None, None))
-            main.append(("P_i(%d)" % s, {PART_H: s + 1, PART_I: s + 1}, {PRED_I: s + 1}, None, None, None, None))
+            if fold:
+                main.append(("P_i(%d)" % s, {PART_H: s + 1, PART_I: s + 1}, {PRED_I: s + 1}, None, None, None, None, {"await": "G"}))
+            else:
+                main.append(("wait G(%d)" % s, {}, {}, None, "G", None, None))
+                main.append(("P_i(%d)" % s, {PART_H: s + 1, PART_I: s + 1}, {PRED_I: s + 1}, None, None, None, None))
             v_pending = True
             s += 1
-        main.append(("signal V(%d)" % (s - 1), {}, {}, "V", None, None, None))
+        main.append(("signal V(%d)" % (s - 1), {}, {}, "V", None, None, None) + (({"clear": "G"},) if fold else ()))
         if pending:
             halo.append(("raise A%d" % (s & 1), {}, {}, PEER + "A%d" % (s & 1), None, None, None))
             pending = False
@@ -282,9 +296,12 @@ def _final_arrived_is_expected(fn):
 
 P2P = _final_arrived_is_expected(rank_program_p2p)
 P2P_GROUP = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, raise_in_own_kernel=True))
+P2P_FOLD = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, fold=True))
+P2P_GROUP_FOLD = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, raise_in_own_kernel=True, fold=True))
 
 
-@pytest.mark.parametrize("program", [P2P, P2P_GROUP], ids=["one rank per process", "ranks of one process"])
+@pytest.mark.parametrize("program", [P2P, P2P_GROUP, P2P_FOLD, P2P_GROUP_FOLD],
+                         ids=["one rank per process", "ranks of one process", "one rank per process, G awaited by the particle kernel", "ranks of one process, G awaited by the particle kernel"])
 @pytest.mark.parametrize("calls", [[1], [2], [3], [1, 1], [2, 1, 2], [4], [2, -2], [1, -1, -3, 2], [3, 3]])
 def test_peer_to_peer_halo_every_interleaving_is_live_and_race_free(calls, program):
     assert explore(calls, program=program) > 10 * sum(abs(n) for n in calls)
@@ -306,6 +323,18 @@ def test_the_model_notices_a_broken_peer_to_peer_choreography(what, mutate):
     with pytest.raises(Violation):
         for calls in ([2], [3], [2, 2], [3, 3]):
             explore(calls, mutate, program=P2P)
+
+
+@pytest.mark.parametrize("what,mutate", [
+    # nobody puts G back: the next substep's particle kernel finds it still raised and adds up halo-side partial sums of the substep before
+    ("G never put back", _edit(lambda op: op[:7] + ({k: v for k, v in op[7].items() if k != "clear"},) if len(op) > 7 else op)),
+    # the particle kernel's waves do not look at G: they add up halo-side partial sums that may not exist yet
+    ("particle kernel does not await G", _edit(lambda op: op[:7] + ({k: v for k, v in op[7].items() if k != "await"},) if len(op) > 7 else op)),
+])
+def test_the_model_notices_a_broken_folded_wait(what, mutate):
+    with pytest.raises(Violation):
+        for calls in ([2], [3], [2, 2]):
+            explore(calls, mutate, program=P2P_FOLD)
 
 
 # ---- two-layer ghost region on the peer-to-peer halo (TETSIM_FLAG_DEEP_GHOSTS): ghosts cross every other substep ---------------------

@@ -54,19 +54,30 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
+    bool loaded = false, process_wide = false;
     bool load() {
-        if (lib) return true;
+        if (loaded) return true;
         // TETSIM_RCCL_LIB: explicit library path (deployments with several RCCL builds; the test double of tests/mock_rccl)
         if (const char* over = getenv("TETSIM_RCCL_LIB")) {
             lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
             if (!lib) { err = std::string("cannot load TETSIM_RCCL_LIB=") + over + ": " + dlerror(); return false; }
         }
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // An RCCL that is ALREADY in the process (PyTorch brings its own) is the one to use: a second copy next to it is two sets of
+        // the same symbols, and whichever of the two is loaded later binds some of its own calls to the other (seen on ROCm 7.2
+        // boxes, where "librccl.so.1" resolves to /opt/rocm's build and PyTorch's bundled one has another name: `double free or
+        // corruption` when the process exits).  So: by name without loading, then whatever the process exports, and only then a
+        // fresh copy -- with LOCAL scope and DEEPBIND, so that neither copy ever resolves into the other.
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
             if (lib) break;
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         }
-        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
-        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        if (!lib && dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclSend")) process_wide = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (lib || process_wide) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        }
+        if (!lib && !process_wide) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(process_wide ? RTLD_DEFAULT : lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
@@ -77,7 +88,8 @@ struct Rccl {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        return GetUniqueId && CommInitRank && CommDestroy && CommCount && CommUserRank && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+        loaded = GetUniqueId && CommInitRank && CommDestroy && CommCount && CommUserRank && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+        return loaded;
     }
 };
 extern Rccl g_rccl;
@@ -174,6 +186,8 @@ struct tetsim_body {
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
+    bool fold_possible = false;       // ... this body could (interior tiles and interior particles exist, not switched off)
+    bool fold_wait = false;           // flag path: the interior particle kernel awaits G itself (TETSIM_HALO_FOLD_WAIT=0 at creation: a wait kernel in front of it)
     bool v_pending = false;           // flag path: the interior particles of the last enqueued substep are not signalled yet (flush_v)
     uint32_t fuse_step = 0;           // substep index inside the current run (enqueue_substep)
     bool fin_in_b = false;            // the latest end-of-substep positions are in pos_final_b (only between the kernels of one call)

@@ -136,8 +136,9 @@ void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const ui
 void nh_launch_post_predict_list_fast(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel
 // in its queue is done" -- a signal kernel folded into its successor
+// clear_word != nullptr: ... and puts that word back to 0 first (a word whose waiters were the waves of the kernel in front: pjb_launch_vertex_await)
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0 = nullptr,
-                    hipEvent_t e1 = nullptr, uint32_t* raise_word = nullptr);
+                    hipEvent_t e1 = nullptr, uint32_t* raise_word = nullptr, uint32_t* clear_word = nullptr);
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
@@ -189,7 +190,9 @@ void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await + c
 void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w);   // y.flag may be null (nothing local to wait for)
 void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word);
 void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count);   // ghosts from d.ghost_alt
-void pjb_launch_signal(hipStream_t s, const PJSync& y);   // one wave: set
+void pjb_launch_signal(hipStream_t s, const PJSync& y, uint32_t* clear_word = nullptr);   // one wave: [clear another word,] set
+// the particle kernel whose every wave awaits y.flag itself, without clearing it (the queue's next kernel does: clear_word above)
+void pjb_launch_vertex_await(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJSync& y, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_predict_fast(hipStream_t s, const NHDev& d);

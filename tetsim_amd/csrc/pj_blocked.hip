@@ -301,14 +301,22 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d
 __device__ __forceinline__ void raise(uint32_t* sig) {
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... and, in front of the raise, putting back a word whose waiters were the waves of the kernel in front of this one in its queue (the
+// interior particle kernel that waits for G itself, pjb_vertex_kernel_await: all of its waves are through when this kernel starts)
+__device__ __forceinline__ void clear_then_raise(uint32_t* clear, uint32_t* sig) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (clear) __hip_atomic_store(clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sig) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                              uint32_t tiles_per_xcd, uint32_t* sig TETSIM_DBG_PARAM) {
-    raise(sig);
+                                                              uint32_t tiles_per_xcd, uint32_t* sig, uint32_t* clear TETSIM_DBG_PARAM) {
+    clear_then_raise(clear, sig);
     pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                                            uint32_t tiles_per_xcd, uint32_t* sig TETSIM_DBG_PARAM) {
-    raise(sig);
+                                                                            uint32_t tiles_per_xcd, uint32_t* sig, uint32_t* clear TETSIM_DBG_PARAM) {
+    clear_then_raise(clear, sig);
     pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 // ... reading the ghosts from the second buffer (peer-to-peer halo; halo-side tiles of odd substeps)
@@ -577,7 +585,9 @@ __device__ __forceinline__ void await_done(const PJSync& y) {
 
 // 64-thread workgroups: 175,616 particles are only 2,744 waves (2.7 per SIMD); one-wave workgroups spread over the
 // 256 CUs evenly (10.7 per CU) where 256-thread ones leave some CUs with 3 and others with 2.
-template <bool kPeer = false>
+// kCoherent: the partial sums are read from the memory side (dev_store.h: load_coherent) -- for the kernel that starts BEFORE the
+// halo-side tiles of its substep are known to be done (pjb_vertex_kernel_await): a line this XCD's L2 cached earlier must not be served
+template <bool kPeer = false, bool kCoherent = false>
 __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, uint32_t count, const PJPeer* peer = nullptr) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= count) return;
@@ -595,7 +605,10 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t j = 0; j < 8u; j++) {
+            if constexpr (kCoherent) { const float4 t = load_coherent(d.partial, idx[j] != 0xffffffffu ? idx[j] : 0u); g[j] = idx[j] != 0xffffffffu ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            else g[j] = idx[j] != 0xffffffffu ? d.partial[idx[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
         if (__all(idx[7] == 0xffffffffu)) break;  // lists are front-packed: nobody in this wave has a ninth partial
@@ -634,6 +647,24 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t 
     raise(sig);
     pjb_vertex_body(d, first, count);
 }
+// ... waiting for a hand-over word ITSELF: every wave looks at the word before it touches a partial sum (one lane, agent-scope loads,
+// bounded like the wait kernels) and nobody puts it back -- the next kernel of this queue does, as it starts (clear_then_raise).  The
+// one-wave wait kernel this replaces cost the main queue a third launch boundary per substep.
+__global__ __launch_bounds__(64) void pjb_vertex_kernel_await(PJBlk d, uint32_t first, uint32_t count, uint32_t* flag, uint32_t* error, uint32_t timeout_ms) {
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64(), limit = 100000ll * timeout_ms;   // 100 MHz ticks
+        // (RELAXED: an acquire load is a load plus a cache invalidation, and thousands of waves invalidating their XCD's L2 on every
+        // look took the substep from 37 to 53-150 us)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(16);
+            if (limit && wall_clock64() - t0 > limit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (no cache invalidation here either -- 2,744 waves invalidating their XCD's L2 took the substep from 37 to 71 us: the partial sums, the
+    // only input another queue's kernel may still have been writing when this kernel started, are read past the caches instead)
+    pjb_vertex_body<false, true>(d, first, count);
+}
 __global__ __launch_bounds__(64) void pjb_vertex_kernel_peer(PJBlk d, uint32_t first, uint32_t count, PJPeer peer, uint32_t* sig) {
     if (sig) raise(sig);
     pjb_vertex_body<true>(d, first, count, &peer);
@@ -667,7 +698,12 @@ __global__ void pjb_wait_kernel(uint32_t* flag, uint32_t* error, uint32_t timeou
     y.flag = flag; y.error = error; y.timeout_ms = timeout_ms;
     await_done(y);
 }
-__global__ void pjb_signal_kernel(uint32_t* flag) { if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void pjb_signal_kernel(uint32_t* flag, uint32_t* clear) {
+    if (threadIdx.x == 0) {
+        if (clear) __hip_atomic_store(clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -697,13 +733,14 @@ static uint32_t tet_mode() {
 #else
 #define TETSIM_DBG_LAUNCH
 #endif
-void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
-    if (tile_count == 0) return;   // (callers with a word to raise check this themselves)
+void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word,
+                    uint32_t* clear_word) {
+    if (tile_count == 0) return;   // (callers with a word to raise or clear check this themselves)
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    if (raise_word) {
+    if (raise_word || clear_word) {
         auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_raise : pjb_tet_kernel_raise;
-        if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, raise_word TETSIM_DBG_LAUNCH);
-        else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, raise_word TETSIM_DBG_LAUNCH);
+        if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, raise_word, clear_word TETSIM_DBG_LAUNCH);
+        else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, raise_word, clear_word TETSIM_DBG_LAUNCH);
         return;
     }
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
@@ -761,7 +798,12 @@ void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint
     hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y.flag, y.error, y.timeout_ms); }
-void pjb_launch_signal(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y.flag); }
+void pjb_launch_signal(hipStream_t s, const PJSync& y, uint32_t* clear_word) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y.flag, clear_word); }
+void pjb_launch_vertex_await(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJSync& y, hipEvent_t e0, hipEvent_t e1) {
+    if (count == 0) return;
+    if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel_await, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count, y.flag, y.error, y.timeout_ms);
+    else hipLaunchKernelGGL(pjb_vertex_kernel_await, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, y.flag, y.error, y.timeout_ms);
+}
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
     if (count == 0) return;
     if (raise_word) {

@@ -166,6 +166,14 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         PJBlk& k = h->blk;
         h->interior_tets = B.blk_tet_off[B.num_interior_blocks];
         k.nb = B.num_blocks; k.nb_interior = B.num_interior_blocks; k.nt = ntl; k.nv_local = nvl; k.nv_owned = nvo; k.nv_boundary = nvb;
+        {   // (tetsim_halo.hip: interior_particles) needs interior tiles to put G back and interior particles to look at it
+            // Used with the peer-to-peer halo (switched on when it is connected: 38.2 against 39.5 us per substep in loopback, 42.1
+            // against 42.9 with 20 us of injected latency); with RCCL's transfer kernel on the halo queue it gains 0.7 us at +0 and
+            // loses 1.7 us at +20 us, so there it stays off.  TETSIM_HALO_FOLD_WAIT=0 / 1: never / also with RCCL (development A/B).
+            const char* fw = getenv("TETSIM_HALO_FOLD_WAIT");
+            h->fold_possible = !(fw && fw[0] == '0') && h->partitioned && B.num_interior_blocks > 0 && B.num_interior_blocks < B.num_blocks && nvo > nvb;
+            h->fold_wait = h->fold_possible && fw && fw[0] == '1';
+        }
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
         uint32_t *bto, *bvo, *lcr, *vpe;

@@ -131,6 +131,21 @@ bool uses_flag_sync(const tetsim_body* h) {
 //
 // In-process groups must issue every partition's particle pass before anyone's sends (a send waits for the RECEIVER's
 // boundary event of the same substep), so a substep is enqueued in two phases; RCCL bodies run both back to back.
+// The main queue's second half of a substep: wait for G ("the halo-side tiles of this substep are done": the interior particles add
+// up their partial sums too), then the interior particles.  Folded (h->fold_wait): the particle kernel's waves look at G themselves and
+// the queue's NEXT kernel puts the word back as it starts (the interior tiles of the next substep, or flush_v's signal) -- two kernels per
+// substep on this queue, like a monolithic body, instead of three.
+static void interior_particles(tetsim_body* h, const PJSync& yg, hipEvent_t* ev) {
+    const uint32_t nvb = h->pj.nv_boundary, cnt = h->pj.nv_owned - nvb;
+    if (h->fold_wait) {
+        HP("launch vertex interior (awaits G)");
+        pjb_launch_vertex_await(h->stream, h->blk, nvb, cnt, yg, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+        return;
+    }
+    { HP("wait G"); pjb_launch_wait(h->stream, yg); }
+    { HP("launch vertex interior"); pj_vertex(h, nvb, cnt, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+}
+
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
     if (h->deep && !h->p2p) return fail(h, TETSIM_ESTATE, "a body with a two-layer ghost region steps through the peer-to-peer halo only: call tetsim_halo_p2p_export / _connect first");
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));  // in-process groups may span devices: streams, events and lazy allocations below are per device
@@ -167,8 +182,10 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             const bool v_open = h->v_pending;   // the previous substep's "interior particles done": raised here, consumed below
             if (v_open && h->blk.nb_interior) h->v_pending = false;
             else if ((rc = flush_v(h))) return rc;
+            // (fold_wait: whoever raises V also puts G back -- the waves that looked at it belong to the kernel in front of this one)
             { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr,
-                                                       v_open && h->blk.nb_interior ? yv.flag : nullptr); }
+                                                       v_open && h->blk.nb_interior ? yv.flag : nullptr,
+                                                       v_open && h->blk.nb_interior && h->fold_wait ? yg.flag : nullptr); }
             PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
             if (h->d_params_halo) kb.params = h->d_params_halo;
             if (h->p2p && h->deep) {
@@ -237,8 +254,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                     { HP("evolve second-layer tets"); pjb_launch_tet_alt(h->comm_stream, kb, h->nb_first, h->blk.nb - h->nb_first); }
                 }
                 h->p2p_round++;
-                { HP("wait G"); pjb_launch_wait(h->stream, yg); }
-                { HP("launch vertex interior"); pj_vertex(h, nvb, nvo - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+                interior_particles(h, yg, ev);
                 h->v_pending = true;
                 return 0;
             }
@@ -279,8 +295,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                     h->p2p_raise_pending = false;
                 }
                 h->p2p_round++;
-                { HP("wait G"); pjb_launch_wait(h->stream, yg); }
-                { HP("launch vertex interior"); pj_vertex(h, nvb, h->pj.nv_owned - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+                interior_particles(h, yg, ev);
                 h->v_pending = true;
                 return 0;
             }
@@ -290,8 +305,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
             if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
             if (nvb) { HP("launch vertex boundary"); pjb_launch_vertex(h->comm_stream, kb, 0, nvb, nullptr, nullptr, yg.flag); }
-            { HP("wait G"); pjb_launch_wait(h->stream, yg); }
-            { HP("launch vertex interior"); pj_vertex(h, nvb, h->pj.nv_owned - nvb, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr); }
+            interior_particles(h, yg, ev);
             h->v_pending = true;
             return 0;
         }
@@ -336,7 +350,7 @@ int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of 
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     PJSync yv;
     yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms(h);
-    if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv); }
+    if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv, h->fold_wait ? h->d_sync + 0 : nullptr); }
     if (h->p2p) {   // ... and the "arrived" words of the last boundary-particle kernel, which no following substep's wait will raise
         PJPeerSync w;
         const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
