@@ -63,6 +63,10 @@ class Violation(Exception):
     pass
 
 
+def _words(x):
+    return () if not x else (x,) if isinstance(x, str) else tuple(x)
+
+
 PEER = "peer:"   # prefix of a buffer / word that lives at the OTHER rank (peer-to-peer halo: stores and raises into the neighbour's memory)
 
 
@@ -113,8 +117,8 @@ def explore(calls, mutate=None, program=None):
                 # ---- START
                 if waits is not None and not words[r][wi[waits]]:
                     continue                                   # the wait kernel spins: model it as "cannot complete yet"
-                if extra.get("await") and not words[r][wi[extra["await"]]]:
-                    continue                                   # a kernel whose waves look at the word themselves: no wave gets past its first instruction
+                if any(not words[r][wi[wd]] for wd in _words(extra.get("await"))):
+                    continue                                   # a kernel whose waves look at the word(s) themselves: no wave gets past its first instructions
                 if join is not None and pcs[r * 2 + 1] < join:
                     continue                                   # behind an event recorded on the halo queue
                 if xfer is not None:
@@ -153,10 +157,10 @@ def explore(calls, mutate=None, program=None):
                         nwords[r][wi[waits]] = 0               # consumed (wait kernels are modelled as atomic)
                         npcs[q] += 1
                     else:
-                        if extra.get("clear"):                 # put back a word whose waiters were the waves of the kernel in front
-                            if not nwords[r][wi[extra["clear"]]]:
-                                raise Violation("%s clears %s, which is not raised" % (name, extra["clear"]))
-                            nwords[r][wi[extra["clear"]]] = 0
+                        for wd in _words(extra.get("clear")):  # put back a word whose waiters were the waves of the kernel in front
+                            if not nwords[r][wi[wd]]:
+                                raise Violation("%s clears %s, which is not raised" % (name, wd))
+                            nwords[r][wi[wd]] = 0
                         for word in ((raises,) if isinstance(raises, str) else (raises or ())):
                             wr, wn = where(r, word)
                             if nwords[wr][wi[wn]]:
@@ -234,13 +238,15 @@ def test_the_model_notices_a_broken_choreography(what, mutate):
 # ---- peer-to-peer halo (tetsim_halo_p2p_connect): no transfer; the boundary-particle kernel stores into the PEER's ghost buffer of the
 # next substep's parity, the wait kernel in front of the halo-side tiles raises the peer's "arrived" word of that parity as it starts and
 # waits for its own ------------------------------------------------------------------------------------------------------------------
-def rank_program_p2p(calls, raise_in_own_kernel=False, fold=False):
+def rank_program_p2p(calls, raise_in_own_kernel=False, fold=False, fold_halo=False):
     """As rank_program, for a connected body.  Substep s reads ghost buffer s & 1; P_b(s) also writes the peer's buffer (s + 1) & 1; the
     words A0 / A1 ("arrived", by parity) live at the receiver.  raise_in_own_kernel: partitions of one process give the raise a kernel of
     its own right behind P_b (tetsim_group_step_n), one rank per process folds it into the next wait kernel / the flush.
     fold (tetsim_halo.hip: interior_particles, the default of a connected body): no `wait G` kernel -- the interior particle kernel's
     waves look at G themselves (an 8th element {"await": word}) and nobody consumes it there; the main queue's NEXT operation -- the
-    interior tiles of the next substep, or the flush's signal -- puts it back as it starts ({"clear": word}), in front of its raise."""
+    interior tiles of the next substep, or the flush's signal -- puts it back as it starts ({"clear": word}), in front of its raise.
+    fold_halo (one rank per process): the halo queue's wait kernel is gone too -- the halo-side tiles look at V and at the neighbour's
+    "arrived" word themselves, the boundary-particle kernel behind them puts both back as it starts, in front of its raise of G."""
     main, halo = [], []
     s = 0
     gb = lambda k: PRED_G1 if k & 1 else PRED_G
@@ -259,12 +265,17 @@ def rank_program_p2p(calls, raise_in_own_kernel=False, fold=False):
             if pending:
                 halo.append(("raise A%d" % (s & 1), {}, {}, PEER + "A%d" % (s & 1), None, None, None))
                 pending = False
-            if v_pending:
-                halo.append(("wait V(%d)" % (s - 1), {}, {}, None, "V", None, None))
-            if s > 0:
-                halo.append(("wait A%d(%d)" % (s & 1, s), {}, {}, None, "A%d" % (s & 1), None, None))
-            halo.append(("T_H(%d)" % s, {PRED_B: s, PRED_I: s, gb(s): s}, {PART_H: s + 1}, None, None, None, None))
-            halo.append(("P_b(%d)" % s, {PART_H: s + 1}, {PRED_B: s + 1, PEER + gb(s + 1): s + 1}, "G", None, None, None))
+            looked = (["V"] if v_pending else []) + (["A%d" % (s & 1)] if s > 0 else [])
+            if fold_halo:
+                halo.append(("T_H(%d)" % s, {PRED_B: s, PRED_I: s, gb(s): s}, {PART_H: s + 1}, None, None, None, None, {"await": looked}))
+                halo.append(("P_b(%d)" % s, {PART_H: s + 1}, {PRED_B: s + 1, PEER + gb(s + 1): s + 1}, "G", None, None, None, {"clear": looked}))
+            else:
+                if v_pending:
+                    halo.append(("wait V(%d)" % (s - 1), {}, {}, None, "V", None, None))
+                if s > 0:
+                    halo.append(("wait A%d(%d)" % (s & 1, s), {}, {}, None, "A%d" % (s & 1), None, None))
+                halo.append(("T_H(%d)" % s, {PRED_B: s, PRED_I: s, gb(s): s}, {PART_H: s + 1}, None, None, None, None))
+                halo.append(("P_b(%d)" % s, {PART_H: s + 1}, {PRED_B: s + 1, PEER + gb(s + 1): s + 1}, "G", None, None, None))
             pending = True
             if raise_in_own_kernel:
                 halo.append(("raise A%d" % ((s + 1) & 1), {}, {}, PEER + "A%d" % ((s + 1) & 1), None, None, None))
@@ -298,10 +309,12 @@ P2P = _final_arrived_is_expected(rank_program_p2p)
 P2P_GROUP = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, raise_in_own_kernel=True))
 P2P_FOLD = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, fold=True))
 P2P_GROUP_FOLD = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, raise_in_own_kernel=True, fold=True))
+P2P_FOLD_BOTH = _final_arrived_is_expected(lambda calls: rank_program_p2p(calls, fold=True, fold_halo=True))
 
 
-@pytest.mark.parametrize("program", [P2P, P2P_GROUP, P2P_FOLD, P2P_GROUP_FOLD],
-                         ids=["one rank per process", "ranks of one process", "one rank per process, G awaited by the particle kernel", "ranks of one process, G awaited by the particle kernel"])
+@pytest.mark.parametrize("program", [P2P, P2P_GROUP, P2P_FOLD, P2P_GROUP_FOLD, P2P_FOLD_BOTH],
+                         ids=["one rank per process", "ranks of one process", "one rank per process, G awaited by the particle kernel", "ranks of one process, G awaited by the particle kernel",
+                              "one rank per process, no wait kernel on either queue"])
 @pytest.mark.parametrize("calls", [[1], [2], [3], [1, 1], [2, 1, 2], [4], [2, -2], [1, -1, -3, 2], [3, 3]])
 def test_peer_to_peer_halo_every_interleaving_is_live_and_race_free(calls, program):
     assert explore(calls, program=program) > 10 * sum(abs(n) for n in calls)
@@ -332,9 +345,10 @@ def test_the_model_notices_a_broken_peer_to_peer_choreography(what, mutate):
     ("particle kernel does not await G", _edit(lambda op: op[:7] + ({k: v for k, v in op[7].items() if k != "await"},) if len(op) > 7 else op)),
 ])
 def test_the_model_notices_a_broken_folded_wait(what, mutate):
-    with pytest.raises(Violation):
-        for calls in ([2], [3], [2, 2]):
-            explore(calls, mutate, program=P2P_FOLD)
+    for program in (P2P_FOLD, P2P_FOLD_BOTH):
+        with pytest.raises(Violation):
+            for calls in ([2], [3], [2, 2]):
+                explore(calls, mutate, program=program)
 
 
 # ---- two-layer ghost region on the peer-to-peer halo (TETSIM_FLAG_DEEP_GHOSTS): ghosts cross every other substep ---------------------

@@ -186,6 +186,7 @@ struct tetsim_body {
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
+    bool fold_halo = false;           // peer-to-peer halo: the halo-side tiles do their queue's hand-overs themselves (TETSIM_HALO_FOLD_WAIT=0: a wait kernel in front)
     bool fold_possible = false;       // ... this body could (interior tiles and interior particles exist, not switched off)
     bool fold_wait = false;           // flag path: the interior particle kernel awaits G itself (TETSIM_HALO_FOLD_WAIT=0 at creation: a wait kernel in front of it)
     bool v_pending = false;           // flag path: the interior particles of the last enqueued substep are not signalled yet (flush_v)

@@ -188,7 +188,11 @@ struct PJPeerSync {
 };
 void pjb_launch_wait(hipStream_t s, const PJSync& y);     // one wave: await + clear
 void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w);   // y.flag may be null (nothing local to wait for)
-void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word);
+struct PJClear { uint32_t* word[kMaxPeers + 1] = {}; uint32_t n = 0; };   // words a kernel puts back to 0 as it starts
+void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word, const PJClear& clr = PJClear());
+// the halo-side tiles with the halo queue's hand-overs inside (raise w.raise at the start, await yv.flag and w.wait without clearing them;
+// positions from the memory side, ghosts from `ghosts`)
+void pjb_launch_tet_hwait(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, const PJSync& yv, const PJPeerSync& w, const float4* ghosts);
 void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count);   // ghosts from d.ghost_alt
 void pjb_launch_signal(hipStream_t s, const PJSync& y, uint32_t* clear_word = nullptr);   // one wave: [clear another word,] set
 // the particle kernel whose every wave awaits y.flag itself, without clearing it (the queue's next kernel does: clear_word above)

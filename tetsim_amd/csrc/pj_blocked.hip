@@ -116,8 +116,13 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 // kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
-template <bool kLean, bool kFused, bool kAlt = false>
-__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+// kHaloWait: the halo-side tiles of a peer-to-peer body do their queue's hand-overs themselves (pjb_tet_kernel_hwait): the first wave of
+// every tile looks at V and at the neighbours' "arrived" words -- after the record loads are out, before the positions are asked for --
+// and every position comes from the memory side: the kernel may have started before the data it waits for was written.
+struct PJHaloWait { const PJPeerSync* w; const uint32_t* vflag; uint32_t* error; uint32_t timeout_ms; const float4* ghosts; };
+template <bool kLean, bool kFused, bool kAlt = false, bool kHaloWait = false>
+__device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
+                                             [[maybe_unused]] const PJHaloWait* hw = nullptr) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -202,6 +207,24 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             store_wt(d.fin_out, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
             store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
         }
+    } else if constexpr (kHaloWait) {
+        if (tid < 64u) {
+            const PJPeerSync& w = *hw->w;
+            const uint32_t* word = tid == 0u ? hw->vflag : (tid <= w.n_wait ? w.wait[tid - 1u] : nullptr);
+            bool pending = word != nullptr;
+            const long long t0 = wall_clock64(), limit = 100000ll * hw->timeout_ms;   // 100 MHz ticks
+            while (true) {   // (relaxed looks: an acquire load is a load plus a cache invalidation)
+                if (pending) pending = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
+                if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
+                __builtin_amdgcn_s_sleep(16);
+                if (limit && wall_clock64() - t0 > limit) { if (tid == 0) __hip_atomic_store(hw->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            if (w.delay_us && w.n_wait) { const long long d0 = wall_clock64(); while (wall_clock64() - d0 < 100ll * w.delay_us) __builtin_amdgcn_s_sleep(8); }
+        }
+        __syncthreads();
+        const bool ghost = vid >= d.nv_owned;
+        const float4 own = load_coherent(d.pos_pred, ghost ? 0u : vid), gh = load_coherent(hw->ghosts, ghost ? vid - d.nv_owned : 0u);
+        pos_stage = ghost ? gh : own;
     } else if constexpr (kAlt) {
         const uint32_t g = vid - d.nv_owned;   // (ghost index; two-layer regions keep the layers in separate buffers)
         const float4* src = vid >= d.nv_owned ? (g < d.n_ghost1 ? d.ghost_alt + g : d.ghost2 + (g - d.n_ghost1)) : d.pos_pred + vid;
@@ -327,6 +350,23 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                           uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+// ... doing the halo queue's hand-overs themselves (peer-to-peer halo, one rank per process): as the kernel STARTS its first thread tells
+// the neighbours "my boundary predictions of the previous substep are in your ghost range" (the kernel in front of it in this queue is
+// this rank's boundary-particle kernel), every tile waits for V and the neighbours' words here (kHaloWait), and nobody consumes them:
+// the boundary-particle kernel behind this one puts them back as it starts (pjb_vertex_kernel_peer).  The one-wave wait kernel this
+// replaces was a launch boundary on the chain that decides how much wire latency a rank can hide.
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_hwait(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd,
+                                                              PJPeerSync w, const uint32_t* vflag, uint32_t* error, uint32_t timeout_ms, const float4* ghosts TETSIM_DBG_PARAM) {
+    if (blockIdx.x == 0 && threadIdx.x < w.n_raise) __hip_atomic_store(w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const PJHaloWait hw = {&w, vflag, error, timeout_ms, ghosts};
+    pjb_tet_body<false, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_hwait(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd,
+                                                                            PJPeerSync w, const uint32_t* vflag, uint32_t* error, uint32_t timeout_ms, const float4* ghosts TETSIM_DBG_PARAM) {
+    if (blockIdx.x == 0 && threadIdx.x < w.n_raise) __hip_atomic_store(w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const PJHaloWait hw = {&w, vflag, error, timeout_ms, ghosts};
+    pjb_tet_body<true, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
 }
 // ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -665,8 +705,11 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel_await(PJBlk d, uint32_t 
     // only input another queue's kernel may still have been writing when this kernel started, are read past the caches instead)
     pjb_vertex_body<false, true>(d, first, count);
 }
-__global__ __launch_bounds__(64) void pjb_vertex_kernel_peer(PJBlk d, uint32_t first, uint32_t count, PJPeer peer, uint32_t* sig) {
-    if (sig) raise(sig);
+__global__ __launch_bounds__(64) void pjb_vertex_kernel_peer(PJBlk d, uint32_t first, uint32_t count, PJPeer peer, uint32_t* sig, PJClear clr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // (the words the halo-side tiles in front of this kernel looked at: all of them are through)
+        for (uint32_t i = 0; i < clr.n; i++) __hip_atomic_store(clr.word[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (sig) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     pjb_vertex_body<true>(d, first, count, &peer);
 }
 // One wave in front of the halo-side tiles of a peer-to-peer body: (1) as it STARTS, the boundary-particle kernel in front of it
@@ -787,9 +830,15 @@ uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks) {
     return 8;
 }
 void pjb_launch_wait_peers(hipStream_t s, const PJSync& y, const PJPeerSync& w) { hipLaunchKernelGGL(pjb_wait_peers_kernel, dim3(1), dim3(64), 0, s, y.flag, y.error, y.timeout_ms, w); }
-void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word) {
+void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJPeer& peer, uint32_t* raise_word, const PJClear& clr) {
     if (count == 0) return;
-    hipLaunchKernelGGL(pjb_vertex_kernel_peer, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, peer, raise_word);
+    hipLaunchKernelGGL(pjb_vertex_kernel_peer, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, peer, raise_word, clr);
+}
+void pjb_launch_tet_hwait(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, const PJSync& yv, const PJPeerSync& w, const float4* ghosts) {
+    if (tile_count == 0) return;
+    const uint32_t per_xcd = (tile_count + 7u) / 8u;
+    auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_hwait : pjb_tet_kernel_hwait;
+    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, w, yv.flag, yv.error, yv.timeout_ms, ghosts TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count) {
     if (tile_count == 0) return;

@@ -273,15 +273,24 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 if (h->loopback) { static const uint32_t delay_us = [] { const char* e = getenv("TETSIM_DEBUG_LOOPBACK_DELAY_US"); return e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : 0u; }(); w.delay_us = delay_us; }
                 PJSync yw = yv;
                 if (!(v_open && h->blk.nb_interior)) yw.flag = nullptr;
-                if (yw.flag || w.n_raise || w.n_wait) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
+                // One rank per process with boundary particles (fold_halo): no wait kernel -- the halo-side tiles raise, look at V and
+                // at the neighbours' words themselves, and the boundary-particle kernel behind them puts those words back as it starts.
+                const bool fold = h->fold_halo && h->group.empty() && nvb != 0u && !h->needs_halo_refresh;
+                if (!fold && (yw.flag || w.n_raise || w.n_wait)) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
                 if ((rc = halo_wait(h, h->comm_stream))) return rc;   // (a refresh exchange after a dt change, in-process groups)
                 kb.ghost_alt = h->ghost_alt;
                 PJPeer pr;
                 pr.slots = h->d_peer_slots; pr.cols = h->p2p_cols; pr.stride = h->p2p_stride; pr.n = static_cast<uint32_t>(h->links.size());
                 for (size_t i = 0; i < h->links.size(); i++) pr.ghost[i] = h->links[i].ghost[par ^ 1u];
-                { HP("launch tet halo-side"); if (par) pjb_launch_tet_alt(h->comm_stream, kb, h->blk.nb_interior, nbnd); else pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
+                PJClear clr;
+                if (fold) {
+                    HP("launch tet halo-side (hand-overs inside)");
+                    pjb_launch_tet_hwait(h->comm_stream, kb, h->blk.nb_interior, nbnd, yw, w, par ? h->ghost_alt : h->pj.pos_pred + h->pj.nv_owned);
+                    if (yw.flag) clr.word[clr.n++] = yw.flag;
+                    for (uint32_t i = 0; i < w.n_wait; i++) clr.word[clr.n++] = w.wait[i];
+                } else { HP("launch tet halo-side"); if (par) pjb_launch_tet_alt(h->comm_stream, kb, h->blk.nb_interior, nbnd); else pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
                 if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
-                else { HP("launch vertex boundary"); pjb_launch_vertex_peer(h->comm_stream, kb, 0, nvb, pr, yg.flag); h->p2p_raise_pending = true; }
+                else { HP("launch vertex boundary"); pjb_launch_vertex_peer(h->comm_stream, kb, 0, nvb, pr, yg.flag, clr); h->p2p_raise_pending = true; }
                 if (h->p2p_raise_pending && !h->group.empty()) {
                     // partitions of ONE process may share hardware queues: a wait of one body must never be submitted in front of the
                     // kernel of another body that raises its word.  Here the raise gets a kernel of its own right behind the

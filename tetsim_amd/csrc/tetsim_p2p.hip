@@ -189,6 +189,10 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     h->p2p_round = 0;
     h->p2p_raise_pending = false;
     h->fold_wait = h->fold_possible;   // (between calls: nothing is pending, the captured chains are dropped below)
+    {   // ... and the halo queue's wait kernel goes into the halo-side tiles (tetsim_halo.hip: enqueue_phase_a), one-layer ghost regions only
+        const char* fw = getenv("TETSIM_HALO_FOLD_WAIT");
+        h->fold_halo = !(fw && fw[0] == '0') && !h->deep;
+    }
     h->halo_warm = false;     // the first call after the connection runs eagerly (its first substep has no "arrived" to wait for)
     drop_flag_graphs(h);
     return 0;
