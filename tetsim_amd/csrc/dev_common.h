@@ -142,7 +142,7 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                       uint32_t* raise_word = nullptr);
+                       uint32_t* raise_word = nullptr, uint32_t* clear_word = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 // n substeps of an unpartitioned fused-eligible body in ONE persistent launch (pjb_frame_kernel): every tile's workgroup stays
 // resident for the whole call.  block_tile[blocks]: the tile each block works on, -1 = none (the host places the tiles of a body

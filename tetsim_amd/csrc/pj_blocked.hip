@@ -683,8 +683,8 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
-__global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t first, uint32_t count, uint32_t* sig) {
-    raise(sig);
+__global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t first, uint32_t count, uint32_t* sig, uint32_t* clear) {
+    clear_then_raise(clear, sig);
     pjb_vertex_body(d, first, count);
 }
 // ... waiting for a hand-over word ITSELF: every wave looks at the word before it touches a partial sum (one lane, agent-scope loads,
@@ -853,11 +853,11 @@ void pjb_launch_vertex_await(hipStream_t s, const PJBlk& d, uint32_t first, uint
     if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel_await, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count, y.flag, y.error, y.timeout_ms);
     else hipLaunchKernelGGL(pjb_vertex_kernel_await, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, y.flag, y.error, y.timeout_ms);
 }
-void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word) {
+void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word, uint32_t* clear_word) {
     if (count == 0) return;
-    if (raise_word) {
-        if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count, raise_word);
-        else hipLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, raise_word);
+    if (raise_word || clear_word) {
+        if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count, raise_word, clear_word);
+        else hipLaunchKernelGGL(pjb_vertex_kernel_raise, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, raise_word, clear_word);
         return;
     }
     if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count);

@@ -173,6 +173,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const char* fw = getenv("TETSIM_HALO_FOLD_WAIT");
             h->fold_possible = !(fw && fw[0] == '0') && h->partitioned && B.num_interior_blocks > 0 && B.num_interior_blocks < B.num_blocks && nvo > nvb;
             h->fold_wait = h->fold_possible && fw && fw[0] == '1';
+            h->fold_halo = h->fold_wait;   // (RCCL bodies: only when forced; the peer-to-peer connection switches both on)
         }
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;

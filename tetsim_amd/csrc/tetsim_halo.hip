@@ -137,7 +137,10 @@ bool uses_flag_sync(const tetsim_body* h) {
 // substep on this queue, like a monolithic body, instead of three.
 static void interior_particles(tetsim_body* h, const PJSync& yg, hipEvent_t* ev) {
     const uint32_t nvb = h->pj.nv_boundary, cnt = h->pj.nv_owned - nvb;
-    if (h->fold_wait) {
+    // Waves that look at a word hold their slots while they wait, and the kernel that raises the word needs slots too: only one rank
+    // per process (partitions of one process share the device: eight 1 M-tet slabs' particle kernels are 22,000 waves on 8,192 slots
+    // -- they starved the boundary-particle kernels until the time-out), and only while the kernel is at most half the device's waves.
+    if (h->fold_wait && h->group.empty() && (cnt + 63u) / 64u <= 4096u) {
         HP("launch vertex interior (awaits G)");
         pjb_launch_vertex_await(h->stream, h->blk, nvb, cnt, yg, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
         return;
@@ -183,9 +186,10 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             if (v_open && h->blk.nb_interior) h->v_pending = false;
             else if ((rc = flush_v(h))) return rc;
             // (fold_wait: whoever raises V also puts G back -- the waves that looked at it belong to the kernel in front of this one)
+            const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - nvb + 63u) / 64u <= 4096u;   // (interior_particles' rule)
             { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr,
                                                        v_open && h->blk.nb_interior ? yv.flag : nullptr,
-                                                       v_open && h->blk.nb_interior && h->fold_wait ? yg.flag : nullptr); }
+                                                       v_open && h->blk.nb_interior && g_folded ? yg.flag : nullptr); }
             PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
             if (h->d_params_halo) kb.params = h->d_params_halo;
             if (h->p2p && h->deep) {
@@ -275,7 +279,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 if (!(v_open && h->blk.nb_interior)) yw.flag = nullptr;
                 // One rank per process with boundary particles (fold_halo): no wait kernel -- the halo-side tiles raise, look at V and
                 // at the neighbours' words themselves, and the boundary-particle kernel behind them puts those words back as it starts.
-                const bool fold = h->fold_halo && h->group.empty() && nvb != 0u && !h->needs_halo_refresh;
+                const bool fold = h->fold_halo && h->group.empty() && nvb != 0u && !h->needs_halo_refresh && nbnd <= 512u;   // (at most a quarter of the device's workgroup slots may wait)
                 if (!fold && (yw.flag || w.n_raise || w.n_wait)) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
                 if ((rc = halo_wait(h, h->comm_stream))) return rc;   // (a refresh exchange after a dt change, in-process groups)
                 kb.ghost_alt = h->ghost_alt;
@@ -308,12 +312,16 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 h->v_pending = true;
                 return 0;
             }
-            if (v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
+            // (RCCL, one rank per process, TETSIM_HALO_FOLD_WAIT=1: the halo-side tiles look at V themselves -- as the peer-to-peer branch
+            // does by default -- and the boundary-particle kernel puts it back)
+            const bool fold_v = h->fold_halo && h->comm && h->group.empty() && nvb != 0u && v_open && h->blk.nb_interior && nbnd <= 512u;
+            if (!fold_v && v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
             if ((rc = halo_wait(h, h->comm_stream))) return rc;   // in-process groups: the neighbours' transfers of the previous substep (events)
-            { HP("launch tet halo-side"); pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
+            if (fold_v) { HP("launch tet halo-side (awaits V)"); pjb_launch_tet_hwait(h->comm_stream, kb, h->blk.nb_interior, nbnd, yv, PJPeerSync(), h->pj.pos_pred + h->pj.nv_owned); }
+            else { HP("launch tet halo-side"); pjb_launch_tet(h->comm_stream, kb, h->blk.nb_interior, nbnd); }
             if (!nvb) { HP("signal G"); pjb_launch_signal(h->comm_stream, yg); }
             if (!h->comm) { HP("record boundary"); HIPCHK(h, hipEventRecord(h->ev_boundary2[h->halo_parity], h->comm_stream)); }  // group transport: ghosts are free again
-            if (nvb) { HP("launch vertex boundary"); pjb_launch_vertex(h->comm_stream, kb, 0, nvb, nullptr, nullptr, yg.flag); }
+            if (nvb) { HP("launch vertex boundary"); pjb_launch_vertex(h->comm_stream, kb, 0, nvb, nullptr, nullptr, yg.flag, fold_v ? yv.flag : nullptr); }
             interior_particles(h, yg, ev);
             h->v_pending = true;
             return 0;
@@ -359,7 +367,8 @@ int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of 
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     PJSync yv;
     yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms(h);
-    if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv, h->fold_wait ? h->d_sync + 0 : nullptr); }
+    const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - h->pj.nv_boundary + 63u) / 64u <= 4096u;   // (interior_particles' rule)
+    if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv, g_folded ? h->d_sync + 0 : nullptr); }
     if (h->p2p) {   // ... and the "arrived" words of the last boundary-particle kernel, which no following substep's wait will raise
         PJPeerSync w;
         const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
