@@ -116,8 +116,8 @@ typedef struct TetSimOptions {
     int32_t device;     /* HIP device ordinal */
     double density;     /* physicsParams.density, consumed at construction (Softbody.js:32,74) */
     /* Domain decomposition (POLAR_JACOBI).  part_count <= 1: whole mesh on this handle.  Otherwise this
-     * handle owns the vertices v with vert_owner[v] == part_index (vert_owner == NULL: equal contiguous
-     * index ranges) plus a ghost layer; see DESIGN.md "Multi-GPU". */
+     * handle owns the vertices v with vert_owner[v] == part_index (vert_owner == NULL: the built-in
+     * partitioner, tetsim_prep_partition without coordinates) plus a ghost layer; see DESIGN.md "Multi-GPU". */
     int32_t part_count;
     int32_t part_index;
     const int32_t *vert_owner;
@@ -413,6 +413,33 @@ int tetsim_prep_ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t nu
  * invRestVolume[nt]. */
 int tetsim_prep_rest(const float *verts, uint32_t nv, const int32_t *tets, uint32_t nt, double density,
                      float *inv_mass, float *inv_rest_pose, float *inv_rest_volume);
+
+/* The built-in vertex partitioner for general meshes (SURVEY.md 8(e) "General meshes: host-side graph partition"; the coupling a cut
+ * must respect is the particle -> incident tets table of SoftbodyGPU.js:563-577 that the Jacobi average :306-319 reads): which
+ * partition owns each particle, vert_owner_out [nv], values in [0, part_count).  Recursive bisection at the weighted median
+ * (weights 1 + valence: a part's tets ~ the corners it owns / 4) of the key that cuts the fewest tets -- breadth-first distances
+ * from the two ends of a pseudo-diameter and their difference (topology only), plus x / y / z when `verts` is not NULL -- then
+ * k-way boundary refinement (a particle moves to the part holding more of its tet-mates) with every part kept within +-3% of the
+ * mean weight.  Deterministic.  tetsim_create and tetsim_plan_create* with part_count > 1 and vert_owner == NULL use this WITHOUT
+ * coordinates (verts == NULL: the plan entry points have none, and a plan must equal what tetsim_create builds); pass the
+ * result of a call WITH coordinates as vert_owner to both for planar cuts on lattice-like meshes, or store it in a .tetsim
+ * container (TetSimMeshArrays.vert_owner). */
+int tetsim_prep_partition(const float *verts /* [3*nv] or NULL */, uint32_t nv, const int32_t *tets, uint32_t nt,
+                          int32_t part_count, int32_t *vert_owner_out);
+/* What a particle -> partition map costs, per partition (out [part_count]; the counts the partition plans would have, without
+ * building them).  vert_owner == NULL: the map tetsim_create would pick itself.  Ghost-particle fraction of partition r =
+ * ghost_particles / (owned_particles + ghost_particles) -- what crosses the wire per substep against what is integrated --,
+ * ghost-tet fraction = (local_elems - owned_elems summed over r) / num_elems -- the tets solved twice. */
+typedef struct TetSimPartQuality {
+    uint32_t owned_particles;    /* particles this partition integrates */
+    uint32_t ghost_particles;    /* particles it reads but does not own (received every substep) */
+    uint32_t boundary_particles; /* owned particles some other partition reads (sent every substep) */
+    uint32_t local_elems;        /* tets it solves: every tet touching an owned particle */
+    uint32_t owned_elems;        /* tets counted once across partitions (lowest-owner rule) */
+    uint32_t num_neighbours;
+} TetSimPartQuality;
+int tetsim_prep_partition_quality(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t part_count,
+                                  const int32_t *vert_owner, TetSimPartQuality *out);
 
 /* Domain-decomposition plan of one partition, computed on the host exactly as tetsim_create does for
  * part_count > 1 (local numbering: owned boundary | owned interior | ghosts grouped by owner).  Lets a host

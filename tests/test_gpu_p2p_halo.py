@@ -26,12 +26,14 @@ def _gather(parts, nv):
     return pos
 
 
-@pytest.mark.parametrize("case", ["slabs2", "slabs5", "dragon3"])
+@pytest.mark.parametrize("case", ["slabs2", "slabs5", "dragon3", "dragon3_partitioner"])
 def test_p2p_equals_copy_transport_bit_for_bit(case):
-    if case == "dragon3":
+    if case.startswith("dragon3"):
+        from tetsim_amd.partition import index_range_owner
         v, t = load_mesh("dragon")
         v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])
-        n, owner = 3, None                                   # contiguous index ranges of the Dragon: ragged interfaces
+        # contiguous index ranges of the Dragon: ragged interfaces, two neighbours reading one particle; or the built-in partitioner's cut
+        n, owner = 3, (index_range_owner(len(v), 3) if case == "dragon3" else None)
     else:
         n = int(case[5:])
         cells = 16

@@ -335,12 +335,16 @@ def test_quats_follow_local_tet_order():
     within("polar fast blocked vs gather quats dragon @30", np.abs(qa - b.quats).max(), 1e-4)
 
 
-def test_partition_irregular_mesh():
-    """Dragon-class mesh with an arbitrary (index-range) vertex partition: non-contiguous send lists."""
+@pytest.mark.parametrize("cut", ["partitioner", "index_ranges"])
+def test_partition_irregular_mesh(cut):
+    """Dragon-class mesh cut by the library's own partitioner (no owner map given: tetsim_prep_partition), and by contiguous index
+    ranges of the file's vertex order (ragged interfaces): non-contiguous send lists, PRECISE partitioned == monolithic bit for bit."""
+    from tetsim_amd.partition import index_range_owner
     v, t = load_mesh("dragon")
     parts = 4
+    owner = None if cut == "partitioner" else index_range_owner(len(v), parts)
     mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar")
-    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", part_count=parts, part_index=p) for p in range(parts)]
+    bodies = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", part_count=parts, part_index=p, vert_owner=owner) for p in range(parts)]
     for _ in range(25):
         mono.simulate(DT20, PP)
         for b in bodies:

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from conftest import load_mesh
 from tetsim_amd import make_lattice
-from tetsim_amd.partition import PartitionPlan, slab_owner
+from tetsim_amd.partition import PartitionPlan, index_range_owner, slab_owner
 
 PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
           worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
@@ -25,7 +25,9 @@ def _mesh(kind):
         v, t = make_lattice(4, nz=9, y0=0.03)
         return v, t, lambda world: slab_owner(4, 9, world)
     v, t = load_mesh("dragon")
-    return v, t, lambda world: None  # index-range ownership: ragged, non-contiguous halos
+    if kind == "dragon_ranges":
+        return v, t, lambda world: index_range_owner(len(v), world)  # the file's vertex order cut into ranges: ragged, non-contiguous halos
+    return v, t, lambda world: None  # no owner given: the built-in partitioner (tetsim_prep_partition without coordinates)
 
 
 def _worker(rank, world, port, kind, nsteps, out_dir):
@@ -64,7 +66,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind,world", [("slab", 2), ("slab", 3), ("dragon", 2)])
+@pytest.mark.parametrize("kind,world", [("slab", 2), ("slab", 3), ("dragon", 2), ("dragon", 3), ("dragon_ranges", 2)])
 def test_partitioned_gloo_equals_single_process(kind, world, tmp_path):
     from oracle import OraclePJ
     nsteps = 30

@@ -70,6 +70,11 @@ class TetSimPlanSizes(C.Structure):
                 ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32), ("num_neighbours", C.c_uint32)]
 
 
+class TetSimPartQuality(C.Structure):
+    _fields_ = [("owned_particles", C.c_uint32), ("ghost_particles", C.c_uint32), ("boundary_particles", C.c_uint32),
+                ("local_elems", C.c_uint32), ("owned_elems", C.c_uint32), ("num_neighbours", C.c_uint32)]
+
+
 class TetSimError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("tetsim error %d: %s" % (code, msg))
@@ -89,7 +94,7 @@ SYMBOLS = [
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_p2p_export", "tetsim_halo_p2p_connect",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
-    "tetsim_prep_tiles", "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
+    "tetsim_prep_tiles", "tetsim_prep_slot_table", "tetsim_prep_ref_grab_texels", "tetsim_prep_rest", "tetsim_prep_partition", "tetsim_prep_partition_quality", "tetsim_plan_create", "tetsim_plan_destroy", "tetsim_plan_sizes",
     "tetsim_plan_arrays", "tetsim_plan_neighbour", "tetsim_plan_neighbour_ids",
     "tetsim_plan_create_deep", "tetsim_plan_layers", "tetsim_plan_neighbour_layer2", "tetsim_plan_neighbour_layer2_ids",
     "tetsim_mesh_write", "tetsim_mesh_open", "tetsim_mesh_arrays", "tetsim_mesh_close", "tetsim_create_from_file",
@@ -173,6 +178,8 @@ def lib():
     L.tetsim_prep_slot_table.argtypes = [ip, u32, u32, i32, ip, C.POINTER(u32)]
     L.tetsim_prep_ref_grab_texels.argtypes = [i32, u32, u32, ip]
     L.tetsim_prep_rest.argtypes = [fp, u32, ip, u32, dbl, fp, fp, fp]
+    L.tetsim_prep_partition.argtypes = [fp, u32, ip, u32, i32, ip]
+    L.tetsim_prep_partition_quality.argtypes = [ip, u32, u32, i32, ip, C.POINTER(TetSimPartQuality)]
     L.tetsim_plan_create.argtypes = [ip, u32, u32, i32, i32, ip, C.POINTER(H)]
     L.tetsim_plan_destroy.argtypes = [H]
     L.tetsim_plan_destroy.restype = None

@@ -30,6 +30,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-paramet
 UNITS = {
     "host_prep.cpp": ["-ffp-contract=off", "-x", "hip"],
     "mesh_file.cpp": ["-ffp-contract=off", "-x", "hip"],
+    "partitioner.cpp": ["-ffp-contract=off", "-x", "hip"],
     "tetsim_api.hip": ["-ffp-contract=off"],
     "tetsim_state.hip": ["-ffp-contract=off"],
     "tetsim_visual.hip": ["-ffp-contract=off"],

@@ -86,6 +86,7 @@ struct PJBlk {
     uint32_t n_ghost1 = 0xffffffffu;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
+    unsigned long long* iter_hist = nullptr; // development (ablation build): rotation-iteration statistics, TETSIM_DEBUG_ITER_HIST (pj_blocked.hip: pjb_log_iterations)
 };
 
 // ---- NEOHOOKEAN_GS device state ---------------------------------------------------------------------

@@ -552,8 +552,8 @@ std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int p
             owner[v] = vert_owner[v];
         }
     } else {
-        for (uint32_t v = 0; v < nv; v++)
-            owner[v] = static_cast<int32_t>(std::min<uint64_t>(part_count - 1, static_cast<uint64_t>(v) * part_count / nv));
+        const std::string perr = prep_partition(nullptr, nv, tets, nt, part_count, owner.data());
+        if (!perr.empty()) return perr;
     }
     const int me = part_index;
 

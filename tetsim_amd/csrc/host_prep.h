@@ -83,7 +83,17 @@ struct Partition {
     uint32_t n_ghost1 = 0;
     std::vector<uint8_t> tet_layer;
 };
-// vert_owner may be null (equal contiguous index ranges). Returns "" or an error message.
+// The built-in vertex partitioner (partitioner.cpp): recursive bisection by breadth-first pseudo-diameter keys (and by x / y / z when
+// `verts` is given), then k-way boundary refinement; weights 1 + valence, parts within +-3% of the mean.  out_owner [nv].
+std::string prep_partition(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, int parts, int32_t* out_owner);
+// What a vertex -> part map costs, per part (the counts build_partition would produce for it, without building the plans).
+struct PartQuality {
+    uint32_t owned_particles = 0, ghost_particles = 0, boundary_particles = 0;   // ghosts: read, not owned; boundary: owned, read by others
+    uint32_t local_elems = 0, owned_elems = 0;                                    // tets solved here; tets counted once (lowest-owner rule)
+    uint32_t num_neighbours = 0;
+};
+std::string partition_quality(const int32_t* tets, uint32_t nt, uint32_t nv, int parts, const int32_t* owner, PartQuality* out);
+// vert_owner may be null: prep_partition without coordinates (the plan entry points have none). Returns "" or an error message.
 std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int part_count, int part_index,
                             const int32_t* vert_owner, Partition* out, int depth = 1);
 

@@ -92,6 +92,37 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
     return o;
 }
 
+#ifdef TETSIM_ABLATION
+// Development (TETSIM_DEBUG_ITER_HIST; tools/rotation_iterations.py): what a tet's nine |omega|^2 say about exit thresholds.  For each of
+// the thresholds {1e-9 (the reference's), 1e-7, 3e-7, 1e-6} the number of iterations this tet (level 0) and its whole wave (level 1:
+// the loop is wave-uniform) would execute if the correction iterations 2..9 ended at that threshold -- iteration 1 always uses 1e-9 --
+// and the distribution of |omega| per iteration in half decades.  hist: [2][4][10] counts by iterations executed (1..9), then
+// [9][22] half-decade bins (bin 0: < 1e-10 incl. "done", bin 21: >= 1).
+__device__ __forceinline__ void pjb_log_iterations(unsigned long long* hist, const float* w2log) {
+    const float thr2[4] = {1.0e-18f, 1.0e-14f, 9.0e-14f, 1.0e-12f};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int n = 9;
+#pragma unroll
+        for (int j = 8; j >= 0; j--) {   // the first iteration whose omega fails the test ends the loop (computed, not applied)
+            const float lim = j == 0 ? 1.0e-18f : thr2[k];
+            if (w2log[j] < lim) n = j + 1;   // (-1 = not executed: done)
+        }
+        atomicAdd(&hist[(0 * 4 + k) * 10 + n], 1ull);
+        int wn = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wn = max(wn, __shfl_xor(wn, o));   // (lanes without a tet are not here: the tail wave of a tile under-reports by its idle lanes only)
+        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__builtin_amdgcn_ballot_w64(true))) - 1)) atomicAdd(&hist[(1 * 4 + k) * 10 + wn], 1ull);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const float w = w2log[j] > 0.0f ? sqrtf(w2log[j]) : 0.0f;
+        int bin = w > 0.0f ? static_cast<int>(floorf(2.0f * log10f(w))) + 21 : 0;   // 1e-10 -> 1, 1 -> 21
+        bin = min(max(bin, 0), 21);
+        atomicAdd(&hist[80 + j * 22 + bin], 1ull);
+    }
+}
+#endif
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
@@ -254,7 +285,15 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         // world-space goal is goal + cc.  Same bytes as the reference's world-space shape, 21 instructions fewer per tet
         // (no rest centroid, no subtraction), and without the add-then-subtract of a position-sized number every substep.
         f3 cc;
+#ifdef TETSIM_ABLATION
+        float w2log[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) w2log[i] = -1.0f;   // -1: iteration not executed (the wave had left the loop: every tet done)
+        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.iter_hist ? w2log : nullptr);
+        if (d.iter_hist) pjb_log_iterations(d.iter_hist, w2log);
+#else
         pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc);
+#endif
         TETSIM_STAMP(3);  // solved
         // LDS staging first, global results after it: nothing below may have to wait for the write-through stores
         const f3 vcc = cc * V;

@@ -467,6 +467,18 @@ void tetsim_destroy(tetsim_handle h) {
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
     }
+#ifdef TETSIM_ABLATION
+    if (h->blk.iter_hist && getenv("TETSIM_DEBUG_ITER_HIST")) {   // one text line per body, appended: "<tets> <particles> <278 counters>"
+        std::vector<unsigned long long> hs(278);
+        if (hipMemcpy(hs.data(), h->blk.iter_hist, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = fopen(getenv("TETSIM_DEBUG_ITER_HIST"), "a")) {
+                fprintf(f, "%u %u", h->info.num_elems, h->info.num_particles);
+                for (unsigned long long x : hs) fprintf(f, " %llu", x);
+                fprintf(f, "\n");
+                fclose(f);
+            }
+    }
+#endif
     // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();

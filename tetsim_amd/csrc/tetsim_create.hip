@@ -353,6 +353,12 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
+#ifdef TETSIM_ABLATION
+        if (getenv("TETSIM_DEBUG_ITER_HIST")) {  // development: rotation-iteration statistics of every tet-kernel launch (pjb_log_iterations)
+            if ((rc = dev_alloc(h, &k.iter_hist, 278))) return rc;
+            HIPCHK(h, hipMemset(k.iter_hist, 0, 278 * sizeof(unsigned long long)));
+        }
+#endif
         if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
             if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
             HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));

@@ -115,6 +115,34 @@ int tetsim_prep_rest(const float* verts, uint32_t nv, const int32_t* tets, uint3
     return 0;
 }
 
+// ---- the built-in partitioner (partitioner.cpp) -------------------------------------------------------------------
+int tetsim_prep_partition(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, int32_t part_count, int32_t* vert_owner_out) {
+    if ((nt && !tets) || (nv && !vert_owner_out) || part_count < 1) return fail(nullptr, TETSIM_EINVAL, "tetsim_prep_partition: null argument or part_count < 1");
+    if (verts)
+        for (uint64_t i = 0; i < 3ull * nv; i++)
+            if (!std::isfinite(verts[i])) return fail(nullptr, TETSIM_EINVAL, "non-finite vertex coordinate");
+    const std::string e = prep_partition(verts, nv, tets, nt, part_count, vert_owner_out);
+    return e.empty() ? TETSIM_OK : fail(nullptr, TETSIM_EINVAL, e);
+}
+int tetsim_prep_partition_quality(const int32_t* tets, uint32_t nt, uint32_t nv, int32_t part_count, const int32_t* vert_owner, TetSimPartQuality* out) {
+    if ((nt && !tets) || !out || part_count < 1) return fail(nullptr, TETSIM_EINVAL, "tetsim_prep_partition_quality: null argument or part_count < 1");
+    std::vector<int32_t> own;
+    if (!vert_owner) {   // what tetsim_create / tetsim_plan_create pick by themselves
+        own.resize(nv);
+        const std::string e = prep_partition(nullptr, nv, tets, nt, part_count, own.data());
+        if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+        vert_owner = own.data();
+    }
+    std::vector<PartQuality> q(part_count);
+    const std::string e = partition_quality(tets, nt, nv, part_count, vert_owner, q.data());
+    if (!e.empty()) return fail(nullptr, TETSIM_EINVAL, e);
+    for (int32_t r = 0; r < part_count; r++) {
+        out[r].owned_particles = q[r].owned_particles; out[r].ghost_particles = q[r].ghost_particles; out[r].boundary_particles = q[r].boundary_particles;
+        out[r].local_elems = q[r].local_elems; out[r].owned_elems = q[r].owned_elems; out[r].num_neighbours = q[r].num_neighbours;
+    }
+    return TETSIM_OK;
+}
+
 // ---- partition plan (host only) ---------------------------------------------------------------------------------
 struct tetsim_plan_s { Partition P; };
 

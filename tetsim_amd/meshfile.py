@@ -118,7 +118,7 @@ def _main(argv):
     pk.add_argument("--vis", help="f32 [tetNr,b0,b1,b2] per embedded vertex")
     pk.add_argument("--vis-tris", help="i32, 3 ids per triangle")
     pk.add_argument("--colour", action="store_true", help="store the greedy tet colouring")
-    pk.add_argument("--parts", type=int, default=0, help="store a contiguous-range partition map for N parts")
+    pk.add_argument("--parts", type=int, default=0, help="store the built-in partitioner's particle -> partition map for N parts (tetsim_prep_partition)")
     inf = sub.add_parser("info", help="print the sections of a .tetsim file")
     inf.add_argument("file")
     args = ap.parse_args(argv)
@@ -136,9 +136,12 @@ def _main(argv):
             kw["tet_colour"], n = greedy_colours(t, v.size // 3)
             print("colours:", n)
         if args.parts > 1:
-            nv = v.size // 3
-            kw["vert_owner"] = np.minimum(np.arange(nv) * args.parts // nv, args.parts - 1).astype(np.int32)
+            from .partition import partition, partition_quality   # the built-in partitioner, with the coordinates' candidates
+            kw["vert_owner"] = partition(t, v.size // 3, args.parts, v)
             kw["part_count"] = args.parts
+            q = partition_quality(t, v.size // 3, args.parts, kw["vert_owner"])
+            print("partition: %d parts, ghost particles %.1f%%, ghost tets %.1f%%, local-tet imbalance %.1f%%" %
+                  (args.parts, 100 * q["ghost_particle_fraction"], 100 * q["ghost_tet_fraction"], 100 * q["local_tet_imbalance"]))
         write_mesh(args.out, v, t, **kw)
         print("wrote", args.out)
     else:

@@ -18,6 +18,43 @@ def slab_owner(n_cells_xy, nz_cells, parts):
     return np.minimum(k // per, parts - 1).astype(np.int32)
 
 
+def index_range_owner(num_particles, parts):
+    """Equal contiguous index ranges: the cut a file's vertex order happens to give (the library's default until round 4; kept for tests
+    that want ragged interfaces)."""
+    return np.minimum(np.arange(num_particles, dtype=np.int64) * parts // max(num_particles, 1), parts - 1).astype(np.int32)
+
+
+def partition(tetIds, num_particles, parts, vertices=None):
+    """The library's built-in vertex partitioner (include/tetsim.h: tetsim_prep_partition): owner [num_particles] in [0, parts).
+    vertices=None is what tetsim_create / tetsim_plan_create use when no owner is given (topology only); with coordinates the
+    axis-aligned cuts are candidates too."""
+    tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
+    v = None if vertices is None else np.ascontiguousarray(np.asarray(vertices).reshape(-1), dtype=np.float32)
+    out = np.empty(int(num_particles), dtype=np.int32)
+    capi.check(capi.lib().tetsim_prep_partition(v.ctypes.data_as(C.POINTER(C.c_float)) if v is not None else None, int(num_particles),
+                                                tets.ctypes.data_as(C.POINTER(C.c_int32)), tets.size // 4, int(parts),
+                                                out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
+def partition_quality(tetIds, num_particles, parts, vert_owner=None):
+    """Per part: owned / ghost / boundary particles, local / owned tets, neighbours (tetsim_prep_partition_quality), and the totals
+    a decomposition is judged by.  vert_owner=None: the map the library picks itself."""
+    tets = np.ascontiguousarray(np.asarray(tetIds).reshape(-1), dtype=np.int32)
+    own = None if vert_owner is None else np.ascontiguousarray(vert_owner, dtype=np.int32)
+    q = (capi.TetSimPartQuality * int(parts))()
+    capi.check(capi.lib().tetsim_prep_partition_quality(tets.ctypes.data_as(C.POINTER(C.c_int32)), tets.size // 4, int(num_particles), int(parts),
+                                                        own.ctypes.data_as(C.POINTER(C.c_int32)) if own is not None else None, q))
+    per = [{k: int(getattr(q[r], k)) for k, _ in capi.TetSimPartQuality._fields_} for r in range(int(parts))]
+    nt = tets.size // 4
+    local = [p["local_elems"] for p in per]
+    return {"parts": per,
+            "ghost_particle_fraction": sum(p["ghost_particles"] for p in per) / max(1, sum(p["ghost_particles"] + p["owned_particles"] for p in per)),
+            "ghost_tet_fraction": (sum(local) - nt) / max(1, sum(local)),
+            "local_tet_imbalance": max(local) / (sum(local) / len(local)) - 1.0 if sum(local) else 0.0,
+            "max_neighbours": max(p["num_neighbours"] for p in per)}
+
+
 class Neighbour:
     __slots__ = ("rank", "send_local", "send_global", "recv_start", "recv_count", "recv_global", "contiguous",
                  "send2_local", "send2_global", "recv2_start", "recv2_count", "recv2_global")   # second ghost layer (depth 2)
