@@ -141,7 +141,7 @@ def cpu_baseline(verts, tets):
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def other_configs():
+def other_configs(steps=20, warmup=5):
     """BASELINE configs 1, 2 and 4 on this box, outside the timed region, a few seconds in total.  (Config 3 is the line itself,
     config 5 needs N > 1.)  Same metric everywhere: M tet-solves/s = tets x substeps / wall."""
     import shutil
@@ -192,6 +192,23 @@ def other_configs():
                     "every tile's workgroup resident for the 20 substeps; PRECISE: a tet and a particle kernel per substep)",
         "fast": hip_rate(dv, dtets, 20, 400, solver="polar", precision="fast"),
         "precise": hip_rate(dv, dtets, 20, 200, solver="polar", precision="precise")}
+    # config 3 once more with the REFERENCE's rotation-exit threshold (TETSIM_FLAG_REF_ROTATION_EXIT: |omega| < 1e-9, i.e. all nine iterations
+    # in f32, SoftbodyGPU.js:131) -- the headline's FAST default ends a tet's correction iterations below 1e-6 rad.  Same lattice, same
+    # protocol as the headline (warm-up + timed frames from rest); what the threshold is worth depends on the phase of the fall.
+    lv, lt = make_lattice(CELLS)
+    body = SoftBodyHIP(lv, lt, None, dict(PP), solver="polar", precision="fast", ref_rotation_exit=True)
+    for _ in range(warmup):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        body.simulateSubsteps(SUBSTEPS, DT, PP)
+    body.sync()
+    el = time.perf_counter() - t0
+    body.close()
+    out["config3_reference_threshold"] = {
+        "workload": "the headline's lattice and frames (%d warm-up + %d timed, from rest) with rotation_exit = the reference's |omega| < 1e-9" % (warmup, steps),
+        "value": round(len(lt) * SUBSTEPS * steps / el / 1e6, 1), "unit": "M tet-solves/s", "ms_per_step": round(el / steps * 1e3, 4)}
     # config 4: Neo-Hookean Gauss-Seidel on the 1 M-tet lattice + convergence against Jacobi (dropped 2 cm onto the floor)
     v, t = make_lattice(CELLS, y0=0.02)
     Dm_inv = np.linalg.inv((v[t[:, 1:]] - v[t[:, :1]]).astype(np.float64).transpose(0, 2, 1))
@@ -973,6 +990,9 @@ def run(args, rank, world, local_rank, ranks):
                                    "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
                        "solver": "polar_jacobi", "arithmetic": args.precision,
                        "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
+                       "rotation_exit": ("iteration 1: |omega| < 1e-9 (the reference's, SoftbodyGPU.js:131); correction iterations 2..9: |omega| < 1e-6 rad "
+                                         "(FAST default; other_configs.config3_reference_threshold has the same frames with 1e-9 throughout)") if args.precision == "fast"
+                                        else "|omega| < 1e-9 (the reference's, SoftbodyGPU.js:131)",
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
             "library": lib,
@@ -1076,7 +1096,7 @@ def run(args, rank, world, local_rank, ranks):
         if not args.no_beyond_mall and args.precision == "fast" and cells == CELLS and args.solver == "polar" and "roofline" in out:
             out["roofline"]["beyond_mall"] = beyond_mall(args, local_rank, out["roofline"].get("measured_copy_peak", {}))
         if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
-            out["other_configs"] = other_configs()
+            out["other_configs"] = other_configs(args.steps, args.warmup)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(verts, tets)
     return out, body

@@ -96,7 +96,14 @@ enum {
     /* partitioned POLAR_JACOBI + TETSIM_FAST (blocked): a ghost region TWO layers deep.  The partition advances its first ghost layer
      * itself and its neighbours' particles cross only every other substep -- half the hand-overs on the substep's critical chain
      * (DESIGN.md 6).  Needs the peer-to-peer halo (tetsim_halo_p2p_connect) before the first step; dt must stay fixed. */
-    TETSIM_FLAG_DEEP_GHOSTS = 1u << 5
+    TETSIM_FLAG_DEEP_GHOSTS = 1u << 5,
+    /* POLAR_JACOBI + TETSIM_FAST: end a tet's rotation iterations only where the reference does (|omega| < 1e-9,
+     * SoftbodyGPU.js:131 -- unreachable in f32 unless the tet is exactly rigid, so all nine run).  Without the flag FAST ends the
+     * CORRECTION iterations 2..9 of a tet (of a wavefront, when all its tets agree) once |omega| < 1e-6 rad: an order of magnitude
+     * below the rotation that f32 position rounding alone induces in a centimetre-sized tet a metre from the origin (iteration 1 of
+     * a rigid free fall reads 1e-6..3e-5, profiles/r04_rotation_iterations.txt).  Iteration 1 always keeps the reference's test.
+     * PRECISE ignores this flag: it always is the reference. */
+    TETSIM_FLAG_REF_ROTATION_EXIT = 1u << 6
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */

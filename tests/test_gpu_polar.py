@@ -68,6 +68,34 @@ def test_fast_tolerance(gather):
             within("polar fast %s vs oracle dragon @%d" % ("gather" if gather else "blocked", step), np.abs(body.pos - orc.pos).max(), tol[step])
 
 
+@pytest.mark.parametrize("gather", [False, True])
+def test_reference_rotation_exit_flag(gather):
+    """FAST ends a tet's correction iterations 2..9 below |omega| = 1e-6 rad (DESIGN.md 5.3, profiles/r04_rotation_iterations.txt);
+    TETSIM_FLAG_REF_ROTATION_EXIT keeps the reference's 1e-9 (SoftbodyGPU.js:131: all nine iterations in f32).  Both must sit inside
+    the same FAST envelope against the oracle (which runs all nine), the two stay within the envelope of each other, and the flag is
+    a no-op for PRECISE."""
+    v, t = load_mesh("dragon")
+    ref, orc = _pair(v, t, precision="fast", gather=gather, ref_rotation_exit=True)
+    dflt = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", gather=gather)
+    tol = {1: 2e-6, 20: 5e-5, 200: 2e-3}
+    name = "gather" if gather else "blocked"
+    for step in range(1, 201):
+        for b in (ref, dflt, orc):
+            b.simulate(DT20, PP)
+        if step in tol:
+            within("polar fast %s reference rotation exit vs oracle dragon @%d" % (name, step), np.abs(ref.pos - orc.pos).max(), tol[step])
+            within("polar fast %s default vs reference rotation exit dragon @%d" % (name, step), np.abs(dflt.pos - ref.pos).max(), tol[step])
+    if not gather:
+        a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
+        b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise", ref_rotation_exit=True)
+        a.simulateSubsteps(40, DT20, PP); b.simulateSubsteps(40, DT20, PP)
+        assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+        # the frame kernel (tetsim_step_n) and the per-substep kernels (tetsim_step) of the flagged body agree bit for bit as well
+        c = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_rotation_exit=True)
+        c.simulateSubsteps(200, DT20, PP)
+        assert np.array_equal(c.pos.view(np.uint32), ref.pos.view(np.uint32))
+
+
 def test_constant_rest_shape_option():
     """TETSIM_FLAG_CONSTANT_REST_SHAPE: R(q) * rest0 instead of the carried world-space shape.  Equal in exact
     arithmetic, so it must sit inside the same FAST envelope against the oracle (which carries the shape, as the

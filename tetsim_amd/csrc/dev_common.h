@@ -39,6 +39,7 @@ struct PJDev {
     int32_t* slot_tab = nullptr;  // ELL [max_valence][nv_pad]: index into elem (corner*nt_pad + tet)
     uint32_t* slot_cnt = nullptr; // [nv_pad]
     const DevParams* params = nullptr;
+    float rot_exit_w2 = 1.0e-18f; // FAST: squared |omega| that ends a tet's correction iterations (pj_math.inc)
 };
 
 // ---- POLAR_JACOBI, blocked formulation (FAST mode; DESIGN.md "Blocked formulation") -----------------------
@@ -85,6 +86,7 @@ struct PJBlk {
     const float4* ghost2 = nullptr;
     uint32_t n_ghost1 = 0xffffffffu;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
+    float rot_exit_w2 = 1.0e-18f;            // squared |omega| that ends a tet's correction iterations 2..9 (pj_math.inc; 1e-18 = the reference's 1e-9)
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
     unsigned long long* iter_hist = nullptr; // development (ablation build): rotation-iteration statistics, TETSIM_DEBUG_ITER_HIST (pj_blocked.hip: pjb_log_iterations)
 };

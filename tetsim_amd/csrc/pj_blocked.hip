@@ -289,10 +289,10 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         float w2log[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) w2log[i] = -1.0f;   // -1: iteration not executed (the wave had left the loop: every tet done)
-        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.iter_hist ? w2log : nullptr);
+        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.rot_exit_w2, d.iter_hist ? w2log : nullptr);
         if (d.iter_hist) pjb_log_iterations(d.iter_hist, w2log);
 #else
-        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc);
+        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.rot_exit_w2);
 #endif
         TETSIM_STAMP(3);  // solved
         // LDS staging first, global results after it: nothing below may have to wait for the write-through stores
@@ -548,7 +548,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
             for (int k = 0; k < 4; k++) r[k] = rest[k];
             float4 q_new;
             f3 cc;
-            pj_solve_tet(cur, r, q, q_new, goal, kFrameIters, true, kLean, !kLean, &cc);
+            pj_solve_tet(cur, r, q, q_new, goal, kFrameIters, true, kLean, !kLean, &cc, d.rot_exit_w2);
             q = q_new;
             if (!kLean) {
 #pragma unroll

@@ -110,6 +110,8 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     if ((rc = dev_alloc(h, &d.pos_final, nvl))) return rc;
     if ((rc = dev_alloc(h, &d.vel, nvl))) return rc;
     d.params = h->d_params;
+    // FAST: the correction iterations 2..9 of a tet end below 1e-6 rad unless the caller wants the reference's 1e-9 (pj_math.inc)
+    d.rot_exit_w2 = (h->fast && !(o.flags & TETSIM_FLAG_REF_ROTATION_EXIT)) ? 1.0e-12f : 1.0e-18f;
 
     std::vector<float4> pos(nvl);
     std::vector<float> lverts(3ull * nvl);
@@ -177,6 +179,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         }
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
+        k.rot_exit_w2 = d.rot_exit_w2;
         uint32_t *bto, *bvo, *lcr, *vpe;
         int32_t* bv;
         uchar4* lidx;

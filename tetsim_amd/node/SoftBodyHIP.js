@@ -20,7 +20,8 @@ const path = require('path');
 const SOLVER = { polar: 0, neohookean: 1 };
 const PRECISION = { precise: 0, fast: 1 };
 const ORDER = { original: 0, coloured: 1, clustered: 2 };
-const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2, FLAG_GATHER_FORMULATION = 4, FLAG_CONSTANT_REST_SHAPE = 8, FLAG_REF_GRAB_TEXEL = 16;
+const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2, FLAG_GATHER_FORMULATION = 4, FLAG_CONSTANT_REST_SHAPE = 8, FLAG_REF_GRAB_TEXEL = 16,
+    FLAG_REF_ROTATION_EXIT = 64;
 
 let addon = null;
 function loadTetSim(libPath) {
@@ -50,7 +51,7 @@ class SoftBodyHIP {
             solver: SOLVER[this._solver], precision: PRECISION[opt.precision || 'precise'], order: ORDER[opt.order || 'original'],
             flags: (opt.refSlotTable === false ? 0 : FLAG_REF_SLOT_TABLE) | (opt.refFixedBounds === false ? 0 : FLAG_REF_FIXED_BOUNDS) |
                    (opt.gather ? FLAG_GATHER_FORMULATION : 0) | (opt.constantRestShape ? FLAG_CONSTANT_REST_SHAPE : 0) |
-                   (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0),
+                   (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0) | (opt.refRotationExit ? FLAG_REF_ROTATION_EXIT : 0),
             device: opt.device || 0,
             partCount: opt.partCount || 1, partIndex: opt.partIndex || 0,
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
