@@ -487,7 +487,8 @@ int tetsim_abi_version(void);
  * tet kernel obeys TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL -- never the product; debug_env: bit i set = the i-th of
  * {TETSIM_DEBUG_LOOPBACK_HALO, TETSIM_DEBUG_LOOPBACK_COPY, TETSIM_DEBUG_ONE_STREAM, TETSIM_DEBUG_GROUP_SYNC,
  * TETSIM_DEBUG_HOSTPROF, TETSIM_DEBUG_TRACE, TETSIM_HALO_SYNC, TETSIM_HALO_GRAPH, TETSIM_DEBUG_LOOPBACK_DELAY_US, TETSIM_NH_QUADS,
- * TETSIM_FUSED_PARTICLE_PASS} is set in the
+ * TETSIM_FUSED_PARTICLE_PASS, TETSIM_FRAME_KERNEL, TETSIM_FRAME_LOCAL, TETSIM_NH_FOLD, TETSIM_HALO_ALIGNED_TILES, TETSIM_HALO_FOLD_WAIT, TETSIM_QUAD,
+ * TETSIM_QUAD_POLL_DELAY} is set in the
  * environment.  bench.py records all of it in its JSON line. */
 typedef struct TetSimLibraryInfo {
     int32_t abi;

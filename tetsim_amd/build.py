@@ -43,6 +43,9 @@ UNITS = {
     "pj_precise.hip": ["-ffp-contract=off"],
     "pj_fast.hip": ["-ffp-contract=fast"],
     "pj_blocked.hip": ["-ffp-contract=fast"],
+    # four lanes per tet, small bodies: the frame kernel and its two-launch substep must agree bit for bit, so no contraction is left to
+    # the compiler -- every fused multiply-add is spelled out in the source
+    "pj_quad.hip": ["-ffp-contract=off"],
     "nh_precise.hip": ["-ffp-contract=off"],
     # kernarg preload: the four-lane cluster kernel's leading scalar arguments (ids, particles, mask, count) arrive in SGPRs with the
     # wave instead of through a scalar load at the head of every colour's chain: 66.8 -> 65.4 us per substep (profiles/r03_neohookean.txt)

@@ -179,12 +179,15 @@ struct tetsim_body {
     bool fused = false;
     // persistent frame kernel (pjb_frame_kernel): tetsim_step_n runs ONE launch per call; fused bodies of few enough tiles
     bool frame = false;
-    uint32_t frame_epoch = 1;         // sequence number of the next call's first substep (DevParams::epoch), advanced by n per call
+    uint32_t frame_epoch = 1;         // sequence number of the next call's first substep (DevParams::epoch), advanced by 65536 per parameter push
+    bool quad = false;                // SMALL body: 64-tet tiles, one tet / one particle on four lanes (pj_quad.hip) -- tetsim_step runs pjq_tet + pjq_vertex,
+                                      // tetsim_step_n the persistent pjq_frame_kernel (while `frame`); the three agree bit for bit
     uint32_t* d_frame_err = nullptr;  // raised by a tile whose neighbour's partial sums never arrived (bounded wait)
     int32_t* d_block_tile = nullptr;  // [frame_blocks] tile of every block of the frame kernel's grid, -1 = none
     uint32_t frame_blocks = 0;
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
+    size_t partial_slots = 0;         // float4s in each of the two
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)
     bool fold_halo = false;           // peer-to-peer halo: the halo-side tiles do their queue's hand-overs themselves (TETSIM_HALO_FOLD_WAIT=0: a wait kernel in front)
     bool fold_possible = false;       // ... this body could (interior tiles and interior particles exist, not switched off)

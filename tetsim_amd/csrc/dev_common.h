@@ -17,8 +17,9 @@ struct DevParams {
     float grab[3];
     int32_t grab_local;  // local vertex index, -1 = none
     int32_t grab_local2; // second pinned particle (TETSIM_FLAG_REF_GRAB_TEXEL can select two), -1 = none
-    uint32_t epoch;      // persistent frame kernel (pj_blocked.hip): sequence number of this call's first substep (the host adds n per call)
-    int32_t pad3[2];
+    uint32_t epoch;      // persistent frame kernel (pj_blocked.hip): sequence number of this call's first substep (the host advances it by 65536 per parameter push: tetsim_api.hip push_params)
+    int32_t poll_delay;  // pj_quad.hip frame kernel: s_sleep units (64 clocks each) between a tile's partial-sum store and its first look at the neighbours'
+    int32_t pad3[1];
     // f64 view -- NEOHOOKEAN_GS: JS numbers (Softbody.js:195-240)
     double d_dt, d_gravity, d_friction, d_dev_compliance, d_vol_compliance;
     double d_lo[3], d_hi[3];
@@ -154,6 +155,14 @@ void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
 // did not appear within timeout_ms (never in a correct run: all workgroups are co-resident -- pjb_frame_capacity).
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
                       uint32_t* err, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// ... and the same three entry points for SMALL bodies tiled into 64-tet tiles, one tet / one particle on four lanes (pj_quad.hip):
+// the persistent frame kernel, and its substep as two launches through memory (tetsim_step, tetsim_profile, fallback).  All three
+// agree bit for bit.  d.partial: the split kernels' partial sums; pbuf0 / pbuf1: the frame kernel's (sequence-numbered).
+void pjq_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
+                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pjq_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void pjq_launch_vertex(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+uint32_t pjq_frame_capacity(uint32_t* compute_units);              // workgroups of pjq_frame_kernel one CU keeps resident (0 = query failed)
 uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units);   // workgroups of the frame kernel one CU keeps resident (0 = query failed)
 uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks);            // 8 if block i of a grid runs on XCD i % 8, else 0
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores

@@ -365,11 +365,12 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet, const uint32_t* body_first_vert, uint32_t bodies,
-                  uint32_t nv_boundary, const uint8_t* tet_class, uint32_t nv_owned) {
+                  uint32_t nv_boundary, const uint8_t* tet_class, uint32_t nv_owned, uint32_t tile) {
     BlockPlan& B = *out;
     B = BlockPlan();
+    B.tile = tile;
     if (nv_owned > nv_sum) nv_owned = nv_sum;
-    constexpr uint32_t kMaxTets = kBlockTile, kMaxVerts = kBlockTile;   // = the tet kernel's workgroup size (pj_blocked.hip kTile)
+    const uint32_t kMaxTets = tile, kMaxVerts = tile;   // = tets (and LDS particle slots) of one workgroup: pj_blocked.hip kTile, or pj_quad.hip kQuadTile
     const uint32_t one_t[2] = {0u, nt}, one_v[2] = {0u, nv};
     if (!body_first_tet || !body_first_vert || bodies == 0) { body_first_tet = one_t; body_first_vert = one_v; bodies = 1; }
     // 1. Morton order of rest centroids (quantised to 10 bits per axis over the body's bounding box), body after body

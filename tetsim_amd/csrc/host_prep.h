@@ -109,8 +109,12 @@ std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t
 #define TETSIM_TILE 256
 #endif
 constexpr uint32_t kBlockTile = TETSIM_TILE;   // tets per workgroup tile of the blocked polar kernel (pj_blocked.hip kTile)
+constexpr uint32_t kQuadTile = 64;             // ... of the four-lanes-per-tet kernels of small bodies (pj_quad.hip): 64 quads = 256 threads
+constexpr int32_t kQuadPollDelay = 0;           // s_sleep units between a tile's store and its first poll of the neighbours' sums (TETSIM_QUAD_POLL_DELAY overrides: A/B)
+constexpr uint32_t kQuadMaxPartials = 12;      // ... which take lists of at most this many partial sums per particle (the Dragon: 10)
 struct BlockPlan {
     uint32_t num_blocks = 0;
+    uint32_t tile = kBlockTile;          // tets (and particle slots) per tile at most: 256 (pj_blocked.hip) or kQuadTile (pj_quad.hip, small bodies)
     std::vector<int32_t> tet_perm;       // new tet position -> input tet index
     std::vector<uint32_t> blk_tet_off;   // [num_blocks+1]
     std::vector<uint32_t> blk_vert_off;  // [num_blocks+1] into blk_verts / partial sums
@@ -151,7 +155,7 @@ struct BlockPlan {
 void build_blocks(const float* verts, const int32_t* tets, uint32_t nt, uint32_t nv, uint32_t nv_sum,
                   const Incidence& inc, BlockPlan* out, const uint32_t* body_first_tet = nullptr,
                   const uint32_t* body_first_vert = nullptr, uint32_t bodies = 1, uint32_t nv_boundary = 0,
-                  const uint8_t* tet_class = nullptr, uint32_t nv_owned = 0xffffffffu);
+                  const uint8_t* tet_class = nullptr, uint32_t nv_owned = 0xffffffffu, uint32_t tile = kBlockTile);
 
 std::string validate_mesh(const float* verts, uint32_t nv, const int32_t* tets, uint32_t nt, bool forbid_repeats);
 

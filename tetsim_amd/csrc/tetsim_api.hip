@@ -72,6 +72,8 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
         } else o->grab_local = to_device(h->grab_global);
     }
     o->epoch = h->frame_epoch;
+    static const int32_t poll_delay = [] { const char* e = getenv("TETSIM_QUAD_POLL_DELAY"); return e ? atoi(e) : kQuadPollDelay; }();
+    o->poll_delay = poll_delay;
     o->d_dt = dt;
     o->d_gravity = p.gravity;
     o->d_friction = p.friction;
@@ -88,8 +90,17 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
     if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
-    // every call gets a fresh block of sequence numbers for the partial sums of the frame kernel (DevParams::epoch + the substep's
-    // index inside the call): stale sums of an earlier call never match
+    // every call gets a fresh block of 65,536 sequence numbers for the partial sums of the frame kernel (DevParams::epoch + the substep's
+    // index inside the call; tetsim_step_n chunks longer calls): stale sums of an earlier call never match.  Before the 32-bit
+    // counter wraps -- 65,535 pushes, minutes at interactive rates -- the numbers left in both buffers are wiped (in stream order,
+    // behind every kernel that reads them) and the count restarts: a sum of 65,536 calls ago can never pass for a fresh one.
+    if (h->frame_epoch >= 0xfffe0000u) {
+        if (h->partial_b && h->partial_slots) {
+            HIPCHK(h, hipMemsetAsync(h->blk.partial, 0, h->partial_slots * sizeof(float4), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->partial_b, 0, h->partial_slots * sizeof(float4), h->stream));
+        }
+        h->frame_epoch = 1u;
+    }
     h->frame_epoch += 65536u;
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
@@ -110,11 +121,13 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
 void pj_tet(tetsim_body* h, hipEvent_t e0, hipEvent_t e1) {
-    if (h->blocked) pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb, e0, e1);
+    if (h->quad) pjq_launch_tet(h->stream, h->blk, e0, e1);
+    else if (h->blocked) pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb, e0, e1);
     else h->fast ? pj_launch_tet_fast(h->stream, h->pj, e0, e1) : pj_launch_tet_precise(h->stream, h->pj, e0, e1);
 }
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0, hipEvent_t e1) {
-    if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
+    if (h->quad) pjq_launch_vertex(h->stream, h->blk, e0, e1);   // (all owned particles: quad bodies are unpartitioned)
+    else if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
     else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count, e0, e1) : pj_launch_vertex_precise(h->stream, h->pj, first, count, e0, e1);
 }
 // One substep of a fused body inside a run of substeps with one dt:
@@ -255,7 +268,8 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
     if (h->frame) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
-        pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+        if (h->quad) pjq_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+        else pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else
@@ -521,6 +535,10 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
     if (!h) return TETSIM_EINVAL;
     if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     if (n == 0) return 0;
+    while (h->frame && n > 32768u) {   // (a persistent launch numbers its substeps inside one block of 65,536 sequence numbers)
+        if (int rc = tetsim_step_n(h, 32768u, dt, params)) return rc;
+        n -= 32768u;
+    }
     HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = push_params(h, dt, params);
     if (rc) return rc;

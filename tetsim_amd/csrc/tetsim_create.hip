@@ -154,8 +154,24 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 }
             }
         }
-        build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo + nvg1, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
-                     batch ? h->batch_first_vert.data() : nullptr, bodies, nvb, h->partitioned ? tet_class.data() : nullptr, nvo);
+        // SMALL bodies (the reference's own workload, main.js:79-84) are tiled into 64-tet tiles and solved with one tet / one particle
+        // on FOUR lanes (pj_quad.hip): every tile's workgroup must be resident at once for the frame kernel, half the device's capacity
+        // at most (another body's kernels may hold slots too).  TETSIM_QUAD=0 keeps the 256-tet tiles (development A/B).
+        static const bool allow_quad = [] { const char* e = getenv("TETSIM_QUAD"); return !(e && e[0] == '0'); }();
+        uint32_t quad_cus = 0, quad_per_cu = 0;
+        bool quad = allow_quad && !h->partitioned && !(o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && ntl > 0 && nvo == nvl;
+        if (quad) {
+            quad_per_cu = pjq_frame_capacity(&quad_cus);
+            quad = quad_per_cu != 0u && (static_cast<uint64_t>(ntl) + kQuadTile - 1u) / kQuadTile <= static_cast<uint64_t>(quad_per_cu) * quad_cus / 2u;
+        }
+        for (;;) {
+            build_blocks(lverts.data(), ltets.data(), ntl, nvl, nvo + nvg1, inc, &B, batch ? h->batch_first_tet.data() : nullptr,
+                         batch ? h->batch_first_vert.data() : nullptr, bodies, nvb, h->partitioned ? tet_class.data() : nullptr, nvo, quad ? kQuadTile : kBlockTile);
+            // (what the quad kernels take: every particle summed by some tile, lists of at most kQuadMaxPartials partial sums, all tiles resident)
+            if (!quad || (B.every_owned_particle_has_a_partial && B.max_partials <= kQuadMaxPartials && B.num_blocks <= quad_per_cu * quad_cus / 2u)) break;
+            quad = false;
+        }
+        h->quad = quad;
         h->tet_perm = B.tet_perm;
         h->nb_first = B.num_first_blocks;
         // the two-queue halo path (tetsim_halo.hip) rests on this: an interior tile touches neither a ghost nor a boundary particle
@@ -235,7 +251,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 for (uint32_t u = 0; u < nu; u++) {
                     const uint32_t first = B.lc_range[v0 + u] & 0x7ffu, last = B.lc_range[v0 + u] >> 16;   // (bit 15: owner flag)
                     float w = 0.0f;
-                    for (uint32_t i = first; i < last; i++) w += volh[t0 + (B.lc_ent[4ull * t0 + i] % kBlockTile)];
+                    for (uint32_t i = first; i < last; i++) w += volh[t0 + (B.lc_ent[4ull * t0 + i] % B.tile)];
                     slot_w[v0 + u] = w;
                 }
             }
@@ -261,20 +277,23 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         // (32.0 us against 25.6 + 5.8), needs 74 registers instead of 49 (6 waves per SIMD instead of 8) and reads lower on the
         // roofline -- and keeps the two-kernel substep.  TETSIM_FUSED_PARTICLE_PASS=1 forces it on (A/B).
         static const bool force_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return e && e[0] == '1'; }();
-        h->fused = allow_fused && !h->partitioned && nvo == nvl && B.every_owned_particle_has_a_partial && B.max_partials <= 9 && ntl > 0 &&
+        h->fused = allow_fused && !h->quad && !h->partitioned && nvo == nvl && B.every_owned_particle_has_a_partial && B.max_partials <= 9 && ntl > 0 &&
                    (B.num_blocks < 2048u || force_fused);
         k.fin_in = d.pos_final; k.fin_out = d.pos_final;
         h->info.fused_particle_pass = h->fused ? 1u : 0u;
-        if (h->fused) {
+        if (h->fused || h->quad) {
             uint32_t *dsrc, *dmax;
             if ((rc = dev_alloc(h, &dsrc, B.slot_src.size()))) return rc;
             if ((rc = dev_alloc(h, &dmax, B.blk_maxsrc.size()))) return rc;
             if ((rc = dev_alloc(h, &h->partial_b, nslots))) return rc;
-            if ((rc = dev_alloc(h, &h->pos_final_b, nvl))) return rc;
             if ((rc = upload(h, dsrc, B.slot_src))) return rc;
             if ((rc = upload(h, dmax, B.blk_maxsrc))) return rc;
             HIPCHK(h, hipMemset(h->partial_b, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
-            if ((rc = upload(h, h->pos_final_b, pos))) return rc;
+            h->partial_slots = nslots;
+            if (h->fused) {   // (the fused per-substep kernel double-buffers the end-of-substep positions; the quad kernels do not)
+                if ((rc = dev_alloc(h, &h->pos_final_b, nvl))) return rc;
+                if ((rc = upload(h, h->pos_final_b, pos))) return rc;
+            }
             k.slot_src = dsrc; k.blk_maxsrc = dmax; k.ns_pad = B.ns_pad;
             // ... and bodies small enough for every tile's workgroup to be resident at once run a whole tetsim_step_n call as ONE
             // persistent launch (pj_blocked.hip: pjb_frame_kernel; TETSIM_FRAME_KERNEL=0 keeps one kernel per substep: A/B).  Half
@@ -288,7 +307,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             // through the memory side.  Either way at most half the resident workgroups the device offers are used: another body's
             // kernels may hold slots too, and a waiting tile keeps its slot.
             uint32_t cus = 0;
-            const uint32_t per_cu = allow_frame ? pjb_frame_capacity(k.lean, &cus) : 0u;
+            const uint32_t per_cu = !allow_frame ? 0u : h->quad ? pjq_frame_capacity(&cus) : pjb_frame_capacity(k.lean, &cus);
             const uint32_t nbk = B.num_blocks;
             std::vector<int32_t> block_tile;
             if (per_cu != 0u && nbk != 0u && nbk <= per_cu * cus / 2u) {

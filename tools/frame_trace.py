@@ -1,6 +1,7 @@
 """Development: where a substep of the persistent frame kernel (pjb_frame_kernel) spends its cycles -- thread 0 of every tile adds up
 s_memtime differences per phase over one call (ablation build; python -m tetsim_amd.build --ablation).
-    python tools/frame_trace.py [substeps]"""
+    python tools/frame_trace.py [substeps] [floor]      floor: the Dragon starts 1 cm above the floor (contact: all nine rotation iterations)
+TETSIM_QUAD=0: the one-lane-per-tet frame kernel on 256-tet tiles (pj_blocked.hip) instead of the four-lane one (pj_quad.hip)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,8 @@ G = os.path.join(ROOT, "tests", "golden")
 v = np.fromfile(os.path.join(G, "dragon_verts.f32"), dtype="<f4").reshape(-1, 3); t = np.fromfile(os.path.join(G, "dragon_tets.i32"), dtype="<i4").reshape(-1, 4)
 pp = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0, worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+if len(sys.argv) > 2 and sys.argv[2] == "floor":
+    v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])
 dt = (1 / 60) / 20
 b = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast")
 for _ in range(5):
