@@ -1036,8 +1036,13 @@ def run(args, rank, world, local_rank, ranks):
         if world == 1:
             # SURVEY.md 8(d) "bounding roofline": the peak is also MEASURED on this box -- a device copy at the footprint class of
             # the 1 M-tet working set (fits the 256 MB Infinity Cache) and at 1 GiB (streams from HBM)
+            # (the tuned probe of tetsim_measure_stream_bandwidth: four independent 16-byte accesses per lane, plain / non-temporal and the
+            # grid size chosen at first use; read-only and write-only rates beside the copy rate)
+            from tetsim_amd import measure_stream_bandwidth
             cp = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0), "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
             out["roofline"]["measured_copy_peak"] = cp
+            out["roofline"]["measured_stream_peak_1GiB"] = {"read": round(measure_stream_bandwidth(1 << 30, "read", 10), 0),
+                                                            "write": round(measure_stream_bandwidth(1 << 30, "write", 10), 0), "unit": "GB/s"}
             out["roofline"]["frac_of_measured_peak"] = {"kernel_vs_64MiB_copy": round(achieved / cp["64MiB"], 4),
                                                         "kernel_vs_1GiB_copy": round(achieved / cp["1GiB"], 4),
                                                         "substep_vs_64MiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["64MiB"], 4),

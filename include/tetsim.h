@@ -317,6 +317,11 @@ int tetsim_time_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParam
 /* Device-to-device stream copy of `bytes` on the handle's stream, `reps` times: measured copy
  * bandwidth in GB/s (read+write bytes / time) -- the "measured HBM peak" of SURVEY.md §8(d). */
 int tetsim_measure_copy_bandwidth(int32_t device, uint64_t bytes, uint32_t reps, double *gbps_out);
+/* The same probe by kind: 0 = copy (read + write bytes / time, what tetsim_measure_copy_bandwidth returns), 1 = read only, 2 = write
+ * only (bytes / time).  Every lane keeps four independent 16-byte accesses in flight; at its first use per (device, kind, size class)
+ * the probe times plain and non-temporal accesses at five grid sizes and keeps the fastest -- a yardstick has to be the best the
+ * chip does, not one guess at it (MI355X_MICROARCH.md "HBM": ~6.3 TB/s achievable for a float4 copy). */
+int tetsim_measure_stream_bandwidth(int32_t device, uint64_t bytes, uint32_t reps, int32_t kind, double *gbps_out);
 
 /* --- multi-GPU halo (POLAR_JACOBI, part_count > 1) ---------------------------------------------- */
 

@@ -91,7 +91,7 @@ SYMBOLS = [
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh",
     "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
-    "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth",
+    "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth", "tetsim_measure_stream_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_p2p_export", "tetsim_halo_p2p_connect",
     "tetsim_halo_export", "tetsim_halo_import", "tetsim_prep_levels", "tetsim_prep_colours", "tetsim_prep_clusters",
@@ -161,6 +161,7 @@ def lib():
     L.tetsim_time_kernels.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]
     L.tetsim_time_step_n.argtypes = [H, u32, dbl, PP, dp]
     L.tetsim_measure_copy_bandwidth.argtypes = [i32, C.c_uint64, u32, dp]
+    L.tetsim_measure_stream_bandwidth.argtypes = [i32, C.c_uint64, u32, i32, dp]
     L.tetsim_comm_unique_id.argtypes = [C.c_void_p]
     L.tetsim_comm_init.argtypes = [H, C.c_void_p, i32, i32]
     L.tetsim_comm_selftest.argtypes = [H]

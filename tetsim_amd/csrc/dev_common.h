@@ -241,6 +241,9 @@ void util_launch_pack_xyz(hipStream_t s, const float4* src, const uint32_t* map,
 void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, uint32_t n, double px, double py, double pz,
                          double* best_d2, uint32_t* best_id);
 void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n);
+// streaming probe (tetsim_measure_stream_bandwidth): kind 0 copy / 1 read only / 2 write only, nt = non-temporal accesses, unroll = 4 or 8
+// independent 16-byte accesses per lane, grid = workgroups (0: one per chunk of 256 x unroll float4s)
+void util_launch_stream(hipStream_t s, int kind, bool nt, uint32_t unroll, uint32_t grid, const float4* src, float4* dst, uint64_t n);
 void util_launch_delay(hipStream_t s, uint32_t us);   // loopback measurements: a stand-in for wire latency
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 

@@ -1,14 +1,49 @@
 // util_kernels.hip -- small memory-bound helpers: stream copy (measured-peak probe),
 // halo pack (gather of 16-byte elements).
+#include <algorithm>
+
 #include "dev_common.h"
 
 namespace tetsim {
 namespace {
 
-// 16 B per lane, grid-stride: one dwordx4 load + one dwordx4 store per element, 1 KiB per wave instruction.
-__global__ __launch_bounds__(256) void copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t n) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+// Streaming probes: the MEASURED memory peak the roofline fractions are quoted against (MI355X_MICROARCH.md "HBM": 8 TB/s
+// spec, ~6.3 TB/s achievable with a float4 copy).  A workgroup takes chunks of 256 x kUnroll float4s: every lane has kUnroll
+// INDEPENDENT 16-byte accesses in flight (one load + one store per trip of a plain grid-stride loop -- the first version -- left the
+// memory system a quarter idle: 4.84 TB/s at 1 GiB), optionally non-temporal (the data is touched once).  kKind: 0 copy, 1 read only
+// (the sum keeps the loads alive; it is stored by no lane of a sane run), 2 write only.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int kKind, bool kNt, uint32_t kStreamUnroll>
+__global__ __launch_bounds__(256) void stream_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, uint64_t n, v4f* __restrict__ sink) {
+    const uint64_t chunk = 256ull * kStreamUnroll, chunks = (n + chunk - 1) / chunk;
+    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint64_t k = blockIdx.x; k < chunks; k += gridDim.x) {
+        const uint64_t base = k * chunk + threadIdx.x;
+        v4f a[kStreamUnroll];
+        if constexpr (kKind != 2) {
+#pragma unroll
+            for (uint32_t u = 0; u < kStreamUnroll; u++) {
+                const uint64_t i = base + 256ull * u;
+                const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                a[u] = i < n ? (kNt ? __builtin_nontemporal_load(src + i) : src[i]) : zero;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < kStreamUnroll; u++) { const v4f one = {1.0f, 2.0f, 3.0f, static_cast<float>(k)}; a[u] = one; }
+        }
+        if constexpr (kKind == 1) {
+#pragma unroll
+            for (uint32_t u = 0; u < kStreamUnroll; u++) acc += a[u];
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < kStreamUnroll; u++) {
+                const uint64_t i = base + 256ull * u;
+                if (i < n) { if constexpr (kNt) __builtin_nontemporal_store(a[u], dst + i); else dst[i] = a[u]; }
+            }
+        }
+    }
+    if constexpr (kKind == 1)
+        if (acc.x == 123456.789f && acc.y == acc.z) sink[threadIdx.x] = acc;   // (never: the probe's buffers hold one repeated byte)
 }
 
 __global__ __launch_bounds__(256) void gather16_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx,
@@ -77,13 +112,31 @@ void util_launch_nearest(hipStream_t s, const float4* pos, const uint32_t* map, 
     hipLaunchKernelGGL(nearest_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, pos, map, n, px, py, pz, best_d2, best_id);
 }
 
-void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n) {
-    if (n == 0) return;
-    // memory-bound: cap the grid at 256 CUs x 8 workgroups and grid-stride the rest
-    const uint64_t want = (n + 255u) / 256u;
-    const uint32_t grid = static_cast<uint32_t>(want < 2048u ? want : 2048u);
-    hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, s, src, dst, n);
+// kind 0 copy / 1 read / 2 write; nt: non-temporal accesses; unroll: 4 or 8 independent 16-byte accesses per lane; grid: workgroups (0 = one per chunk)
+template <int kKind, bool kNt, uint32_t kU>
+static void stream_launch(hipStream_t s, uint32_t grid, const float4* src, float4* dst, uint64_t n) {
+    const uint64_t chunks = (n + 256ull * kU - 1) / (256ull * kU);
+    const uint32_t g = static_cast<uint32_t>(grid == 0u || chunks < grid ? std::min<uint64_t>(chunks, 0x7fffffffull) : grid);
+    hipLaunchKernelGGL((stream_kernel<kKind, kNt, kU>), dim3(g), dim3(256), 0, s, reinterpret_cast<const v4f*>(src), reinterpret_cast<v4f*>(dst), n, reinterpret_cast<v4f*>(dst));
 }
+void util_launch_stream(hipStream_t s, int kind, bool nt, uint32_t unroll, uint32_t grid, const float4* src, float4* dst, uint64_t n) {
+    if (n == 0) return;
+    switch (kind * 4 + (nt ? 2 : 0) + (unroll >= 8u ? 1 : 0)) {
+        case 0: stream_launch<0, false, 4>(s, grid, src, dst, n); break;
+        case 1: stream_launch<0, false, 8>(s, grid, src, dst, n); break;
+        case 2: stream_launch<0, true, 4>(s, grid, src, dst, n); break;
+        case 3: stream_launch<0, true, 8>(s, grid, src, dst, n); break;
+        case 4: stream_launch<1, false, 4>(s, grid, src, dst, n); break;
+        case 5: stream_launch<1, false, 8>(s, grid, src, dst, n); break;
+        case 6: stream_launch<1, true, 4>(s, grid, src, dst, n); break;
+        case 7: stream_launch<1, true, 8>(s, grid, src, dst, n); break;
+        case 8: stream_launch<2, false, 4>(s, grid, src, dst, n); break;
+        case 9: stream_launch<2, false, 8>(s, grid, src, dst, n); break;
+        case 10: stream_launch<2, true, 4>(s, grid, src, dst, n); break;
+        default: stream_launch<2, true, 8>(s, grid, src, dst, n); break;
+    }
+}
+void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n) { util_launch_stream(s, 0, false, 4u, 0u, src, dst, n); }
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n) {
     if (n == 0) return;
     hipLaunchKernelGGL(gather16_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, idx, dst, n);

@@ -410,6 +410,13 @@ def measure_copy_bandwidth(nbytes, reps=20, device=0):
     return g.value
 
 
+def measure_stream_bandwidth(nbytes, kind="copy", reps=20, device=0):
+    """GB/s of the tuned streaming probe (include/tetsim.h: tetsim_measure_stream_bandwidth): kind copy (read + write bytes), read, write."""
+    g = C.c_double()
+    capi.check(capi.lib().tetsim_measure_stream_bandwidth(device, int(nbytes), int(reps), {"copy": 0, "read": 1, "write": 2}[kind], C.byref(g)))
+    return g.value
+
+
 def group_step_n(bodies, n, dt, physicsParams):
     """n substeps of every partition of one decomposition (same choreography as the RCCL path, in-process copies)."""
     arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
