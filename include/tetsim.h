@@ -211,8 +211,11 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams *params);
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params);
 /* Block until everything enqueued on the handle's stream(s) has finished.  Partitioned bodies: TETSIM_ECOMM if a device-side
  * halo wait gave up (TETSIM_HALO_TIMEOUT_MS, 30 s by default: a stuck peer, or the two chains of a graph replay sharing one
- * hardware queue).  The substeps since then used stale data -- restore a checkpoint or stop; the body itself stays usable and
- * steps eagerly (no graph replay of the halo chains) from then on. */
+ * hardware queue).  The substeps since then used stale data.  A PARTITIONED body has no checkpoint to go back to
+ * (tetsim_save_state / tetsim_load_state take unpartitioned bodies only): rebuild the partitions of every rank from the last state
+ * the host holds (tetsim_read_positions / _velocities gathered over the ranks restart a trajectory only approximately -- the
+ * polar solver's per-tet state is lost) or stop.  The handle itself stays usable and steps eagerly (no graph replay of the halo
+ * chains) from then on. */
 int tetsim_sync(tetsim_handle h);
 
 /* --- state access (synchronising) ------------------------------------------------------------ */

@@ -399,7 +399,10 @@ def test_lattice_1m_two_partitions_match_monolithic():
         group_step_n(parts, 20, DT20, PP)
     ref = mono.pos
     for b in parts:
-        within("polar fast 1M two slabs vs monolithic @40", np.abs(b.pos - ref[b.ownedIds]).max(), 1e-4)
+        # (stated bound: 2x the 3.5e-5 m observed since the halo-side tets have tiles of their own -- thin interface-aligned tiles mean more
+        # partial sums per interface particle than the monolithic body's cube-shaped tiles, i.e. another summation order there; the
+        # calibrated table holds the run's own 3x)
+        within("polar fast 1M two slabs vs monolithic @40", np.abs(b.pos - ref[b.ownedIds]).max(), 7e-5)
 
 
 def test_lattice_8m_eight_slabs_match_monolithic():

@@ -180,6 +180,7 @@ struct tetsim_body {
     // persistent frame kernel (pjb_frame_kernel): tetsim_step_n runs ONE launch per call; fused bodies of few enough tiles
     bool frame = false;
     uint32_t frame_epoch = 1;         // sequence number of the next call's first substep (DevParams::epoch), advanced by 65536 per parameter push
+    uint32_t fold_wave_limit = 0, fold_tile_limit = 0;   // waves / workgroups that may wait in-kernel on this device (pjb_wait_capacity, at creation)
     bool quad = false;                // SMALL body: 64-tet tiles, one tet / one particle on four lanes (pj_quad.hip) -- tetsim_step runs pjq_tet + pjq_vertex,
                                       // tetsim_step_n the persistent pjq_frame_kernel (while `frame`); the three agree bit for bit
     uint32_t* d_frame_err = nullptr;  // raised by a tile whose neighbour's partial sums never arrived (bounded wait)

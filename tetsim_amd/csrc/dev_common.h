@@ -164,6 +164,8 @@ void pjq_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipE
 void pjq_launch_vertex(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 uint32_t pjq_frame_capacity(uint32_t* compute_units);              // workgroups of pjq_frame_kernel one CU keeps resident (0 = query failed)
 uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units);   // workgroups of the frame kernel one CU keeps resident (0 = query failed)
+// waves of the self-waiting particle kernel / workgroups of the self-waiting halo-side tiles that may wait at once on the current device
+void pjb_wait_capacity(bool lean, uint32_t* vertex_waves, uint32_t* hwait_blocks);
 uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks);            // 8 if block i of a grid runs on XCD i % 8, else 0
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores
 // 1 behind the producer kernel, wait spins until it is non-zero in front of the consumer kernel and clears it.  No per-launch

@@ -853,6 +853,23 @@ uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
     if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
     return static_cast<uint32_t>(per_cu);
 }
+// How many waiting workgroups the in-kernel hand-overs may put on the current device (tetsim_halo.hip: folded waits).  A wave that looks
+// at a word keeps its slot while it waits, and the kernel that raises the word needs slots too: the waiting kernels may hold HALF of
+// what the device keeps resident of pjb_vertex_kernel_await (one-wave workgroups) and a QUARTER of what it keeps of
+// pjb_tet_kernel_hwait -- measured limits, not constants: a compute partition with fewer CUs (or a kernel that grew) shrinks them.
+void pjb_wait_capacity(bool lean, uint32_t* vertex_waves, uint32_t* hwait_blocks) {
+    *vertex_waves = 0; *hwait_blocks = 0;
+    int per_cu_v = 0, per_cu_t = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, pjb_vertex_kernel_await, 64, 0) != hipSuccess) per_cu_v = 0;
+    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_constant_rest_hwait, static_cast<int>(kTile), 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_hwait, static_cast<int>(kTile), 0);
+    if (e != hipSuccess) per_cu_t = 0;
+    const uint32_t cus = static_cast<uint32_t>(std::max(prop.multiProcessorCount, 0));
+    *vertex_waves = static_cast<uint32_t>(std::max(per_cu_v, 0)) * cus / 2u;
+    *hwait_blocks = static_cast<uint32_t>(std::max(per_cu_t, 0)) * cus / 4u;
+}
 // 8 if block i of a grid runs on XCD i % 8 (whatever the XCDs' numbering) on this device, else 0: a grid of `blocks` one-wave
 // workgroups reports its XCC_ID register
 uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks) {

@@ -190,6 +190,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             // loses 1.7 us at +20 us, so there it stays off.  TETSIM_HALO_FOLD_WAIT=0 / 1: never / also with RCCL (development A/B).
             const char* fw = getenv("TETSIM_HALO_FOLD_WAIT");
             h->fold_possible = !(fw && fw[0] == '0') && h->partitioned && B.num_interior_blocks > 0 && B.num_interior_blocks < B.num_blocks && nvo > nvb;
+            if (h->fold_possible) pjb_wait_capacity((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0, &h->fold_wave_limit, &h->fold_tile_limit);
             h->fold_wait = h->fold_possible && fw && fw[0] == '1';
             h->fold_halo = h->fold_wait;   // (RCCL bodies: only when forced; the peer-to-peer connection switches both on)
         }

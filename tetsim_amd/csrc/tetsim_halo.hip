@@ -140,7 +140,7 @@ static void interior_particles(tetsim_body* h, const PJSync& yg, hipEvent_t* ev)
     // Waves that look at a word hold their slots while they wait, and the kernel that raises the word needs slots too: only one rank
     // per process (partitions of one process share the device: eight 1 M-tet slabs' particle kernels are 22,000 waves on 8,192 slots
     // -- they starved the boundary-particle kernels until the time-out), and only while the kernel is at most half the device's waves.
-    if (h->fold_wait && h->group.empty() && (cnt + 63u) / 64u <= 4096u) {
+    if (h->fold_wait && h->group.empty() && (cnt + 63u) / 64u <= h->fold_wave_limit) {
         HP("launch vertex interior (awaits G)");
         pjb_launch_vertex_await(h->stream, h->blk, nvb, cnt, yg, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
         return;
@@ -186,7 +186,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             if (v_open && h->blk.nb_interior) h->v_pending = false;
             else if ((rc = flush_v(h))) return rc;
             // (fold_wait: whoever raises V also puts G back -- the waves that looked at it belong to the kernel in front of this one)
-            const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - nvb + 63u) / 64u <= 4096u;   // (interior_particles' rule)
+            const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - nvb + 63u) / 64u <= h->fold_wave_limit;   // (interior_particles' rule)
             { HP("launch tet interior"); pjb_launch_tet(h->stream, h->blk, 0, h->blk.nb_interior, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr,
                                                        v_open && h->blk.nb_interior ? yv.flag : nullptr,
                                                        v_open && h->blk.nb_interior && g_folded ? yg.flag : nullptr); }
@@ -279,7 +279,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
                 if (!(v_open && h->blk.nb_interior)) yw.flag = nullptr;
                 // One rank per process with boundary particles (fold_halo): no wait kernel -- the halo-side tiles raise, look at V and
                 // at the neighbours' words themselves, and the boundary-particle kernel behind them puts those words back as it starts.
-                const bool fold = h->fold_halo && h->group.empty() && nvb != 0u && !h->needs_halo_refresh && nbnd <= 512u;   // (at most a quarter of the device's workgroup slots may wait)
+                const bool fold = h->fold_halo && h->group.empty() && nvb != 0u && !h->needs_halo_refresh && nbnd <= h->fold_tile_limit;   // (at most a quarter of the workgroups the device keeps resident may wait: pjb_wait_capacity)
                 if (!fold && (yw.flag || w.n_raise || w.n_wait)) { HP("wait V + peers"); pjb_launch_wait_peers(h->comm_stream, yw, w); }
                 if ((rc = halo_wait(h, h->comm_stream))) return rc;   // (a refresh exchange after a dt change, in-process groups)
                 kb.ghost_alt = h->ghost_alt;
@@ -314,7 +314,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             }
             // (RCCL, one rank per process, TETSIM_HALO_FOLD_WAIT=1: the halo-side tiles look at V themselves -- as the peer-to-peer branch
             // does by default -- and the boundary-particle kernel puts it back)
-            const bool fold_v = h->fold_halo && h->comm && h->group.empty() && nvb != 0u && v_open && h->blk.nb_interior && nbnd <= 512u;
+            const bool fold_v = h->fold_halo && h->comm && h->group.empty() && nvb != 0u && v_open && h->blk.nb_interior && nbnd <= h->fold_tile_limit;
             if (!fold_v && v_open && h->blk.nb_interior) { HP("wait V"); pjb_launch_wait(h->comm_stream, yv); }
             if ((rc = halo_wait(h, h->comm_stream))) return rc;   // in-process groups: the neighbours' transfers of the previous substep (events)
             if (fold_v) { HP("launch tet halo-side (awaits V)"); pjb_launch_tet_hwait(h->comm_stream, kb, h->blk.nb_interior, nbnd, yv, PJPeerSync(), h->pj.pos_pred + h->pj.nv_owned); }
@@ -367,7 +367,7 @@ int flush_v(tetsim_body* h) {   // the last substep's V hand-over as kernels of 
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));
     PJSync yv;
     yv.flag = h->d_sync + 2; yv.error = h->d_sync + 4; yv.timeout_ms = halo_timeout_ms(h);
-    const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - h->pj.nv_boundary + 63u) / 64u <= 4096u;   // (interior_particles' rule)
+    const bool g_folded = h->fold_wait && h->group.empty() && (h->pj.nv_owned - h->pj.nv_boundary + 63u) / 64u <= h->fold_wave_limit;   // (interior_particles' rule)
     if (h->v_pending) { HP("signal V"); pjb_launch_signal(h->stream, yv, g_folded ? h->d_sync + 0 : nullptr); }
     if (h->p2p) {   // ... and the "arrived" words of the last boundary-particle kernel, which no following substep's wait will raise
         PJPeerSync w;
@@ -442,9 +442,19 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
     if (it == h->flag_graphs.end()) {
         hipGraph_t gm = nullptr, gh = nullptr;
         hipGraphExec_t em = nullptr, eh = nullptr;
+        // The capture walks enqueue_phase_a / _b / flush_v, which advance the host's picture of the choreography (substep parity of the
+        // peer-to-peer buffers and words, pending raises and hand-overs) as if the substeps had RUN.  If the capture fails nothing has
+        // run: every error path below puts that picture back, so that the eager fallback (tetsim_step_n) starts from where the device
+        // really is -- an odd number of phantom substeps would make it read the wrong-parity ghost buffers and wait for words nobody raises.
+        struct Picture { uint64_t p2p_round; bool p2p_raise_pending, v_pending, halo_pending, fork_needed; uint32_t halo_parity; };
+        const Picture before = {h->p2p_round, h->p2p_raise_pending, h->v_pending, h->halo_pending, h->fork_needed, h->halo_parity};
+        auto undo = [&]() {
+            h->p2p_round = before.p2p_round; h->p2p_raise_pending = before.p2p_raise_pending; h->v_pending = before.v_pending;
+            h->halo_pending = before.halo_pending; h->fork_needed = before.fork_needed; h->halo_parity = before.halo_parity;
+        };
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipStreamBeginCapture(h->comm_stream, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) { (void)hipStreamEndCapture(h->stream, &gm); if (gm) (void)hipGraphDestroy(gm); return fail(h, TETSIM_EHIP, std::string("begin capture (halo stream): ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipStreamEndCapture(h->stream, &gm); if (gm) (void)hipGraphDestroy(gm); undo(); return fail(h, TETSIM_EHIP, std::string("begin capture (halo stream): ") + hipGetErrorString(e)); }
         int rc = 0;
         for (uint32_t i = 0; i < n && !rc; i++) {
             rc = enqueue_phase_a(h);
@@ -458,7 +468,7 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
         if (!rc && hipGraphInstantiate(&eh, gh, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, TETSIM_EHIP, "graph instantiate (halo chain) failed");
         if (gm) (void)hipGraphDestroy(gm);
         if (gh) (void)hipGraphDestroy(gh);
-        if (rc) { if (em) (void)hipGraphExecDestroy(em); if (eh) (void)hipGraphExecDestroy(eh); return rc; }
+        if (rc) { if (em) (void)hipGraphExecDestroy(em); if (eh) (void)hipGraphExecDestroy(eh); undo(); return rc; }
         it = h->flag_graphs.emplace(key, std::make_pair(em, eh)).first;
         if (h->p2p) h->p2p_round -= n;   // (the capture advanced the counter; the replay below is what runs)
     }

@@ -133,7 +133,16 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     }
     HIPCHK(h, hipMemset(h->d_arrived, 0, kArrivedWords * sizeof(uint32_t)));
     const char* all = static_cast<const char*>(blobs);
+    // a re-connect replaces the links: the IPC mappings of the previous connection are closed first (opening a handle that is still
+    // open can fail), and every error return below closes what this call has opened so far
+    for (PeerLink& l : h->links) for (void*& m : l.ipc) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+    h->links.clear();
+    h->p2p = false;
     std::vector<PeerLink> links(h->neigh.size());
+    struct CloseOnError {
+        std::vector<PeerLink>& v; bool armed = true;
+        ~CloseOnError() { if (armed) for (PeerLink& l : v) for (void*& m : l.ipc) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; } }
+    } guard{links};
     for (size_t k = 0; k < h->neigh.size(); k++) {
         const NeighDev& nb = h->neigh[k];
         P2PBlob pb;
@@ -151,6 +160,16 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
             for (uint32_t j = 0; j < pb.n_neigh && j < kMaxPeers; j++)
                 if (pb.neigh[j].rank == h->opt.part_index) { start = pb.neigh[j].recv_start; cnt = pb.neigh[j].recv_count; start2 = pb.neigh[j].recv2_start; cnt2 = pb.neigh[j].recv2_count; slot = j; }
         if (slot == kMaxPeers || cnt != nb.send_count || cnt2 != send2) return fail(h, TETSIM_ESTATE, "asymmetric halo plan between ranks " + std::to_string(h->opt.part_index) + " and " + std::to_string(nb.rank));
+        // The blob is another process's word: before the boundary-particle kernel stores into peer memory at start + i, the runs must lie
+        // inside the peer's ghost range as the peer itself describes it (a blob of another mesh or partition map with equal counts would
+        // otherwise write out of bounds), and a send-list position must fit the 24 bits PJPeer's slot words give it.
+        if (!h->loopback) {
+            const uint64_t pg = static_cast<uint64_t>(pb.nv_local) - pb.nv_owned, pg1 = h->deep ? pb.n_ghost1 : pg;
+            const bool ok1 = pb.nv_local >= pb.nv_owned && pg1 <= pg && (cnt == 0u || (start >= pb.nv_owned && static_cast<uint64_t>(start) + cnt <= pb.nv_owned + pg1));
+            const bool ok2 = cnt2 == 0u || (start2 >= pb.nv_owned + pg1 && static_cast<uint64_t>(start2) + cnt2 <= pb.nv_local);
+            if (!ok1 || !ok2) return fail(h, TETSIM_EINVAL, "bad peer blob for rank " + std::to_string(nb.rank) + ": this rank's run lies outside the peer's ghost range");
+        }
+        if (cnt >= (1u << 24) || cnt2 >= (1u << 24)) return fail(h, TETSIM_EINVAL, "a neighbour's send list has 2^24 particles or more: the peer-to-peer slot words cannot address it");
         float4 *pred = nullptr, *alt = nullptr;
         uint32_t* arr = nullptr;
         if (pb.pid == static_cast<uint64_t>(getpid())) {   // same process: plain pointers (peer access if the devices differ)
@@ -184,6 +203,7 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
         links[k].arrived[0] = arr + slot;
         links[k].arrived[1] = arr + kMaxPeers + slot;
     }
+    guard.armed = false;
     h->links = std::move(links);
     h->p2p = true;
     h->p2p_round = 0;
