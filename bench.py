@@ -49,16 +49,42 @@ VERTEX_BYTES = 144.0           # per particle per substep (integrate/accumulate/
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(verts, tets):
-    """Time the CPU restatement of the SAME algorithm (oracle section G) on this host by BASELINE.md 4.2's protocol: same
-    lattice, parameters and dt as the GPU run; 3 repetitions and their MEDIAN at 1 thread (like-for-like with the reference's
-    single JS thread), 16, 64 and all the threads this process may run on (OpenMP over tets / particles).  Every thread count is
-    reported (`by_threads`), `value` / `cores` name the fastest median.  Bounded to ~25 s of CPU work."""
-    from oracle import OraclePJ, set_threads
+def cpu_budget():
+    """What this process may actually use of the host: the CPUs it may be scheduled on (sched_getaffinity) and the cgroup's CPU-time quota
+    (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) in units of CPUs -- a container that SEES 256 hardware threads but is
+    throttled to 16 CPUs' worth of time gets slower, not faster, beyond 16 threads."""
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
+    quota, src = None, None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max":
+            quota, src = float(q) / float(period), "cgroup v2 cpu.max"
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0:
+                quota, src = q / period, "cgroup v1 cpu.cfs_quota_us"
+        except Exception:
+            pass
+    return avail, quota, src
+
+
+def cpu_baseline(verts, tets):
+    """Time the CPU restatement of the SAME algorithm (oracle section G) on this host by BASELINE.md 4.2's protocol: same
+    lattice, parameters and dt as the GPU run; 3 repetitions and their MEDIAN at 1 thread (like-for-like with the reference's
+    single JS thread), at the host's CPU BUDGET (the cgroup quota if there is one, else the CPUs the process may run on, capped at 64:
+    beyond one socket's worth of cores the port stops scaling), at half and at twice that (OpenMP over tets / particles).  Every
+    thread count is reported (`by_threads`), `value` / `cores` name the fastest median.  Bounded to ~25 s of CPU work."""
+    from oracle import OraclePJ, set_threads
+    avail, quota, quota_src = cpu_budget()
+    budget = max(1, min(avail, int(round(quota)) if quota else min(avail, 64)))
     o = OraclePJ(verts, tets, PP, slot_quirk=True)
     REPS = 3
 
@@ -80,10 +106,10 @@ def cpu_baseline(verts, tets):
         return {"median": round(rates[REPS // 2], 3), "min": round(rates[0], 3), "max": round(rates[-1], 3), "reps": REPS, "substeps_per_rep": n}
 
     by_threads = {}
-    for th, budget in ((1, 4.0), (16, 2.5), (64, 2.5), (avail, 3.0)):
+    for th, seconds in ((1, 4.0), (max(1, budget // 2), 2.5), (budget, 3.0), (min(avail, 2 * budget), 2.5)):
         th = min(th, avail)
         if str(th) not in by_threads:
-            by_threads[str(th)] = rate(th, budget)
+            by_threads[str(th)] = rate(th, seconds)
     set_threads(1)
     cores = max(by_threads, key=lambda k: by_threads[k]["median"])
     # the reference's own CPU solver is the sequential Neo-Hookean Gauss-Seidel of Softbody.js (BASELINE config 1); its
@@ -127,9 +153,11 @@ def cpu_baseline(verts, tets):
                                            "unit": "M tet-solves/s", "cores": 1, "kind": "port",
                                            "sample": "median of %d repetitions of 2 substeps of the same lattice, sequential Neo-Hookean Gauss-Seidel (oracle section A)" % REPS},
            "sample": "median of %d repetitions of %d substeps of the same %d-tet lattice, same parameters and dt as the GPU run (oracle/tetsim_oracle.c "
-                     "section G, gcc -O2 + OpenMP over tets/particles); every thread count of 1/16/64/all is in by_threads, value = the fastest median"
-                     % (REPS, best["substeps_per_rep"], len(tets)),
-           "value_1core": by_threads["1"]["median"], "host_cpus_available": avail}
+                     "section G, gcc -O2 + OpenMP over tets/particles); thread counts 1, half the CPU budget, the budget and twice the budget are in "
+                     "by_threads, value = the fastest median" % (REPS, best["substeps_per_rep"], len(tets)),
+           "value_1core": by_threads["1"]["median"], "host_cpus_available": avail,
+           "cpu_budget": {"cpus": budget, "cgroup_quota_cpus": round(quota, 2) if quota else None,
+                          "source": quota_src or ("no cgroup CPU quota: the CPUs this process may run on (sched_getaffinity)" + (", capped at 64" if avail > 64 else ""))}}
     try:
         with open("/proc/cpuinfo") as f:
             res["cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
