@@ -1,0 +1,255 @@
+"""One rank of the benchmark: the body, the timed region (W untimed + K timed frames bracketed by synchronise + barrier), the retry
+ladder of an N-rank run, and the JSON line with its roofline object."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .common import CELLS, DT, HBM_PEAK_GBS, PP, ROOT, SUBSTEPS, TET_KERNEL_BYTES, VERTEX_BYTES
+from .cpu import cpu_baseline
+from .body import make_body, timed_frames
+from .launcher import GUARD
+from .legs import beyond_mall, multi_gpu_report, other_configs, p2p_check, promote_p2p, run_neohookean
+
+
+# How an N-rank headline run may be repeated when a transport fails on the node it meets: each rung rebuilds every rank's body with
+# more conservative halo settings (the library reads them per body).  A rung is left only by a VOTE of all ranks, and every rank
+# runs the same collectives whether its local steps worked or not.
+HALO_LADDER = [({}, "flag-synchronised two-queue halo, both chains replayed from captured graphs (the default)"),
+               ({"TETSIM_HALO_GRAPH": "0"}, "the same halo path enqueued eagerly (no graph replay)"),
+               ({"TETSIM_HALO_SYNC": "events", "TETSIM_HALO_GRAPH": "0"}, "event-synchronised halo path, eager (round 1's)")]
+
+def headline_with_retries(args, cells, rank, world, local_rank, ranks):
+    """The timed region of an N-rank run (timed_frames' protocol: W untimed + K timed frames bracketed by synchronise + barrier), with
+    every local step caught and voted on; on a failure anywhere all ranks close their bodies and climb one rung of HALO_LADDER.
+    Returns (body, verts, tets, pp, nz, wall seconds of this rank, host seconds inside the K calls, [attempt records])."""
+    attempts = []
+    keys = sorted({k for env, _ in HALO_LADDER for k in env} | {"TETSIM_HALO_TIMEOUT_MS"})
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for rung, (env, what) in enumerate(HALO_LADDER):
+            for k in keys:
+                if k != "TETSIM_HALO_TIMEOUT_MS":
+                    os.environ.pop(k, None) if saved[k] is None else os.environ.__setitem__(k, saved[k])
+            os.environ.update(env)
+            if saved["TETSIM_HALO_TIMEOUT_MS"] is None:
+                os.environ["TETSIM_HALO_TIMEOUT_MS"] = "10000"   # a rank that waits in vain says so after 10 s, not 30
+            state = {"err": None}
+
+            def local(fn):
+                if state["err"] is None:
+                    try:
+                        return fn()
+                    except Exception as e:  # noqa: BLE001
+                        state["err"] = "rank %d: %r" % (rank, e)
+                return None
+
+            body, verts, tets, pp, nz, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True)
+            el = host = 0.0
+            if body is None:
+                state["err"] = err
+            else:
+                for _ in range(args.warmup):
+                    local(lambda: body.simulateSubsteps(SUBSTEPS, DT, pp))
+                local(body.sync)
+                ranks.barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    h0 = time.perf_counter()
+                    local(lambda: body.simulateSubsteps(SUBSTEPS, DT, pp))
+                    host += time.perf_counter() - h0
+                local(body.sync)
+                ranks.barrier()
+                el = time.perf_counter() - t0
+                fin = local(lambda: bool(np.isfinite(body.pos).all()))
+                if fin is False:
+                    state["err"] = "rank %d: non-finite positions after the timed region" % rank
+                if rung == 0 and os.environ.get("TETSIM_BENCH_TEST_FAIL_FIRST_RUNG") == str(rank) and not state["err"]:
+                    state["err"] = "rank %d: injected failure (test of the retry ladder)" % rank
+            ok = ranks.min_float(0.0 if state["err"] else 1.0) >= 1.0
+            attempts.append({"halo": what, "ok": ok} if ok or not state["err"] else {"halo": what, "ok": False, "error_rank%d" % rank: state["err"][:300]})
+            if ok:
+                return body, verts, tets, pp, nz, el, host, attempts
+            if rank == 0:
+                print("[bench] N-rank run failed with: %s -- %s" % (what, state["err"] or "an error on another rank"), file=sys.stderr)
+            if body is not None:
+                try:
+                    body.close()
+                except Exception:  # noqa: BLE001
+                    pass
+        raise SystemExit("the N-rank run failed with every halo setting: " + json.dumps(attempts))
+    finally:
+        for k in keys:
+            os.environ.pop(k, None) if saved[k] is None else os.environ.__setitem__(k, saved[k])
+
+def pmc_traffic(kname, kernel_sha):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) -- only if they were taken on
+    THIS kernel build (same kernel_sha); a stale figure is reported as null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        return t.get(kname, {}).get("hbm_bytes_per_launch") if t.get("kernel_sha") == kernel_sha else None
+    except Exception:
+        return None
+
+def run(args, rank, world, local_rank, ranks):
+    """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
+    barrier / max_float / min_float."""
+    use_dist = ranks is not None
+    from tetsim_amd import library_info, measure_copy_bandwidth
+
+    cells = args.cells
+    if args.solver == "neohookean":
+        if world > 1:
+            raise SystemExit("--solver neohookean is a single-GPU benchmark: Gauss-Seidel would need one halo per colour (replicas only)")
+        from tetsim_amd import make_lattice
+        verts, tets = make_lattice(cells)
+        out, body = run_neohookean(args, verts, tets, local_rank)
+        out["library"] = library_info()
+        return out, body
+    attempts = []
+    if use_dist and world > 1:
+        body, verts, tets, pp, nz, elapsed_local, host_local, attempts = headline_with_retries(args, cells, rank, world, local_rank, ranks)
+    else:
+        body, verts, tets, pp, nz, _ = make_body(args, cells, args.scaling, rank, world, local_rank, ranks)
+        # ---- timed region --------------------------------------------------------------------------------
+        elapsed_local, host_local = timed_frames(body, pp, args.steps, args.warmup, ranks)
+        if not np.isfinite(body.pos).all():
+            raise SystemExit("non-finite positions after the timed region")
+    nt_global = len(tets)
+    elapsed = ranks.max_float(elapsed_local) if use_dist else elapsed_local
+    mg = multi_gpu_report(body, world, elapsed_local, host_local, args.steps, ranks) if use_dist else None
+    if mg is not None and len(attempts) > 1:
+        mg["halo_attempts"] = attempts   # (the ones before the last failed: the headline was measured with the last one's settings)
+
+    lib = library_info()
+    out = None
+    if rank == 0:
+        value = nt_global * SUBSTEPS * args.steps / elapsed / 1e6
+        nv_global = len(verts)
+        out = {
+            "metric": "tet_solves_per_sec", "value": round(value, 1), "unit": "M tet-solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
+                                   "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
+                       "solver": "polar_jacobi", "arithmetic": args.precision,
+                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
+                       "rotation_exit": ("iteration 1: |omega| < 1e-9 (the reference's, SoftbodyGPU.js:131); correction iterations 2..9: |omega| < 1e-6 rad "
+                                         "(FAST default; other_configs.config3_reference_threshold has the same frames with 1e-9 throughout)") if args.precision == "fast"
+                                        else "|omega| < 1e-9 (the reference's, SoftbodyGPU.js:131)",
+                       "tets": nt_global, "particles": nv_global,
+                       "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
+            "library": lib,
+        }
+        if world == 1:
+            out["host_enqueue_us_per_substep"] = round(host_local / (args.steps * SUBSTEPS) * 1e6, 2)
+        if mg is not None:
+            out["multi_gpu"] = mg
+    # dominant kernel: its OWN begin/end HIP events (hipExtLaunchKernelGGL) on the handle's stream, inside the real
+    # tet -> particle -> tet ... sequence, 60 substeps right after the timed region (same kernels as the graph).  N > 1: every
+    # rank takes part (the substeps exchange halos as usual); rank 0 reports ITS interior tet kernel -- the boundary tiles run
+    # beside it on the halo stream.
+    pr = None
+    if world == 1 or (args.profile_ranks and args.precision == "fast"):
+        # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
+        # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
+        batches = sorted((body.profile(SUBSTEPS * 3, DT, pp) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])
+        pr = batches[1]
+        body.sync()
+        if use_dist:
+            ranks.barrier()
+    tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)   # constant rest shape: read only, never written back
+    b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
+    if rank == 0 and pr is not None:
+        tet_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
+        vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3 if pr["vertex_launches"] else 0.0
+        units = pr["tets_per_tet_launch"]
+        kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
+        if body.info.fused_particle_pass:   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
+            kname, tet_bytes = "pjb_tet_fused_kernel", b_alg
+        achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
+        traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
+        out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
+                           "alg_bytes_per_launch": tet_bytes * units,
+                           "substep_alg_bytes_per_tet": round(b_alg, 1),
+                           "substep_achieved": round(b_alg * out["value"] * 1e6 / 1e9, 1),
+                           "substep_frac": round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+        if world == 1:
+            # SURVEY.md 8(d) "bounding roofline": the peak is also MEASURED on this box -- a device copy at the footprint class of
+            # the 1 M-tet working set (fits the 256 MB Infinity Cache) and at 1 GiB (streams from HBM)
+            # (the tuned probe of tetsim_measure_stream_bandwidth: four independent 16-byte accesses per lane, plain / non-temporal and the
+            # grid size chosen at first use; read-only and write-only rates beside the copy rate)
+            from tetsim_amd import measure_stream_bandwidth
+            cp = {"64MiB": round(measure_copy_bandwidth(64 << 20, 20), 0), "1GiB": round(measure_copy_bandwidth(1 << 30, 10), 0)}
+            out["roofline"]["measured_copy_peak"] = cp
+            out["roofline"]["measured_stream_peak_1GiB"] = {"read": round(measure_stream_bandwidth(1 << 30, "read", 10), 0),
+                                                            "write": round(measure_stream_bandwidth(1 << 30, "write", 10), 0), "unit": "GB/s"}
+            out["roofline"]["frac_of_measured_peak"] = {"kernel_vs_64MiB_copy": round(achieved / cp["64MiB"], 4),
+                                                        "kernel_vs_1GiB_copy": round(achieved / cp["1GiB"], 4),
+                                                        "substep_vs_64MiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["64MiB"], 4),
+                                                        "substep_vs_1GiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["1GiB"], 4)}
+    def whole_job_roofline():
+        # N > 1 without --profile-ranks: the whole-job figure only (no extra GPU work after the timed region)
+        agg = b_alg * out["value"] * 1e6 / 1e9
+        return {"bound": "hbm", "kernel": "whole substep, all ranks (tet + particle kernels)", "achieved": round(agg, 1),
+                "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(agg / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                "substep_alg_bytes_per_tet": round(b_alg, 1)}
+    if rank == 0 and pr is None:
+        out["roofline"] = whole_job_roofline()
+    # ---- optional legs of an N-rank run: nothing below may cost the headline (HeadlineGuard) ------------------------------------
+    if use_dist and world > 1:
+        GUARD.arm(out, int(os.environ.get("TETSIM_BENCH_OPTIONAL_S", "240")), "the legs after the headline (peer-to-peer halo check / config 5)")
+    if use_dist and world > 1 and args.halo == "rccl" and (args.p2p_check == "on" or (args.p2p_check == "auto" and not args.fake_ranks)):
+        try:
+            pos_rccl = body.pos
+        except Exception:  # noqa: BLE001
+            pos_rccl = None
+        res = p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global)
+        if rank == 0:
+            out["multi_gpu"]["p2p_halo"] = res
+            if promote_p2p(out, res, args.steps, world, args.headline_halo):
+                if pr is None:
+                    out["roofline"] = whole_job_roofline()
+                else:
+                    out["roofline"]["substep_achieved"] = round(b_alg * out["value"] * 1e6 / 1e9, 1)
+                    out["roofline"]["substep_frac"] = round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)
+    # ---- BASELINE config 5, literally: the 110^3-cell lattice (7,986,000 tets) cut into N slabs -- strong scaling -----------
+    if use_dist and (args.config5 == "on" or (args.config5 == "auto" and world == 8)) and not (args.scaling == "strong" and cells == args.config5_cells):
+        # (the headline body stays alive: if this second body cannot be built on some rank, the line above is still reported)
+        body5, v5, t5, pp5, _, err5 = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks, vote=True)
+        if body5 is None:
+            if rank == 0:
+                out["config5_strong"] = {"error": err5}
+        else:
+            body.close()
+            body = body5
+            steps5 = max(1, min(args.steps, 10))
+            e5_local, h5_local = timed_frames(body, pp5, steps5, min(args.warmup, 2), ranks)
+            e5 = ranks.max_float(e5_local)
+            finite = ranks.min_float(1.0 if np.isfinite(body.pos).all() else 0.0)
+            mg5 = multi_gpu_report(body, world, e5_local, h5_local, steps5, ranks)
+            if rank == 0:
+                v = len(t5) * SUBSTEPS * steps5 / e5 / 1e6
+                out["config5_strong"] = {
+                    "workload": "Kuhn-6 cube lattice %d^3 cells (%d tets, %d particles) cut into %d z-slabs, %d-particle interface planes, "
+                                "polar-decomposition Jacobi, %d substeps/frame" % (args.config5_cells, len(t5), len(v5), world, (args.config5_cells + 1) ** 2, SUBSTEPS),
+                    "scaling": "strong", "value": round(v, 1), "unit": "M tet-solves/s", "steps": steps5, "ms_per_step": round(e5 / steps5 * 1e3, 4),
+                    "finite": bool(finite), "multi_gpu": mg5,
+                    "substep_frac_of_hbm_roofline": round(b_alg * v * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
+    GUARD.disarm()
+    if world == 1:
+        body.close()
+        if not args.no_beyond_mall and args.precision == "fast" and cells == CELLS and args.solver == "polar" and "roofline" in out:
+            out["roofline"]["beyond_mall"] = beyond_mall(args, local_rank, out["roofline"].get("measured_copy_peak", {}))
+        if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
+            out["other_configs"] = other_configs(args.steps, args.warmup)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(verts, tets)
+    return out, body
