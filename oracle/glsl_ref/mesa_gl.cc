@@ -1,22 +1,24 @@
 // mesa_gl.cc -- TEST INFRASTRUCTURE (golden-vector generation only; never loaded by the product or by any test).
 //
-// A minimal headless OpenGL ES 3.0 binding for Node (N-API) on top of Mesa's software rasteriser (swrast_dri.so: softpipe is what the goldens are recorded with; llvmpipe was rejected, see tests/golden/make_golden_gpu.sh), so that
-// the REFERENCE's own GLSL passes (SoftbodyGPU.js:59-376) and its own pass scheduler
-// (MultiTargetGPUComputationRenderer.js) can be executed in the build container, which has no GPU, no X server and
-// no EGL: the context is created straight through the DRI software-rasteriser interface that libGLX/libEGL use
+// A headless OpenGL ES 3.0 context for Node (N-API) on Mesa's software rasteriser (swrast_dri.so: softpipe is what the goldens are
+// recorded with; llvmpipe was rejected, see tests/golden/make_golden_gpu.sh), exposed as RAW GL ES entry points.  On top of it
+// webgl2_context.mjs provides a WebGL2RenderingContext-shaped object, and the reference's vendored, unmodified
+// THREE.WebGLRenderer({canvas, context}) drives it: the reference's GLSL passes (SoftbodyGPU.js:59-376), its pass scheduler
+// (MultiTargetGPUComputationRenderer.js) AND three.js's own renderer all run as they are in the build container, which has no GPU, no
+// X server and no EGL.  The context is created straight through the DRI software-rasteriser interface that libGLX / libEGL use
 // internally (swrast_dri.so, <GL/internal/dri_interface.h>, both shipped in the image).
 //
-// It exposes exactly what a full-screen-quad "render to float texture" pass needs:
-//   init() createTexture() uploadTexture() createProgram() activeUniforms() draw() readTexture()
-// headless_renderer.mjs builds the subset of THREE.WebGLRenderer the reference calls on top of these.
+// Nothing here knows about the simulation, three.js or WebGL: `call` invokes any GL entry point whose arguments are integers / floats,
+// the rest are thin marshalling wrappers for the entry points that take pointers (strings, typed arrays, out-parameters).
 //
-// build: oracle/glsl_ref/build.sh  ->  oracle/_ref/mesa_gl.node   (git-ignored)
+// build: oracle/glsl_ref/build.sh  ->  oracle/_ref/mesa_gl.node + oracle/_ref/gl_constants.json   (git-ignored)
 #include <node_api.h>
 
 #include <dlfcn.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -36,64 +38,17 @@ const __DRIswrastLoaderExtension g_loader = {{__DRI_SWRAST_LOADER, 1}, getDrawab
 void* (*g_gpa)(const char*) = nullptr;
 bool g_ready = false;
 std::string g_err;
+std::map<std::string, void*> g_fn;
 
-#define GLFN(ret, name, ...) ret (*name)(__VA_ARGS__) = nullptr
-GLFN(const GLubyte*, pGetString, GLenum);
-GLFN(GLenum, pGetError, void);
-GLFN(void, pGenTextures, GLsizei, GLuint*);
-GLFN(void, pBindTexture, GLenum, GLuint);
-GLFN(void, pTexParameteri, GLenum, GLenum, GLint);
-GLFN(void, pTexImage2D, GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void*);
-GLFN(void, pTexSubImage2D, GLenum, GLint, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, const void*);
-GLFN(void, pPixelStorei, GLenum, GLint);
-GLFN(void, pActiveTexture, GLenum);
-GLFN(void, pGenFramebuffers, GLsizei, GLuint*);
-GLFN(void, pBindFramebuffer, GLenum, GLuint);
-GLFN(void, pFramebufferTexture2D, GLenum, GLenum, GLenum, GLuint, GLint);
-GLFN(GLenum, pCheckFramebufferStatus, GLenum);
-GLFN(void, pDrawBuffers, GLsizei, const GLenum*);
-GLFN(void, pReadBuffer, GLenum);
-GLFN(void, pReadPixels, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void*);
-GLFN(void, pViewport, GLint, GLint, GLsizei, GLsizei);
-GLFN(void, pDisable, GLenum);
-GLFN(void, pClearColor, GLfloat, GLfloat, GLfloat, GLfloat);
-GLFN(void, pClear, GLbitfield);
-GLFN(GLuint, pCreateShader, GLenum);
-GLFN(void, pShaderSource, GLuint, GLsizei, const char* const*, const GLint*);
-GLFN(void, pCompileShader, GLuint);
-GLFN(void, pGetShaderiv, GLuint, GLenum, GLint*);
-GLFN(void, pGetShaderInfoLog, GLuint, GLsizei, GLsizei*, char*);
-GLFN(GLuint, pCreateProgram, void);
-GLFN(void, pAttachShader, GLuint, GLuint);
-GLFN(void, pBindAttribLocation, GLuint, GLuint, const char*);
-GLFN(void, pLinkProgram, GLuint);
-GLFN(void, pGetProgramiv, GLuint, GLenum, GLint*);
-GLFN(void, pGetProgramInfoLog, GLuint, GLsizei, GLsizei*, char*);
-GLFN(void, pUseProgram, GLuint);
-GLFN(void, pGetActiveUniform, GLuint, GLuint, GLsizei, GLsizei*, GLint*, GLenum*, char*);
-GLFN(GLint, pGetUniformLocation, GLuint, const char*);
-GLFN(void, pUniform1fv, GLint, GLsizei, const GLfloat*);
-GLFN(void, pUniform2fv, GLint, GLsizei, const GLfloat*);
-GLFN(void, pUniform3fv, GLint, GLsizei, const GLfloat*);
-GLFN(void, pUniform4fv, GLint, GLsizei, const GLfloat*);
-GLFN(void, pUniform1iv, GLint, GLsizei, const GLint*);
-GLFN(void, pUniformMatrix4fv, GLint, GLsizei, GLboolean, const GLfloat*);
-GLFN(void, pGenBuffers, GLsizei, GLuint*);
-GLFN(void, pBindBuffer, GLenum, GLuint);
-GLFN(void, pBufferData, GLenum, GLsizeiptr, const void*, GLenum);
-GLFN(void, pGenVertexArrays, GLsizei, GLuint*);
-GLFN(void, pBindVertexArray, GLuint);
-GLFN(void, pEnableVertexAttribArray, GLuint);
-GLFN(void, pVertexAttribPointer, GLuint, GLint, GLenum, GLboolean, GLsizei, const void*);
-GLFN(void, pDrawElements, GLenum, GLsizei, GLenum, const void*);
-GLFN(void, pFinish, void);
-
-template <typename T>
-bool load(T& fn, const char* name) {
-    fn = reinterpret_cast<T>(g_gpa(name));
-    if (!fn) g_err = std::string("GL entry point missing: ") + name;
-    return fn != nullptr;
+void* gl(const char* name) {
+    auto it = g_fn.find(name);
+    if (it != g_fn.end()) return it->second;
+    void* p = g_gpa ? g_gpa(name) : nullptr;
+    g_fn.emplace(name, p);
+    return p;
 }
+template <typename T>
+T glfn(const char* name) { return reinterpret_cast<T>(gl(name)); }
 
 bool gl_init() {
     if (g_ready) return true;
@@ -125,300 +80,336 @@ bool gl_init() {
     if (!ga) { g_err = std::string("cannot load libglapi.so.0: ") + dlerror(); return false; }
     g_gpa = reinterpret_cast<void* (*)(const char*)>(dlsym(ga, "_glapi_get_proc_address"));
     if (!g_gpa) { g_err = "_glapi_get_proc_address missing"; return false; }
-    bool ok = load(pGetString, "glGetString") && load(pGetError, "glGetError") && load(pGenTextures, "glGenTextures") &&
-              load(pBindTexture, "glBindTexture") && load(pTexParameteri, "glTexParameteri") && load(pTexImage2D, "glTexImage2D") &&
-              load(pTexSubImage2D, "glTexSubImage2D") && load(pPixelStorei, "glPixelStorei") && load(pActiveTexture, "glActiveTexture") &&
-              load(pGenFramebuffers, "glGenFramebuffers") && load(pBindFramebuffer, "glBindFramebuffer") &&
-              load(pFramebufferTexture2D, "glFramebufferTexture2D") && load(pCheckFramebufferStatus, "glCheckFramebufferStatus") &&
-              load(pDrawBuffers, "glDrawBuffers") && load(pReadBuffer, "glReadBuffer") && load(pReadPixels, "glReadPixels") &&
-              load(pViewport, "glViewport") && load(pDisable, "glDisable") && load(pClearColor, "glClearColor") && load(pClear, "glClear") &&
-              load(pCreateShader, "glCreateShader") && load(pShaderSource, "glShaderSource") && load(pCompileShader, "glCompileShader") &&
-              load(pGetShaderiv, "glGetShaderiv") && load(pGetShaderInfoLog, "glGetShaderInfoLog") && load(pCreateProgram, "glCreateProgram") &&
-              load(pAttachShader, "glAttachShader") && load(pBindAttribLocation, "glBindAttribLocation") && load(pLinkProgram, "glLinkProgram") &&
-              load(pGetProgramiv, "glGetProgramiv") && load(pGetProgramInfoLog, "glGetProgramInfoLog") && load(pUseProgram, "glUseProgram") &&
-              load(pGetActiveUniform, "glGetActiveUniform") && load(pGetUniformLocation, "glGetUniformLocation") &&
-              load(pUniform1fv, "glUniform1fv") && load(pUniform2fv, "glUniform2fv") && load(pUniform3fv, "glUniform3fv") &&
-              load(pUniform4fv, "glUniform4fv") && load(pUniform1iv, "glUniform1iv") && load(pUniformMatrix4fv, "glUniformMatrix4fv") &&
-              load(pGenBuffers, "glGenBuffers") && load(pBindBuffer, "glBindBuffer") && load(pBufferData, "glBufferData") &&
-              load(pGenVertexArrays, "glGenVertexArrays") && load(pBindVertexArray, "glBindVertexArray") &&
-              load(pEnableVertexAttribArray, "glEnableVertexAttribArray") && load(pVertexAttribPointer, "glVertexAttribPointer") &&
-              load(pDrawElements, "glDrawElements") && load(pFinish, "glFinish");
-    if (!ok) return false;
-    const char* ext = reinterpret_cast<const char*>(pGetString(GL_EXTENSIONS));
+    auto getString = glfn<const GLubyte* (*)(GLenum)>("glGetString");
+    if (!getString) { g_err = "glGetString missing"; return false; }
+    const char* ext = reinterpret_cast<const char*>(getString(GL_EXTENSIONS));
     if (!ext || !strstr(ext, "GL_EXT_color_buffer_float")) { g_err = "GL_EXT_color_buffer_float missing (float render targets)"; return false; }
     g_ready = true;
     return true;
 }
 
 // ---- N-API helpers -------------------------------------------------------------------------------------------
-#define NAPI_OK(call) do { if ((call) != napi_ok) { napi_throw_error(env, "MESA_GL", "N-API call failed: " #call); return nullptr; } } while (0)
 napi_value fail(napi_env env, const std::string& m) { napi_throw_error(env, "MESA_GL", m.c_str()); return nullptr; }
-
-bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
-    size_t argc = want;
-    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) {
-        napi_throw_error(env, "MESA_GL", "wrong number of arguments");
-        return false;
-    }
+constexpr size_t kMaxArgs = 12;
+struct Args {
+    napi_value v[kMaxArgs];
+    size_t n = kMaxArgs;
+    bool ok;
+    Args(napi_env env, napi_callback_info info, size_t want) { ok = napi_get_cb_info(env, info, &n, v, nullptr, nullptr) == napi_ok && n >= want; if (!ok) napi_throw_error(env, "MESA_GL", "wrong number of arguments"); }
+};
+bool get_i64(napi_env env, napi_value v, int64_t* out) {
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok) { bool b; if (napi_get_value_bool(env, v, &b) != napi_ok) return false; d = b ? 1.0 : 0.0; }
+    *out = static_cast<int64_t>(d);
     return true;
 }
-bool get_u32(napi_env env, napi_value v, uint32_t* out) { return napi_get_value_uint32(env, v, out) == napi_ok; }
 bool get_str(napi_env env, napi_value v, std::string* out) {
     size_t n = 0;
     if (napi_get_value_string_utf8(env, v, nullptr, 0, &n) != napi_ok) return false;
     out->resize(n);
     return napi_get_value_string_utf8(env, v, &(*out)[0], n + 1, &n) == napi_ok;
 }
-// typed array -> pointer + element count; *type receives the napi_typedarray_type
-bool get_typed(napi_env env, napi_value v, napi_typedarray_type* type, void** data, size_t* len) {
+// typed array / DataView-free: pointer + byte length, or null for null / undefined
+bool get_bytes(napi_env env, napi_value v, void** data, size_t* bytes) {
+    *data = nullptr; *bytes = 0;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return false;
+    if (t == napi_null || t == napi_undefined) return true;
     bool is = false;
     if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return false;
-    napi_value ab; size_t off;
-    return napi_get_typedarray_info(env, v, type, len, data, &ab, &off) == napi_ok;
+    napi_typedarray_type ty; size_t len; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, v, &ty, &len, data, &ab, &off) != napi_ok) return false;
+    static const size_t width[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+    *bytes = len * width[ty];
+    return true;
 }
-napi_value mk_u32(napi_env env, uint32_t x) { napi_value v; napi_create_uint32(env, x, &v); return v; }
+napi_value mk_num(napi_env env, double x) { napi_value v; napi_create_double(env, x, &v); return v; }
 napi_value mk_str(napi_env env, const char* s) { napi_value v; napi_create_string_utf8(env, s ? s : "", NAPI_AUTO_LENGTH, &v); return v; }
-
-GLuint g_fbo = 0, g_vao = 0, g_vbo = 0, g_ibo = 0;
+#define NEED_GL() do { if (!g_ready) return fail(env, "init() first"); } while (0)
+#define FN(var, type, name) auto var = glfn<type>(name); if (!var) return fail(env, std::string("GL entry point missing: ") + name)
 
 // ---- exported functions --------------------------------------------------------------------------------------
 napi_value Init(napi_env env, napi_callback_info) {
     if (!gl_init()) return fail(env, g_err);
-    napi_value o; NAPI_OK(napi_create_object(env, &o));
-    napi_set_named_property(env, o, "vendor", mk_str(env, reinterpret_cast<const char*>(pGetString(GL_VENDOR))));
-    napi_set_named_property(env, o, "renderer", mk_str(env, reinterpret_cast<const char*>(pGetString(GL_RENDERER))));
-    napi_set_named_property(env, o, "version", mk_str(env, reinterpret_cast<const char*>(pGetString(GL_VERSION))));
-    napi_set_named_property(env, o, "glsl", mk_str(env, reinterpret_cast<const char*>(pGetString(GL_SHADING_LANGUAGE_VERSION))));
+    auto getString = glfn<const GLubyte* (*)(GLenum)>("glGetString");
+    napi_value o; napi_create_object(env, &o);
+    napi_set_named_property(env, o, "vendor", mk_str(env, reinterpret_cast<const char*>(getString(GL_VENDOR))));
+    napi_set_named_property(env, o, "renderer", mk_str(env, reinterpret_cast<const char*>(getString(GL_RENDERER))));
+    napi_set_named_property(env, o, "version", mk_str(env, reinterpret_cast<const char*>(getString(GL_VERSION))));
+    napi_set_named_property(env, o, "glsl", mk_str(env, reinterpret_cast<const char*>(getString(GL_SHADING_LANGUAGE_VERSION))));
     return o;
 }
 
-// createTexture(w, h, Float32Array | null) -> id     RGBA32F, NEAREST, CLAMP_TO_EDGE (DataTexture / render-target settings
-// of MultiTargetGPUComputationRenderer.js:140-143,353-371,400-403)
-napi_value CreateTexture(napi_env env, napi_callback_info info) {
-    napi_value a[3];
-    if (!get_args(env, info, 3, a)) return nullptr;
-    if (!g_ready) return fail(env, "init() first");
-    uint32_t w, h;
-    if (!get_u32(env, a[0], &w) || !get_u32(env, a[1], &h)) return fail(env, "createTexture(w, h, data)");
-    napi_typedarray_type t; void* data = nullptr; size_t len = 0;
-    if (get_typed(env, a[2], &t, &data, &len)) {
-        if (t != napi_float32_array || len != static_cast<size_t>(w) * h * 4) return fail(env, "data must be a Float32Array of w*h*4");
-    } else data = nullptr;
-    GLuint tex = 0;
-    pGenTextures(1, &tex);
-    pBindTexture(GL_TEXTURE_2D, tex);
-    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
-    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
-    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
-    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
-    pPixelStorei(GL_UNPACK_ALIGNMENT, 1);
-    pTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, data);
-    if (GLenum e = pGetError()) return fail(env, "glTexImage2D error " + std::to_string(e));
-    return mk_u32(env, tex);
+// call(name, [ints...], [floats...]) -> integer result.  Any entry point whose parameters are integers (enums, names, sizes, booleans,
+// byte offsets passed as pointers) and at most four floats; on x86-64 integers and floats travel in separate registers, each class in
+// order, and a callee ignores what it does not declare.
+napi_value Call(napi_env env, napi_callback_info info) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string name;
+    if (!get_str(env, a.v[0], &name)) return fail(env, "call(name, ints, floats)");
+    void* p = gl(name.c_str());
+    if (!p) return fail(env, "GL entry point missing: " + name);
+    intptr_t iv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float fv[4] = {0, 0, 0, 0};
+    uint32_t ni = 0, nf = 0;
+    if (napi_get_array_length(env, a.v[1], &ni) != napi_ok || ni > 10) return fail(env, "call: at most ten integer arguments");
+    for (uint32_t i = 0; i < ni; i++) { napi_value e; int64_t x; napi_get_element(env, a.v[1], i, &e); if (!get_i64(env, e, &x)) return fail(env, "call " + name + ": integer argument expected"); iv[i] = static_cast<intptr_t>(x); }
+    if (a.n > 2) {
+        if (napi_get_array_length(env, a.v[2], &nf) != napi_ok || nf > 4) return fail(env, "call: at most four float arguments");
+        for (uint32_t i = 0; i < nf; i++) { napi_value e; double x; napi_get_element(env, a.v[2], i, &e); if (napi_get_value_double(env, e, &x) != napi_ok) return fail(env, "call " + name + ": float argument expected"); fv[i] = static_cast<float>(x); }
+    }
+    using Fn = intptr_t (*)(intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, float, float, float, float);
+    const intptr_t r = reinterpret_cast<Fn>(p)(iv[0], iv[1], iv[2], iv[3], iv[4], iv[5], iv[6], iv[7], iv[8], iv[9], fv[0], fv[1], fv[2], fv[3]);
+    return mk_num(env, static_cast<double>(static_cast<uint32_t>(r)));   // (every integer-returning entry point returns 32 bits)
 }
 
-napi_value UploadTexture(napi_env env, napi_callback_info info) {
-    napi_value a[4];
-    if (!get_args(env, info, 4, a)) return nullptr;
-    uint32_t tex, w, h;
-    napi_typedarray_type t; void* data; size_t len;
-    if (!get_u32(env, a[0], &tex) || !get_u32(env, a[1], &w) || !get_u32(env, a[2], &h) || !get_typed(env, a[3], &t, &data, &len) ||
-        t != napi_float32_array || len != static_cast<size_t>(w) * h * 4)
-        return fail(env, "uploadTexture(id, w, h, Float32Array)");
-    pBindTexture(GL_TEXTURE_2D, tex);
-    pPixelStorei(GL_UNPACK_ALIGNMENT, 1);
-    pTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, w, h, GL_RGBA, GL_FLOAT, data);
-    if (GLenum e = pGetError()) return fail(env, "glTexSubImage2D error " + std::to_string(e));
+// gen(kind) -> name;  kind: "Textures" | "Buffers" | "Framebuffers" | "Renderbuffers" | "VertexArrays" | "Samplers" | "Queries"
+napi_value Gen(napi_env env, napi_callback_info info) {
+    Args a(env, info, 1);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind;
+    if (!get_str(env, a.v[0], &kind)) return fail(env, "gen(kind)");
+    FN(f, void (*)(GLsizei, GLuint*), ("glGen" + kind).c_str());
+    GLuint id = 0;
+    f(1, &id);
+    return mk_num(env, id);
+}
+napi_value Del(napi_env env, napi_callback_info info) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind; int64_t id;
+    if (!get_str(env, a.v[0], &kind) || !get_i64(env, a.v[1], &id)) return fail(env, "del(kind, name)");
+    FN(f, void (*)(GLsizei, const GLuint*), ("glDelete" + kind).c_str());
+    const GLuint u = static_cast<GLuint>(id);
+    f(1, &u);
     return nullptr;
 }
-
-GLuint compile(GLenum kind, const std::string& src, std::string* log) {
-    GLuint s = pCreateShader(kind);
-    const char* p = src.c_str();
-    pShaderSource(s, 1, &p, nullptr);
-    pCompileShader(s);
-    GLint ok = 0;
-    pGetShaderiv(s, GL_COMPILE_STATUS, &ok);
-    if (!ok) {
-        char buf[8192]; GLsizei n = 0;
-        pGetShaderInfoLog(s, sizeof buf, &n, buf);
-        *log = std::string(kind == GL_VERTEX_SHADER ? "vertex" : "fragment") + " shader: " + std::string(buf, n);
-        return 0;
-    }
-    return s;
+napi_value GetString(napi_env env, napi_callback_info info) {
+    Args a(env, info, 1);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t pname, index = -1;
+    if (!get_i64(env, a.v[0], &pname)) return fail(env, "getString(pname[, index])");
+    if (a.n > 1) get_i64(env, a.v[1], &index);
+    if (index >= 0) { FN(f, const GLubyte* (*)(GLenum, GLuint), "glGetStringi"); return mk_str(env, reinterpret_cast<const char*>(f(pname, index))); }
+    FN(f, const GLubyte* (*)(GLenum), "glGetString");
+    return mk_str(env, reinterpret_cast<const char*>(f(pname)));
 }
-
-// createProgram(vertexGlsl, fragmentGlsl) -> id;  attribute 0 is "position" (three binds index0AttributeName the same way)
-napi_value CreateProgram(napi_env env, napi_callback_info info) {
-    napi_value a[2];
-    if (!get_args(env, info, 2, a)) return nullptr;
-    if (!g_ready) return fail(env, "init() first");
-    std::string vs, fs, log;
-    if (!get_str(env, a[0], &vs) || !get_str(env, a[1], &fs)) return fail(env, "createProgram(vs, fs)");
-    GLuint v = compile(GL_VERTEX_SHADER, vs, &log);
-    if (!v) return fail(env, log);
-    GLuint f = compile(GL_FRAGMENT_SHADER, fs, &log);
-    if (!f) return fail(env, log);
-    GLuint p = pCreateProgram();
-    pAttachShader(p, v);
-    pAttachShader(p, f);
-    pBindAttribLocation(p, 0, "position");
-    pLinkProgram(p);
-    GLint ok = 0;
-    pGetProgramiv(p, GL_LINK_STATUS, &ok);
-    if (!ok) {
-        char buf[8192]; GLsizei n = 0;
-        pGetProgramInfoLog(p, sizeof buf, &n, buf);
-        return fail(env, "link: " + std::string(buf, n));
-    }
-    return mk_u32(env, p);
-}
-
-// activeUniforms(program) -> [{name, type, size}]   (type is the GL enum, e.g. 0x1406 FLOAT, 0x8B5E SAMPLER_2D)
-napi_value ActiveUniforms(napi_env env, napi_callback_info info) {
-    napi_value a[1];
-    if (!get_args(env, info, 1, a)) return nullptr;
-    uint32_t p;
-    if (!get_u32(env, a[0], &p)) return fail(env, "activeUniforms(program)");
-    GLint n = 0;
-    pGetProgramiv(p, GL_ACTIVE_UNIFORMS, &n);
-    napi_value arr; NAPI_OK(napi_create_array_with_length(env, n, &arr));
-    for (GLint i = 0; i < n; i++) {
-        char name[256]; GLsizei len = 0; GLint size = 0; GLenum type = 0;
-        pGetActiveUniform(p, i, sizeof name, &len, &size, &type, name);
-        napi_value o; NAPI_OK(napi_create_object(env, &o));
-        napi_set_named_property(env, o, "name", mk_str(env, name));
-        napi_set_named_property(env, o, "type", mk_u32(env, type));
-        napi_set_named_property(env, o, "size", mk_u32(env, size));
-        napi_set_element(env, arr, i, o);
-    }
+// getIntegerv(pname, count) / getFloatv(pname, count) -> [numbers]
+template <typename T>
+napi_value GetV(napi_env env, napi_callback_info info, const char* entry) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t pname, count;
+    if (!get_i64(env, a.v[0], &pname) || !get_i64(env, a.v[1], &count) || count < 1 || count > 16) return fail(env, "getv(pname, count)");
+    FN(f, void (*)(GLenum, T*), entry);
+    T out[16] = {};
+    f(pname, out);
+    napi_value arr; napi_create_array_with_length(env, count, &arr);
+    for (int64_t i = 0; i < count; i++) napi_set_element(env, arr, i, mk_num(env, out[i]));
     return arr;
 }
+napi_value GetIntegerv(napi_env env, napi_callback_info info) { return GetV<GLint>(env, info, "glGetIntegerv"); }
+napi_value GetFloatv(napi_env env, napi_callback_info info) { return GetV<GLfloat>(env, info, "glGetFloatv"); }
 
-// draw({program, width, height, targets: [texId...], clear: [r,g,b,a] | null,
-//       uniforms: [{name, kind: 'f1'|'f2'|'f3'|'f4'|'i1'|'m4'|'tex', data: Float32Array|Int32Array|Uint32Array(texture ids)}],
-//       position: Float32Array(xyz...), index: Uint32Array})
-napi_value Draw(napi_env env, napi_callback_info info) {
-    napi_value a[1];
-    if (!get_args(env, info, 1, a)) return nullptr;
-    if (!g_ready) return fail(env, "init() first");
-    napi_value v;
-    uint32_t prog, w, h;
-    if (napi_get_named_property(env, a[0], "program", &v) != napi_ok || !get_u32(env, v, &prog)) return fail(env, "draw: program");
-    if (napi_get_named_property(env, a[0], "width", &v) != napi_ok || !get_u32(env, v, &w)) return fail(env, "draw: width");
-    if (napi_get_named_property(env, a[0], "height", &v) != napi_ok || !get_u32(env, v, &h)) return fail(env, "draw: height");
-
-    if (!g_fbo) { pGenFramebuffers(1, &g_fbo); pGenVertexArrays(1, &g_vao); pGenBuffers(1, &g_vbo); pGenBuffers(1, &g_ibo); }
-    pBindFramebuffer(GL_FRAMEBUFFER, g_fbo);
-    napi_value targets;
-    uint32_t nt = 0;
-    if (napi_get_named_property(env, a[0], "targets", &targets) != napi_ok || napi_get_array_length(env, targets, &nt) != napi_ok || nt < 1 || nt > 8)
-        return fail(env, "draw: targets");
-    GLenum bufs[8];
-    for (uint32_t i = 0; i < 8; i++) {
-        uint32_t tex = 0;
-        if (i < nt) { napi_value e; napi_get_element(env, targets, i, &e); if (!get_u32(env, e, &tex)) return fail(env, "draw: target id"); }
-        pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0 + i, GL_TEXTURE_2D, tex, 0);
-        bufs[i] = GL_COLOR_ATTACHMENT0 + i;
-    }
-    if (pCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail(env, "draw: framebuffer incomplete");
-    pDrawBuffers(nt, bufs);
-    pViewport(0, 0, w, h);
-    pDisable(GL_BLEND); pDisable(GL_DEPTH_TEST); pDisable(GL_CULL_FACE); pDisable(GL_SCISSOR_TEST); pDisable(GL_DITHER);
-
-    napi_value clear; napi_valuetype vt;
-    if (napi_get_named_property(env, a[0], "clear", &clear) == napi_ok && napi_typeof(env, clear, &vt) == napi_ok && vt == napi_object) {
-        double c[4] = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < 4; i++) { napi_value e; napi_get_element(env, clear, i, &e); napi_get_value_double(env, e, &c[i]); }
-        pClearColor(c[0], c[1], c[2], c[3]);
-        pClear(GL_COLOR_BUFFER_BIT);
-    }
-
-    pUseProgram(prog);
-    napi_value uniforms; uint32_t nu = 0;
-    if (napi_get_named_property(env, a[0], "uniforms", &uniforms) != napi_ok || napi_get_array_length(env, uniforms, &nu) != napi_ok) return fail(env, "draw: uniforms");
-    GLint unit = 0;
-    for (uint32_t i = 0; i < nu; i++) {
-        napi_value u, nv, kv, dv; std::string name, kind;
-        napi_get_element(env, uniforms, i, &u);
-        if (napi_get_named_property(env, u, "name", &nv) != napi_ok || !get_str(env, nv, &name) ||
-            napi_get_named_property(env, u, "kind", &kv) != napi_ok || !get_str(env, kv, &kind) ||
-            napi_get_named_property(env, u, "data", &dv) != napi_ok) return fail(env, "draw: uniform entry");
-        napi_typedarray_type t; void* data; size_t len;
-        if (!get_typed(env, dv, &t, &data, &len)) return fail(env, "draw: uniform data must be a typed array: " + name);
-        const GLint loc = pGetUniformLocation(prog, name.c_str());
-        if (loc < 0) return fail(env, "draw: no such active uniform: " + name);
-        if (kind == "tex") {
-            if (t != napi_uint32_array) return fail(env, "draw: tex uniform wants Uint32Array ids: " + name);
-            std::vector<GLint> units(len);
-            for (size_t k = 0; k < len; k++) {
-                pActiveTexture(GL_TEXTURE0 + unit);
-                pBindTexture(GL_TEXTURE_2D, static_cast<const uint32_t*>(data)[k]);
-                units[k] = unit++;
-            }
-            pUniform1iv(loc, static_cast<GLsizei>(len), units.data());
-        } else if (kind == "i1") {
-            if (t != napi_int32_array) return fail(env, "draw: i1 wants Int32Array: " + name);
-            pUniform1iv(loc, static_cast<GLsizei>(len), static_cast<const GLint*>(data));
-        } else {
-            if (t != napi_float32_array) return fail(env, "draw: float uniform wants Float32Array: " + name);
-            const GLfloat* f = static_cast<const GLfloat*>(data);
-            if (kind == "f1") pUniform1fv(loc, static_cast<GLsizei>(len), f);
-            else if (kind == "f2") pUniform2fv(loc, static_cast<GLsizei>(len / 2), f);
-            else if (kind == "f3") pUniform3fv(loc, static_cast<GLsizei>(len / 3), f);
-            else if (kind == "f4") pUniform4fv(loc, static_cast<GLsizei>(len / 4), f);
-            else if (kind == "m4") pUniformMatrix4fv(loc, static_cast<GLsizei>(len / 16), GL_FALSE, f);
-            else return fail(env, "draw: unknown uniform kind " + kind);
-        }
-    }
-
-    napi_value pv, iv; napi_typedarray_type t; void* pos; size_t npos; void* idx; size_t nidx;
-    if (napi_get_named_property(env, a[0], "position", &pv) != napi_ok || !get_typed(env, pv, &t, &pos, &npos) || t != napi_float32_array) return fail(env, "draw: position");
-    if (napi_get_named_property(env, a[0], "index", &iv) != napi_ok || !get_typed(env, iv, &t, &idx, &nidx) || t != napi_uint32_array) return fail(env, "draw: index");
-    pBindVertexArray(g_vao);
-    pBindBuffer(GL_ARRAY_BUFFER, g_vbo);
-    pBufferData(GL_ARRAY_BUFFER, npos * sizeof(float), pos, GL_STREAM_DRAW);
-    pEnableVertexAttribArray(0);
-    pVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 0, nullptr);
-    pBindBuffer(GL_ELEMENT_ARRAY_BUFFER, g_ibo);
-    pBufferData(GL_ELEMENT_ARRAY_BUFFER, nidx * sizeof(uint32_t), idx, GL_STREAM_DRAW);
-    pDrawElements(GL_TRIANGLES, static_cast<GLsizei>(nidx), GL_UNSIGNED_INT, nullptr);
-    pFinish();
-    if (GLenum e = pGetError()) return fail(env, "draw: GL error " + std::to_string(e));
-    for (uint32_t i = 0; i < nt; i++) pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0 + i, GL_TEXTURE_2D, 0, 0);
+napi_value ShaderSource(napi_env env, napi_callback_info info) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t id; std::string src;
+    if (!get_i64(env, a.v[0], &id) || !get_str(env, a.v[1], &src)) return fail(env, "shaderSource(shader, text)");
+    FN(f, void (*)(GLuint, GLsizei, const char* const*, const GLint*), "glShaderSource");
+    const char* p = src.c_str();
+    f(id, 1, &p, nullptr);
     return nullptr;
 }
-
-// readTexture(id, x, y, w, h, Float32Array out)
-napi_value ReadTexture(napi_env env, napi_callback_info info) {
-    napi_value a[6];
-    if (!get_args(env, info, 6, a)) return nullptr;
-    uint32_t tex, x, y, w, h;
-    napi_typedarray_type t; void* data; size_t len;
-    if (!get_u32(env, a[0], &tex) || !get_u32(env, a[1], &x) || !get_u32(env, a[2], &y) || !get_u32(env, a[3], &w) || !get_u32(env, a[4], &h) ||
-        !get_typed(env, a[5], &t, &data, &len) || t != napi_float32_array || len < static_cast<size_t>(w) * h * 4)
-        return fail(env, "readTexture(id, x, y, w, h, Float32Array)");
-    if (!g_fbo) { pGenFramebuffers(1, &g_fbo); pGenVertexArrays(1, &g_vao); pGenBuffers(1, &g_vbo); pGenBuffers(1, &g_ibo); }
-    pBindFramebuffer(GL_FRAMEBUFFER, g_fbo);
-    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex, 0);
-    if (pCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail(env, "readTexture: framebuffer incomplete");
-    pReadBuffer(GL_COLOR_ATTACHMENT0);
-    pPixelStorei(GL_PACK_ALIGNMENT, 1);
-    pReadPixels(x, y, w, h, GL_RGBA, GL_FLOAT, data);
-    if (GLenum e = pGetError()) return fail(env, "readTexture: GL error " + std::to_string(e));
-    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, 0, 0);
+// objectiv("Shader" | "Program", name, pname) -> integer
+napi_value Objectiv(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind; int64_t id, pname;
+    if (!get_str(env, a.v[0], &kind) || !get_i64(env, a.v[1], &id) || !get_i64(env, a.v[2], &pname)) return fail(env, "objectiv(kind, name, pname)");
+    FN(f, void (*)(GLuint, GLenum, GLint*), ("glGet" + kind + "iv").c_str());
+    GLint v = 0;
+    f(id, pname, &v);
+    return mk_num(env, v);
+}
+napi_value InfoLog(napi_env env, napi_callback_info info) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind; int64_t id;
+    if (!get_str(env, a.v[0], &kind) || !get_i64(env, a.v[1], &id)) return fail(env, "infoLog(kind, name)");
+    FN(f, void (*)(GLuint, GLsizei, GLsizei*, char*), ("glGet" + kind + "InfoLog").c_str());
+    std::vector<char> buf(16384);
+    GLsizei n = 0;
+    f(id, static_cast<GLsizei>(buf.size()), &n, buf.data());
+    return mk_str(env, std::string(buf.data(), n).c_str());
+}
+// active("Uniform" | "Attrib", program, index) -> {name, type, size}
+napi_value Active(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind; int64_t prog, index;
+    if (!get_str(env, a.v[0], &kind) || !get_i64(env, a.v[1], &prog) || !get_i64(env, a.v[2], &index)) return fail(env, "active(kind, program, index)");
+    FN(f, void (*)(GLuint, GLuint, GLsizei, GLsizei*, GLint*, GLenum*, char*), ("glGetActive" + kind).c_str());
+    char name[512]; GLsizei len = 0; GLint size = 0; GLenum type = 0;
+    f(prog, index, sizeof name, &len, &size, &type, name);
+    napi_value o; napi_create_object(env, &o);
+    napi_set_named_property(env, o, "name", mk_str(env, std::string(name, len).c_str()));
+    napi_set_named_property(env, o, "type", mk_num(env, type));
+    napi_set_named_property(env, o, "size", mk_num(env, size));
+    return o;
+}
+// location("Uniform" | "Attrib", program, name) -> integer (-1: none)
+napi_value Location(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string kind, name; int64_t prog;
+    if (!get_str(env, a.v[0], &kind) || !get_i64(env, a.v[1], &prog) || !get_str(env, a.v[2], &name)) return fail(env, "location(kind, program, name)");
+    FN(f, GLint (*)(GLuint, const char*), ("glGet" + kind + "Location").c_str());
+    return mk_num(env, f(prog, name.c_str()));
+}
+napi_value BindAttribLocation(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t prog, index; std::string name;
+    if (!get_i64(env, a.v[0], &prog) || !get_i64(env, a.v[1], &index) || !get_str(env, a.v[2], &name)) return fail(env, "bindAttribLocation(program, index, name)");
+    FN(f, void (*)(GLuint, GLuint, const char*), "glBindAttribLocation");
+    f(prog, index, name.c_str());
+    return nullptr;
+}
+napi_value ShaderPrecisionFormat(napi_env env, napi_callback_info info) {
+    Args a(env, info, 2);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t st, pt;
+    if (!get_i64(env, a.v[0], &st) || !get_i64(env, a.v[1], &pt)) return fail(env, "shaderPrecisionFormat(shadertype, precisiontype)");
+    FN(f, void (*)(GLenum, GLenum, GLint*, GLint*), "glGetShaderPrecisionFormat");
+    GLint range[2] = {0, 0}, prec = 0;
+    f(st, pt, range, &prec);
+    napi_value arr; napi_create_array_with_length(env, 3, &arr);
+    napi_set_element(env, arr, 0, mk_num(env, range[0])); napi_set_element(env, arr, 1, mk_num(env, range[1])); napi_set_element(env, arr, 2, mk_num(env, prec));
+    return arr;
+}
+// texImage("glTexImage2D" | "glTexSubImage2D" | "glTexImage3D" | "glTexSubImage3D", [integer arguments in GL order without the pointer], data | null)
+napi_value TexImage(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string name; uint32_t ni = 0;
+    if (!get_str(env, a.v[0], &name) || napi_get_array_length(env, a.v[1], &ni) != napi_ok || ni > 10) return fail(env, "texImage(entry, ints, data)");
+    intptr_t iv[10] = {};
+    for (uint32_t i = 0; i < ni; i++) { napi_value e; int64_t x; napi_get_element(env, a.v[1], i, &e); if (!get_i64(env, e, &x)) return fail(env, "texImage: integer expected"); iv[i] = static_cast<intptr_t>(x); }
+    void* data; size_t bytes;
+    if (!get_bytes(env, a.v[2], &data, &bytes)) return fail(env, "texImage: data must be a typed array or null");
+    void* p = gl(name.c_str());
+    if (!p) return fail(env, "GL entry point missing: " + name);
+    if (ni == 8) reinterpret_cast<void (*)(intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, const void*)>(p)(iv[0], iv[1], iv[2], iv[3], iv[4], iv[5], iv[6], iv[7], data);
+    else if (ni == 9) reinterpret_cast<void (*)(intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, const void*)>(p)(iv[0], iv[1], iv[2], iv[3], iv[4], iv[5], iv[6], iv[7], iv[8], data);
+    else if (ni == 10) reinterpret_cast<void (*)(intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, const void*)>(p)(iv[0], iv[1], iv[2], iv[3], iv[4], iv[5], iv[6], iv[7], iv[8], iv[9], data);
+    else return fail(env, "texImage: 8, 9 or 10 integer arguments");
+    return nullptr;
+}
+// bufferData(target, typedArray | byteSize, usage);  bufferSubData(target, byteOffset, typedArray)
+napi_value BufferData(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t target, usage, size = 0;
+    void* data; size_t bytes;
+    if (!get_i64(env, a.v[0], &target) || !get_i64(env, a.v[2], &usage)) return fail(env, "bufferData(target, data | size, usage)");
+    if (!get_bytes(env, a.v[1], &data, &bytes)) { if (!get_i64(env, a.v[1], &size)) return fail(env, "bufferData: data"); bytes = static_cast<size_t>(size); data = nullptr; }
+    FN(f, void (*)(GLenum, GLsizeiptr, const void*, GLenum), "glBufferData");
+    f(target, static_cast<GLsizeiptr>(bytes), data, usage);
+    return nullptr;
+}
+napi_value BufferSubData(napi_env env, napi_callback_info info) {
+    Args a(env, info, 3);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t target, offset;
+    void* data; size_t bytes;
+    if (!get_i64(env, a.v[0], &target) || !get_i64(env, a.v[1], &offset) || !get_bytes(env, a.v[2], &data, &bytes) || !data) return fail(env, "bufferSubData(target, offset, data)");
+    FN(f, void (*)(GLenum, GLintptr, GLsizeiptr, const void*), "glBufferSubData");
+    f(target, offset, static_cast<GLsizeiptr>(bytes), data);
+    return nullptr;
+}
+// uniformv(entry, location, count, typedArray[, transpose]): glUniform{1234}{fi}v / glUniformMatrix{234}fv
+napi_value Uniformv(napi_env env, napi_callback_info info) {
+    Args a(env, info, 4);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    std::string name; int64_t loc, count, transpose = 0;
+    void* data; size_t bytes;
+    if (!get_str(env, a.v[0], &name) || !get_i64(env, a.v[1], &loc) || !get_i64(env, a.v[2], &count) || !get_bytes(env, a.v[3], &data, &bytes) || !data) return fail(env, "uniformv(entry, location, count, data[, transpose])");
+    void* p = gl(name.c_str());
+    if (!p) return fail(env, "GL entry point missing: " + name);
+    if (name.find("Matrix") != std::string::npos) {
+        if (a.n > 4) get_i64(env, a.v[4], &transpose);
+        reinterpret_cast<void (*)(GLint, GLsizei, GLboolean, const void*)>(p)(loc, count, transpose != 0, data);
+    } else reinterpret_cast<void (*)(GLint, GLsizei, const void*)>(p)(loc, count, data);
+    return nullptr;
+}
+napi_value DrawBuffers(napi_env env, napi_callback_info info) {
+    Args a(env, info, 1);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    uint32_t n = 0;
+    if (napi_get_array_length(env, a.v[0], &n) != napi_ok || n > 16) return fail(env, "drawBuffers([enums])");
+    GLenum bufs[16];
+    for (uint32_t i = 0; i < n; i++) { napi_value e; int64_t x; napi_get_element(env, a.v[0], i, &e); if (!get_i64(env, e, &x)) return fail(env, "drawBuffers: enum expected"); bufs[i] = static_cast<GLenum>(x); }
+    FN(f, void (*)(GLsizei, const GLenum*), "glDrawBuffers");
+    f(n, bufs);
+    return nullptr;
+}
+// readPixels(x, y, w, h, format, type, typedArray)
+napi_value ReadPixels(napi_env env, napi_callback_info info) {
+    Args a(env, info, 7);
+    if (!a.ok) return nullptr;
+    NEED_GL();
+    int64_t v[6];
+    for (int i = 0; i < 6; i++) if (!get_i64(env, a.v[i], &v[i])) return fail(env, "readPixels(x, y, w, h, format, type, data)");
+    void* data; size_t bytes;
+    if (!get_bytes(env, a.v[6], &data, &bytes) || !data) return fail(env, "readPixels: data must be a typed array");
+    const size_t texel = (v[5] == GL_FLOAT ? 4u : v[5] == GL_UNSIGNED_BYTE ? 1u : 0u) * (v[4] == GL_RGBA ? 4u : v[4] == GL_RGB ? 3u : v[4] == GL_RED ? 1u : 0u);
+    if (texel == 0 || bytes < static_cast<size_t>(v[2]) * static_cast<size_t>(v[3]) * texel) return fail(env, "readPixels: buffer too small or format not handled");
+    FN(f, void (*)(GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void*), "glReadPixels");
+    f(v[0], v[1], v[2], v[3], v[4], v[5], data);
     return nullptr;
 }
 
 napi_value ModuleInit(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"createTexture", nullptr, CreateTexture, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"uploadTexture", nullptr, UploadTexture, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"createProgram", nullptr, CreateProgram, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"activeUniforms", nullptr, ActiveUniforms, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"draw", nullptr, Draw, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"readTexture", nullptr, ReadTexture, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"call", nullptr, Call, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"gen", nullptr, Gen, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"del", nullptr, Del, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"getString", nullptr, GetString, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"getIntegerv", nullptr, GetIntegerv, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"getFloatv", nullptr, GetFloatv, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"shaderSource", nullptr, ShaderSource, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"objectiv", nullptr, Objectiv, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"infoLog", nullptr, InfoLog, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"active", nullptr, Active, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"location", nullptr, Location, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bindAttribLocation", nullptr, BindAttribLocation, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"shaderPrecisionFormat", nullptr, ShaderPrecisionFormat, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"texImage", nullptr, TexImage, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bufferData", nullptr, BufferData, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bufferSubData", nullptr, BufferSubData, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"uniformv", nullptr, Uniformv, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"drawBuffers", nullptr, DrawBuffers, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"readPixels", nullptr, ReadPixels, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

@@ -1,11 +1,12 @@
 // Golden-vector generator for the polar-decomposition (WebGL) solver: imports the REFERENCE SoftBodyGPU from a scratch
-// copy, gives it a headless renderer whose GL is Mesa softpipe (oracle/glsl_ref), and records texturePos / textureVel /
-// textureQuat after the substeps listed in cases_gpu.json.  Only data is written to the repo.
+// copy and gives it what the reference's own World.js gives it in the browser -- a THREE.WebGLRenderer, the reference's vendored,
+// unmodified one -- created on a WebGL2 context whose GL is Mesa softpipe (oracle/glsl_ref: webgl2_context.mjs over mesa_gl.cc), and
+// records texturePos / textureVel / textureQuat after the substeps listed in cases_gpu.json.  Only data is written to the repo.
 // usage: node make_golden_gpu.mjs <scratch-dir-with-reference> <output-dir> <mesa_gl.node>
 import fs from 'fs';
 import path from 'path';
 import crypto from 'crypto';
-import { makeHeadlessRenderer } from '../../oracle/glsl_ref/headless_renderer.mjs';
+import { createWebGL2Context } from '../../oracle/glsl_ref/webgl2_context.mjs';
 
 const [scratch, outDir, addon] = process.argv.slice(2);
 const sha = a => crypto.createHash('sha256').update(Buffer.from(a.buffer, a.byteOffset, a.byteLength)).digest('hex').slice(0, 16);
@@ -16,11 +17,12 @@ const readI32 = name => { const b = fs.readFileSync(path.join(outDir, name)); re
 async function main() {
     const THREE = await import(path.join(scratch, 'node_modules/three/build/three.module.js'));
     const { SoftBodyGPU } = await import(path.join(scratch, 'src/SoftbodyGPU.js'));
-    const renderer = makeHeadlessRenderer(THREE, addon);
-    console.log('GL:', JSON.stringify(renderer.info));
+    const ctx = createWebGL2Context(addon);
+    const renderer = new THREE.WebGLRenderer({ canvas: ctx.canvas, context: ctx.gl });   // three r160's own renderer (SoftbodyGPU.js:9 takes world.renderer)
+    console.log('GL:', JSON.stringify(ctx.info), ' renderer: THREE.WebGLRenderer r' + THREE.REVISION, 'isWebGL2', renderer.capabilities.isWebGL2);
 
     const cases = JSON.parse(fs.readFileSync(path.join(outDir, 'cases_gpu.json')));
-    const golden = { generator: 'tests/golden/make_golden_gpu.mjs', node: process.version, three: THREE.REVISION, gl: renderer.info, cases: {} };
+    const golden = { generator: 'tests/golden/make_golden_gpu.mjs', node: process.version, three: THREE.REVISION, gl: ctx.info, cases: {} };
     const quietLog = console.log;
     for (const c of cases) {
         const verts = readF32(c.mesh + '_verts.f32');
@@ -33,13 +35,13 @@ async function main() {
         const nv = body.numParticles, nt = body.numElems, dim = body.texDim;
         const texel = new Float32Array(dim * dim * 4);
         const grab3 = (variable, n) => {   // xyz of the first n texels of the variable's CURRENT target
-            renderer.readTargetAttachment(body.gpuCompute.getCurrentRenderTarget(variable), 0, texel);
+            renderer.readRenderTargetPixels(body.gpuCompute.getCurrentRenderTarget(variable), 0, 0, dim, dim, texel);   // as readToCPU, SoftbodyGPU.js:649-668
             const out = new Float32Array(3 * n);
             for (let i = 0; i < n; i++) { out[3 * i] = texel[4 * i]; out[3 * i + 1] = texel[4 * i + 1]; out[3 * i + 2] = texel[4 * i + 2]; }
             return out;
         };
         const grab4 = (variable, n) => {
-            renderer.readTargetAttachment(body.gpuCompute.getCurrentRenderTarget(variable), 0, texel);
+            renderer.readRenderTargetPixels(body.gpuCompute.getCurrentRenderTarget(variable), 0, 0, dim, dim, texel);
             return texel.slice(0, 4 * n);
         };
 
@@ -86,7 +88,7 @@ async function main() {
             }
         }
         golden.cases[c.name] = out;
-        console.log(c.name, JSON.stringify(out.steps[Object.keys(out.steps).pop()]), 'draws', renderer.stats.draws);
+        console.log(c.name, JSON.stringify(out.steps[Object.keys(out.steps).pop()]), 'draws', ctx.stats.draws);
     }
     fs.writeFileSync(path.join(outDir, 'golden_gpu.json'), JSON.stringify(golden, null, 1));
 }
