@@ -65,7 +65,6 @@ struct PJBlk {
     const float* wsum = nullptr;             // per owned particle: sum of V over all its entries -- constant, summed on the host in the device's order
     const uint32_t* vp_ell = nullptr;        // ELL [vp_cols][nv_pad]: partial-sum indices of each owned particle,
     uint32_t vp_cols = 0, nv_pad = 0;        //   ascending tile, 0xffffffff = none
-    const uint8_t* vp_wave_cols = nullptr;   // [nv_pad / 64 + 1] longest list among particles [64 w, 64 w + 64): the ELL columns a wave has to read
     float4* pos_pred = nullptr;
     float4* pos_final = nullptr;
     float4* vel = nullptr;

@@ -678,23 +678,11 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
     // do on the lattice (up to 9 partials; 18 particles have 9), where 4 columns made every wave pay three trips.
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t* col = d.vp_ell + v;
-    // (the columns THIS wave needs: the longest list among its 64 particles, two scalar byte loads -- a wave may straddle two of the
-    // table's runs; the host orders the particles so that most waves need 1-3 of the up to 9 columns, tetsim_create.hip)
-    const uint32_t w0 = first + blockIdx.x * 64u;
-    // (read through the CONSTANT address space, i.e. with scalar loads from the scalar cache: as ordinary byte loads they were a vector
-    // memory trip of their own in front of the index loads, +2.3 us on a kernel of 5.8)
-    uint32_t cols = d.vp_cols;
-    if (d.vp_wave_cols) {
-        typedef const __attribute__((address_space(4))) uint32_t* const_u32;
-        const const_u32 tab = reinterpret_cast<const_u32>(reinterpret_cast<uintptr_t>(d.vp_wave_cols));
-        const uint32_t wa = w0 >> 6, wb = (w0 + 63u) >> 6;
-        cols = max((tab[wa >> 2] >> ((wa & 3u) * 8u)) & 0xffu, (tab[wb >> 2] >> ((wb & 3u) * 8u)) & 0xffu);
-    }
-    for (uint32_t j0 = 0; j0 < cols; j0 += 8u) {
+    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 8u) {
         uint32_t idx[8];
         float4 g[8];
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
+        for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) {
             if constexpr (kCoherent) { const float4 t = load_coherent(d.partial, idx[j] != 0xffffffffu ? idx[j] : 0u); g[j] = idx[j] != 0xffffffffu ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }

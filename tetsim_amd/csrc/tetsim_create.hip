@@ -69,55 +69,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
         for (auto& id : ltets) id = static_cast<int32_t>(h->api2dev[id]);
     }
-    // Tet classes of a partition (host_prep.h: build_blocks): the tets that touch a boundary or a ghost particle get tiles of their own
-    // (class 1), and so do the second-layer ghost tets of a two-layer ghost region (class 2).  TETSIM_HALO_ALIGNED_TILES=0: the round-2
-    // tiling, where every tile that reaches the interface is halo-side (A/B).  Which corners are boundary / ghost particles does not
-    // depend on how the interior is numbered, so the classes are computed once, here.
-    std::vector<uint8_t> tet_class;
-    if (h->partitioned) {
-        const char* e = getenv("TETSIM_HALO_ALIGNED_TILES");
-        const bool aligned = !(e && e[0] == '0');
-        tet_class.assign(ntl, 0);
-        for (uint32_t i = 0; i < ntl; i++) {
-            if (h->deep && h->part.tet_layer[i]) { tet_class[i] = 2; continue; }
-            if (!aligned) continue;
-            for (int c = 0; c < 4; c++) {
-                const uint32_t v = static_cast<uint32_t>(ltets[4ull * i + c]);
-                if (v < nvb || v >= nvo) tet_class[i] = 1;
-            }
-        }
-    }
-    // Large blocked bodies (the two-kernel substep): the particle kernel reads, per particle, the ELL list of its 1..9 tile partial sums,
-    // eight columns per wave whatever the wave needs -- 32 B of indices per particle of which 12 B are entries.  With particles in plain
-    // Morton order nearly every wave of 64 holds a tile-corner particle (8-9 entries), so trimming the columns to the wave's longest
-    // list buys nothing; here the interior particles are re-ordered INSIDE every run of 1,024 Morton-consecutive particles by the
-    // length of their list (a stable sort: locality stays within 16 KB of each array), which makes the waves homogeneous -- most read
-    // 1-3 columns (PJBlk::vp_wave_cols).  Neither the tiles nor the order of any sum change: results are the same bit for bit.
-    // TETSIM_VERTEX_ORDER=0: plain Morton order (A/B).
-    static const bool allow_vorder = [] { const char* e = getenv("TETSIM_VERTEX_ORDER"); return !(e && e[0] == '0'); }();
-    if (allow_vorder && h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION) && !batch && ntl >= 2048u * kBlockTile / 2u && nvo > nvb) {
-        std::vector<float> lvd(3ull * nvl);
-        for (uint32_t i = 0; i < nvl; i++) {
-            const uint32_t a = h->dev2api[i], g = h->partitioned ? static_cast<uint32_t>(l2g_v[a]) : a;
-            lvd[3 * i] = verts[3 * g]; lvd[3 * i + 1] = verts[3 * g + 1]; lvd[3 * i + 2] = verts[3 * g + 2];
-        }
-        const Incidence inc0 = build_incidence(ltets.data(), ntl, nvl, false, false);
-        BlockPlan B0;
-        build_blocks(lvd.data(), ltets.data(), ntl, nvl, nvo + nvg1, inc0, &B0, nullptr, nullptr, 1, nvb, h->partitioned ? tet_class.data() : nullptr, nvo);
-        if (h->partitioned || B0.num_blocks >= 2048u) {
-            std::vector<uint32_t> order(nvl);   // new device index -> old device index
-            for (uint32_t i = 0; i < nvl; i++) order[i] = i;
-            for (uint32_t b0 = nvb; b0 < nvo; b0 += 1024u) {
-                const uint32_t b1 = std::min(nvo, b0 + 1024u);
-                std::stable_sort(order.begin() + b0, order.begin() + b1, [&](uint32_t x, uint32_t y) { return B0.vp_off[x + 1] - B0.vp_off[x] < B0.vp_off[y + 1] - B0.vp_off[y]; });
-            }
-            std::vector<uint32_t> old2new(nvl), d2a(nvl);
-            for (uint32_t i = 0; i < nvl; i++) { old2new[order[i]] = i; d2a[i] = h->dev2api[order[i]]; }
-            h->dev2api.swap(d2a);
-            for (uint32_t dv = 0; dv < nvl; dv++) h->api2dev[h->dev2api[dv]] = dv;
-            for (auto& id : ltets) id = static_cast<int32_t>(old2new[id]);
-        }
-    }
     // incidence (which (tet, corner) contributions each particle sums).  The reference's `<= 0.0` quirk drops the contribution of
     // ITS tet 0 / corner 0: in a batch that is every body's own first tet, so the table is built body by body.
     Incidence inc;
@@ -186,6 +137,23 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
     if (h->blocked) {
         BlockPlan B;
+        // partitions: the tets that touch a boundary or a ghost particle get tiles of their own (class 1), and so do the second-layer
+        // ghost tets of a two-layer ghost region (class 2) -- host_prep.h.  TETSIM_HALO_ALIGNED_TILES=0 (read here): the round-2 tiling,
+        // where every tile that reaches the interface is halo-side (A/B)
+        std::vector<uint8_t> tet_class;
+        if (h->partitioned) {
+            const char* e = getenv("TETSIM_HALO_ALIGNED_TILES");
+            const bool aligned = !(e && e[0] == '0');
+            tet_class.assign(ntl, 0);
+            for (uint32_t i = 0; i < ntl; i++) {
+                if (h->deep && h->part.tet_layer[i]) { tet_class[i] = 2; continue; }
+                if (!aligned) continue;
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t v = static_cast<uint32_t>(ltets[4ull * i + c]);
+                    if (v < nvb || v >= nvo) tet_class[i] = 1;
+                }
+            }
+        }
         // SMALL bodies (the reference's own workload, main.js:79-84) are tiled into 64-tet tiles and solved with one tet / one particle
         // on FOUR lanes (pj_quad.hip): every tile's workgroup must be resident at once for the frame kernel, half the device's capacity
         // at most (another body's kernels may hold slots too).  TETSIM_QUAD=0 keeps the 256-tet tiles (development A/B).
@@ -404,15 +372,6 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = upload(h, lcr, B.lc_range))) return rc;
         if ((rc = upload(h, lce, lceh))) return rc;
         if ((rc = upload(h, vpe, B.vp_ell))) return rc;
-        {   // the longest list among the 64 particles of every wave-sized run of the particle array: the columns that wave reads
-            std::vector<uint8_t> wc(((B.nv_pad / 64u + 1u) + 7u) & ~3u, 0);   // (read as dwords through the scalar cache: pj_blocked.hip)
-            for (uint32_t v = 0; v < nvo + nvg1; v++) wc[v >> 6] = std::max<uint8_t>(wc[v >> 6], static_cast<uint8_t>(B.vp_off[v + 1] - B.vp_off[v]));
-            uint8_t* dwc;
-            if ((rc = dev_alloc(h, &dwc, wc.size()))) return rc;
-            if ((rc = upload(h, dwc, wc))) return rc;
-            static const bool use_cols = [] { const char* e = getenv("TETSIM_VERTEX_COLS"); return !(e && e[0] == '0'); }();
-            if (use_cols) k.vp_wave_cols = dwc;
-        }
         HIPCHK(h, hipMemset(k.partial, 0, std::max<size_t>(nslots, 1) * sizeof(float4)));
         k.blk_tet_off = bto; k.blk_vert_off = bvo; k.blk_verts = bv; k.tet_lidx = lidx; k.vol = vol;
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
