@@ -169,7 +169,7 @@ def run(args, rank, world, local_rank, ranks):
         vert_us = pr["vertex_ms"] / pr["vertex_launches"] * 1e3 if pr["vertex_launches"] else 0.0
         units = pr["tets_per_tet_launch"]
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
-        if body.info.fused_particle_pass:   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
+        if body.info.fused_particle_pass in (1, 2):   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
             kname, tet_bytes = "pjb_tet_fused_kernel", b_alg
         achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
         traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None

@@ -32,11 +32,13 @@ def other_configs(steps=20, warmup=5):
         body.sync()
         el = time.perf_counter() - t0
         levels = body.info.num_levels
-        mode = int(body.info.fused_particle_pass)   # 0: tet + particle kernel per substep; 1: one fused kernel per substep; 2: one persistent kernel per frame
+        mode = int(body.info.fused_particle_pass)   # 0: tet + particle kernel per substep; 1: one fused kernel per substep; 2 / 3: one persistent kernel per frame (3: four lanes per tet)
         body.close()
         return {"value": round(len(t) * n_sub * frames / el / 1e6, 2), "unit": "M tet-solves/s", "ms_per_frame": round(el / frames * 1e3, 4),
                 "us_per_substep": round(el / frames / n_sub * 1e6, 2), "frames": frames,
-                "launches_per_substep": (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3)}[mode]}
+                "launches_per_substep": (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3), 3: round(1.0 / n_sub, 3)}[mode],
+                "kernel": {0: "tet + particle kernel per substep", 1: "fused kernel per substep", 2: "persistent frame kernel, one lane per tet (256-tet tiles)",
+                           3: "persistent frame kernel, four lanes per tet (64-tet tiles)"}[mode] if not levels else "Gauss-Seidel levels"}
 
     # config 1: Dragon, the reference's CPU solver (Neo-Hookean Gauss-Seidel), 10 substeps per frame
     c1 = {"workload": "Dragon (%d tets, %d particles), Neo-Hookean XPBD Gauss-Seidel, 10 substeps/frame" % (len(dtets), len(dv))}

@@ -153,8 +153,10 @@ typedef struct TetSimInfo {
     uint32_t fused_particle_pass; /* 1: tetsim_step_n runs ONE kernel per substep (particle update fused into the tet kernel's staging,
                                      DESIGN.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel.
                                      2: ... and the body is small enough for tetsim_step_n to run ONE persistent kernel per CALL (every
-                                     tile's workgroup resident for all n substeps, DESIGN.md 5.6); tetsim_step / tetsim_profile still
-                                     use the per-substep kernels, whose results are the same bit for bit */
+                                     tile's workgroup resident for all n substeps, DESIGN.md 5.3); tetsim_step / tetsim_profile still
+                                     use the per-substep kernels, whose results are the same bit for bit.
+                                     3: as 2, on 64-tet tiles with one tet and one particle on FOUR lanes (pj_quad.hip: the default for
+                                     small carried-rest-shape bodies); tetsim_step / tetsim_profile run the same substep as two launches */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */

@@ -21,7 +21,9 @@ def _same(a, b):
 def _pair(v, t, **kw):
     a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
     b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
-    assert a.info.fused_particle_pass == 2, "expected the persistent frame kernel for a body of %d tets" % len(t)
+    # 3: the four-lanes-per-tet frame kernel on 64-tet tiles (pj_quad.hip), the default for small bodies that carry their rest shape;
+    # 2: the one-lane-per-tet one on 256-tet tiles (pj_blocked.hip) -- constant-rest-shape bodies
+    assert a.info.fused_particle_pass == (2 if kw.get("constant_rest_shape") else 3), "expected the persistent frame kernel for a body of %d tets" % len(t)
     return a, b
 
 
@@ -68,7 +70,7 @@ def test_frame_kernel_batch_and_save_load():
     bodies = [(dv, dt_), (lv, lt), (dv + np.float32([1.0, 0.2, 0.0]), dt_), (lv + np.float32([-1.0, 0.0, 0.5]), lt)]
     a = SoftBodyHIP.batch(bodies, dict(PP), solver="polar", precision="fast")
     b = SoftBodyHIP.batch(bodies, dict(PP), solver="polar", precision="fast")
-    assert a.info.fused_particle_pass == 2
+    assert a.info.fused_particle_pass == 3
     a.simulateSubsteps(20, DT, PP)
     blob = a.saveState()
     a.simulateSubsteps(15, DT, PP)
@@ -87,3 +89,39 @@ def test_large_bodies_keep_one_kernel_per_substep():
     v, t = make_lattice(40)                        # 384,000 tets = 1,500 tiles: more than half the device's resident workgroups
     body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
     assert body.info.fused_particle_pass == 1
+
+
+def _wheel(spokes):
+    """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
+    ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)
+    ring = np.stack([0.5 * np.cos(ang), np.full(spokes, 1.0), 0.5 * np.sin(ang)], axis=1)
+    v = np.concatenate([[[0.0, 1.3, 0.0], [0.0, 0.7, 0.0]], ring]).astype(np.float32)
+    i = np.arange(spokes)
+    t = np.stack([np.zeros(spokes, int), np.ones(spokes, int), 2 + i, 2 + (i + 1) % spokes], axis=1).astype(np.int32)
+    return v, t
+
+
+def test_long_partial_lists_keep_the_256_tet_tiles():
+    """The four-lane kernels take at most 12 partial sums per particle (host_prep.h kQuadMaxPartials).  A wheel of 1,000 tets around one
+    axis puts its two axis particles into 16 tiles of 64 tets: such a body keeps the 256-tet tiles (4 tiles: lists of 4), says so, and
+    its frame kernel still equals its stepwise kernels bit for bit; a wheel of 600 (10 tiles of 64) takes the four-lane path."""
+    for spokes, want in ((1000, 2), (600, 3)):
+        v, t = _wheel(spokes)
+        a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_slot_table=False)
+        b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_slot_table=False)
+        assert a.info.fused_particle_pass == want, (spokes, a.info.fused_particle_pass)
+        a.simulateSubsteps(25, DT, PP)
+        for _ in range(25):
+            b.simulate(DT, PP)
+        assert _same(a.pos, b.pos) and _same(a.quats, b.quats) and np.isfinite(a.pos).all(), spokes
+
+
+def test_quad_tiles_with_loose_particles_fall_back():
+    """A particle no tet touches is summed by no tile: the fused / frame / four-lane paths cannot serve it (it integrates to NaN in the
+    reference too, 0 / 0) and the body keeps the two-kernel substep -- also for a body small enough for the four-lane kernels."""
+    v, t = make_lattice(3, y0=0.5)
+    v2 = np.concatenate([v, [[2.0, 2.0, 2.0]]]).astype(np.float32)
+    body = SoftBodyHIP(v2, t, None, dict(PP), solver="polar", precision="fast")
+    assert body.info.fused_particle_pass == 0
+    body.simulateSubsteps(5, DT, PP)
+    assert np.isfinite(body.pos[:-1]).all()

@@ -357,7 +357,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 if ((rc = upload(h, h->d_block_tile, block_tile))) return rc;
                 if ((rc = dev_alloc(h, &h->d_frame_err, 1))) return rc;
                 HIPCHK(h, hipMemset(h->d_frame_err, 0, sizeof(uint32_t)));
-                h->info.fused_particle_pass = 2u;
+                h->info.fused_particle_pass = h->quad ? 3u : 2u;
             }
         }
         if ((rc = upload(h, bto, B.blk_tet_off))) return rc;

@@ -135,6 +135,18 @@ class SoftBodyHIP {
     // Afterwards simulate()/simulateSubsteps() exchange ghost positions with the neighbouring partitions over RCCL; `pos`
     // then holds the OWNED particles only, whose global ids are body.ownedIds().
     static commUniqueId() { return loadTetSim().commUniqueId(); }
+    // The library's own vertex partitioner (include/tetsim.h: tetsim_prep_partition): owner of every particle for `parts` partitions, what
+    // goes into `physicsParams.tetsim.vertOwner` of every rank's body (a body created with partCount > 1 and no vertOwner computes the
+    // same map without coordinates).  partitionQuality: per partition { ownedParticles, ghostParticles, boundaryParticles, localElems, ... }.
+    static partition(vertices, tetIds, parts, useCoordinates = true) {
+        const tets32 = tetIds instanceof Int32Array ? tetIds : Int32Array.from(tetIds);
+        const verts32 = vertices instanceof Float32Array ? vertices : Float32Array.from(vertices);
+        return loadTetSim().partition(useCoordinates ? verts32 : null, verts32.length / 3, tets32, parts);
+    }
+    static partitionQuality(tetIds, numParticles, parts, vertOwner = null) {
+        const tets32 = tetIds instanceof Int32Array ? tetIds : Int32Array.from(tetIds);
+        return loadTetSim().partitionQuality(tets32, numParticles, parts, vertOwner);
+    }
     commInit(id, rank, nranks) { this._api.commInit(this._h, id, rank, nranks); }
     ownedIds() { return this._api.ownedIds(this._h); }
 

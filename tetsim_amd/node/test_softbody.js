@@ -174,6 +174,16 @@ if (process.env.TETSIM_TEST_MESH) {
     assert.ok(inf.localParticles > inf.ownedParticles && inf.numNeighbours === 1);
     for (let i = 0; i < ids.length; i++) assert.strictEqual(owner[ids[i]], 1);
     part.dispose();
+    {   // the library's own partitioner through N-API: one owner per particle, both parts used, fewer ghosts than the file's index ranges
+        const own = SoftBodyHIP.partition(verts, tets, 3);
+        assert.ok(own instanceof Int32Array && own.length === verts.length / 3 && own.every(r => r >= 0 && r < 3) && new Set(own).size === 3);
+        const ghosts = q => q.reduce((s, p) => s + p.ghostParticles, 0);
+        const ranges = Int32Array.from(own, (_, i) => Math.min(2, Math.floor(i * 3 / own.length)));
+        const qa = SoftBodyHIP.partitionQuality(tets, own.length, 3, own), qb = SoftBodyHIP.partitionQuality(tets, own.length, 3, ranges);
+        assert.ok(qa.length === 3 && ghosts(qa) < ghosts(qb) && qa.reduce((s, p) => s + p.ownedParticles, 0) === own.length);
+        assert.throws(() => SoftBodyHIP.partition(verts, tets, 0), /parts/);
+        assert.throws(() => SoftBodyHIP.partition(verts, Int32Array.of(0, 1, 2), 2), /4 ids/);
+    }
     const id = SoftBodyHIP.commUniqueId();
     assert.ok(id instanceof Uint8Array && id.length === 128);
     const solo = new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', precision: 'fast' } }), new Float32Array(0), [], null, {});

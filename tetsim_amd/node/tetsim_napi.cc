@@ -57,6 +57,8 @@ struct Api {
     decltype(&tetsim_mesh_arrays) mesh_arrays = nullptr;
     decltype(&tetsim_mesh_close) mesh_close = nullptr;
     decltype(&tetsim_create_from_file) create_from_file = nullptr;
+    decltype(&tetsim_prep_partition) prep_partition = nullptr;
+    decltype(&tetsim_prep_partition_quality) prep_partition_quality = nullptr;
     std::string err;
 } g;
 
@@ -79,6 +81,7 @@ bool load_lib(const std::string& hint) {
     SYM(save_state, "tetsim_save_state") SYM(load_state, "tetsim_load_state") SYM(library_info, "tetsim_library_info")
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
+    SYM(prep_partition, "tetsim_prep_partition") SYM(prep_partition_quality, "tetsim_prep_partition_quality")
 #undef SYM
     if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
     return true;
@@ -470,6 +473,60 @@ napi_value LoadState(napi_env env, napi_callback_info info) {
     if (!typed_array(env, a[1], napi_uint8_array, &blob, &n)) return throw_err(env, "state must be the Uint8Array saveState() returned");
     return check(env, g.load_state(h, blob, n), h);
 }
+// partition(Float32Array verts | null, numParticles, Int32Array tets, parts) -> Int32Array owner   (include/tetsim.h: tetsim_prep_partition;
+// host only -- what a Node host stores in its mesh container or passes as `vertOwner` to every rank's body)
+napi_value Partition(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    float* verts = nullptr; int32_t* tets = nullptr; size_t nvf = 0, ntl = 0;
+    napi_valuetype vt;
+    napi_typeof(env, a[0], &vt);
+    const bool with_coords = vt != napi_null && vt != napi_undefined;
+    if (with_coords && !typed_array(env, a[0], napi_float32_array, &verts, &nvf)) return throw_err(env, "partition: verts must be a Float32Array or null");
+    double nvd = 0, partsd = 0;
+    if (napi_get_value_double(env, a[1], &nvd) != napi_ok || napi_get_value_double(env, a[3], &partsd) != napi_ok || !(nvd >= 0) || nvd > 1073741823.0 || !(partsd >= 1) || partsd > 65536.0)
+        return throw_err(env, "partition(verts | null, numParticles, tets, parts): numParticles / parts out of range");
+    const uint32_t nv = static_cast<uint32_t>(nvd);
+    if (!typed_array(env, a[2], napi_int32_array, &tets, &ntl) || ntl % 4) return throw_err(env, "partition: tets must be an Int32Array of 4 ids per tet");
+    if (with_coords && nvf != 3ull * nv) return throw_err(env, "partition: verts must hold 3 floats per particle");
+    napi_value ab, out; void* data = nullptr;
+    if (napi_create_arraybuffer(env, sizeof(int32_t) * static_cast<size_t>(nv), &data, &ab) != napi_ok || napi_create_typedarray(env, napi_int32_array, nv, ab, 0, &out) != napi_ok)
+        return throw_err(env, "partition: cannot allocate the result");
+    const int rc = g.prep_partition(with_coords ? verts : nullptr, nv, tets, static_cast<uint32_t>(ntl / 4), static_cast<int32_t>(partsd), static_cast<int32_t*>(data));
+    if (rc) return check(env, rc, nullptr);
+    return out;
+}
+// partitionQuality(Int32Array tets, numParticles, parts, Int32Array owner | null) -> [{ownedParticles, ghostParticles, boundaryParticles, localElems, ownedElems, numNeighbours}]
+napi_value PartitionQuality(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
+    int32_t *tets = nullptr, *owner = nullptr; size_t ntl = 0, nol = 0;
+    double nvd = 0, partsd = 0;
+    if (!typed_array(env, a[0], napi_int32_array, &tets, &ntl) || ntl % 4) return throw_err(env, "partitionQuality: tets must be an Int32Array of 4 ids per tet");
+    if (napi_get_value_double(env, a[1], &nvd) != napi_ok || napi_get_value_double(env, a[2], &partsd) != napi_ok || !(nvd >= 0) || nvd > 1073741823.0 || !(partsd >= 1) || partsd > 65536.0)
+        return throw_err(env, "partitionQuality(tets, numParticles, parts, owner | null): numParticles / parts out of range");
+    napi_valuetype vt;
+    napi_typeof(env, a[3], &vt);
+    if (vt != napi_null && vt != napi_undefined && (!typed_array(env, a[3], napi_int32_array, &owner, &nol) || nol != static_cast<size_t>(nvd)))
+        return throw_err(env, "partitionQuality: owner must be an Int32Array of numParticles entries or null");
+    std::vector<TetSimPartQuality> q(static_cast<size_t>(partsd));
+    const int rc = g.prep_partition_quality(tets, static_cast<uint32_t>(ntl / 4), static_cast<uint32_t>(nvd), static_cast<int32_t>(partsd), owner, q.data());
+    if (rc) return check(env, rc, nullptr);
+    napi_value arr; napi_create_array_with_length(env, q.size(), &arr);
+    for (size_t i = 0; i < q.size(); i++) {
+        napi_value o, v; napi_create_object(env, &o);
+        napi_create_uint32(env, q[i].owned_particles, &v); napi_set_named_property(env, o, "ownedParticles", v);
+        napi_create_uint32(env, q[i].ghost_particles, &v); napi_set_named_property(env, o, "ghostParticles", v);
+        napi_create_uint32(env, q[i].boundary_particles, &v); napi_set_named_property(env, o, "boundaryParticles", v);
+        napi_create_uint32(env, q[i].local_elems, &v); napi_set_named_property(env, o, "localElems", v);
+        napi_create_uint32(env, q[i].owned_elems, &v); napi_set_named_property(env, o, "ownedElems", v);
+        napi_create_uint32(env, q[i].num_neighbours, &v); napi_set_named_property(env, o, "numNeighbours", v);
+        napi_set_element(env, arr, static_cast<uint32_t>(i), o);
+    }
+    return arr;
+}
 // libraryInfo() -> { abi, ablation, sourceSha, kernelSha, debugEnv }
 napi_value LibraryInfo(napi_env env, napi_callback_info) {
     if (!g.lib) return throw_err(env, "libtetsim_hip.so is not loaded (call load(path) first)");
@@ -650,6 +707,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"saveState", nullptr, SaveState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"loadState", nullptr, LoadState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"libraryInfo", nullptr, LibraryInfo, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"partition", nullptr, Partition, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"partitionQuality", nullptr, PartitionQuality, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
