@@ -24,14 +24,18 @@ def test_addon_loads_and_fails_loudly_without_gpu():
     _addon()
     js = ("const a=require(%r); const keys=Object.keys(a).sort().join(',');"
           "console.log('KEYS '+keys); console.log('ABI '+a.load(%r));"
+          "const own=a.partition(null,5,new Int32Array([0,1,2,3,1,2,3,4]),2);console.log('OWNERS '+Array.from(own).join(''));"   # host-only: works without a GPU
+          "console.log('QUALITY '+a.partitionQuality(new Int32Array([0,1,2,3,1,2,3,4]),5,2,own).map(p=>p.ownedParticles+'/'+p.ghostParticles).join(' '));"
           "try{a.create(new Float32Array([0,0,0,1,0,0,0,1,0,0,0,1]),new Int32Array([0,1,2,3]),{});console.log('CREATED');}"
           "catch(e){console.log('THROWN '+e.message);}") % (os.path.join(NODE_DIR, "tetsim_napi.node"),
                                                          os.path.join(ROOT, "tetsim_amd", "libtetsim_hip.so"))
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120).stdout
-    assert ("KEYS batchLayout,commInit,commUniqueId,create,createBatch,createFromFile,destroy,info,libraryInfo,load,loadState,mapPositions,mapQuats,ownedIds,readMesh,"
+    assert ("KEYS batchLayout,commInit,commUniqueId,create,createBatch,createFromFile,destroy,info,libraryInfo,load,loadState,mapPositions,mapQuats,ownedIds,partition,partitionQuality,readMesh,"
             "readPositions,readQuats,readVelocities,readVisualMesh,readVisualVertexNormals,readVolError,refreshPositions,refreshQuats,saveState,"
             "setGrab,setVisualMesh,setVisualTriangles,startGrab,step,stepN,sync") in out
     assert "ABI 3" in out
+    owners = out.split("OWNERS ")[1].split()[0]
+    assert len(owners) == 5 and set(owners) == {"0", "1"} and "QUALITY " in out   # the partitioner through N-API: one owner per particle, both parts used
     assert "CREATED" in out or "no CPU fallback" in out  # on a GPU host creation succeeds; otherwise it must throw
 
 
