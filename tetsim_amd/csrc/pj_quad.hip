@@ -191,7 +191,12 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
     uint32_t fr_acc[5] = {0, 0, 0, 0, 0}, fr_last = 0, fr_polls = 0;   // (32-bit: a call is a few hundred thousand cycles, and the kernel has 128 registers)
 #define QSTAMP(i) do { if (kMode == kModeFrame && d.trace && tid == 0) { const uint32_t now_ = static_cast<uint32_t>(__builtin_amdgcn_s_memtime()); if ((i) > 0) fr_acc[(i) > 0 ? (i) - 1 : 0] += now_ - fr_last; fr_last = now_; } } while (0)
 #define QPOLL() do { if (tid == 0) fr_polls++; } while (0)
+    // TETSIM_QUAD_POLL_DELAY=-1 (development): ABSOLUTE s_memtime stamps of substeps n-3 and n-2 instead of the phase sums -- gather
+    // done, solve done, sum stored -- to read the tiles' timelines against each other (one XCD: one clock)
+    unsigned long long fr_abs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QABS(slot) do { if (kMode == kModeFrame && d.trace && tid == 0 && P.poll_delay < 0 && n >= 4u && (s == n - 3u || s == n - 2u)) fr_abs[(s == n - 3u ? 0 : 4) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define QABS(slot) do { } while (0)
 #define QSTAMP(i) do { } while (0)
 #define QPOLL() do { } while (0)
 #endif
@@ -307,6 +312,7 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
 
     for (uint32_t s = 0; s < n; s++) {
         QSTAMP(0);
+        QABS(0);
         if constexpr (kMode == kModeFrame) {
             if (s > 0u) {
                 const QVertex o = gather_update(s - 1u);
@@ -315,6 +321,7 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
             }
         }
         QSTAMP(1);
+        QABS(1);
         if (has_slot) s_pos[tid] = stage;      // (lane 3: the fourth float, 0)
         __syncthreads();
         QSTAMP(2);
@@ -328,6 +335,7 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
             }
         }
         QSTAMP(3);
+        QABS(2);
         __syncthreads();
         QSTAMP(4);
         {   // The tile's reduction, one slot per quad: lane l adds up entries first + l, first + l + 4, ... of ALL three planes (a slot of
@@ -349,14 +357,17 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
             }
         }
         QSTAMP(5);
+        QABS(3);
         // (no barrier here: the next trip writes s_pos, last read before the second barrier above, and the planes are rewritten only
         // behind the next trip's first barrier, which every reducing lane reaches after its reads)
     }
     if constexpr (kMode == kModeFrame) store_particle(gather_update(n - 1u));
 #ifdef TETSIM_ABLATION
-    if (kMode == kModeFrame && d.trace && tid == 0) { for (int i = 0; i < 5; i++) d.trace[8ull * b + i] = fr_acc[i]; d.trace[8ull * b + 5] = fr_polls; d.trace[8ull * b + 6] = n; d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // XCC_ID
+    if (kMode == kModeFrame && d.trace && tid == 0 && P.poll_delay < 0) { for (int i = 0; i < 8; i++) d.trace[8ull * b + i] = fr_abs[i]; }
+    else if (kMode == kModeFrame && d.trace && tid == 0) { for (int i = 0; i < 5; i++) d.trace[8ull * b + i] = fr_acc[i]; d.trace[8ull * b + 5] = fr_polls; d.trace[8ull * b + 6] = n; d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // XCC_ID
 #endif
 #undef QSTAMP
+#undef QABS
 #undef QPOLL
     // every tet back to memory: lane 0 of its quad collects the components
     {
