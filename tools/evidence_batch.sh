@@ -17,6 +17,7 @@ python tools/tolerance_report.py "$OUT/errors.jsonl" --write "$OUT/tolerances.js
 [ "${CALIBRATE:-1}" = 1 ] && cp "$OUT/tolerances.json" tests/golden/tolerances.json
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -25 > "$OUT/pytest_with_table.log"
 timeout 900 bash tools/mutation_check.sh "$OUT/mutation" > "$OUT/mutation.txt" 2>&1
+MUTATION=iters timeout 900 bash tools/mutation_check.sh "$OUT/mutation_iters" > "$OUT/mutation_iters.txt" 2>&1
 timeout 900 bash tools/pmc_run.sh $TAG/pmc > "$OUT/pmc.log" 2>&1
 BENCH_ARGS="--solver neohookean" timeout 900 bash tools/pmc_run.sh $TAG/pmc_nh > "$OUT/pmc_nh.log" 2>&1
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_counters.txt" 2>&1
@@ -29,6 +30,10 @@ timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
 # 7. one interior rank in loopback (the stand-in for a multi-GPU rank): RCCL transfer and peer-to-peer stores, 0 / 10 / 20 us of injected delay
 timeout 900 bash tools/halo_slack.sh "$OUT/halo_slack.txt" > /dev/null 2>&1
+# 7b. round 4: how many rotation iterations move anything, the four-lane kernels of small bodies, the streaming probes
+timeout 900 python tools/rotation_iterations.py > "$OUT/rotation_iterations.txt" 2> "$OUT/rotation_iterations.err"
+timeout 600 bash tools/quad_lanes_report.sh > "$OUT/quad_lanes.txt" 2>&1
+timeout 200 python tools/stream_peak.py > "$OUT/stream_peak.txt" 2>&1
 # 8. small bodies and the Gauss-Seidel solver
 timeout 120 python tools/frame_trace.py 20 > "$OUT/frame_trace.txt" 2>&1
 timeout 300 python tools/dragon_time.py > "$OUT/dragon.txt" 2>&1
