@@ -143,7 +143,7 @@ def run_neohookean(args, verts, tets, device):
                                                                                            body.info.num_levels, SUBSTEPS),
                    "solver": "neohookean_gs", "arithmetic": args.precision, "order": args.order, "substeps_per_step": SUBSTEPS,
                    "tets": len(tets), "particles": len(verts), "parallelism": "single GPU"},
-        # the bound of this solver is its dependency chain (launches x (launch + round trips) + sequential tet solves, DESIGN.md 4);
+        # the bound of this solver is its dependency chain (launches x (launch + round trips) + sequential tet solves, DESIGN.md 6);
         # the HBM figure is reported because the contract asks for one
         "roofline": {"bound": "hbm", "kernel": "whole substep (Gauss-Seidel sweep + particle pass)", "achieved": round(agg, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(agg / HBM_PEAK_GBS, 4), "traffic": None,

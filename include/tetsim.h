@@ -95,7 +95,7 @@ enum {
     TETSIM_FLAG_REF_GRAB_TEXEL = 1u << 4,
     /* partitioned POLAR_JACOBI + TETSIM_FAST (blocked): a ghost region TWO layers deep.  The partition advances its first ghost layer
      * itself and its neighbours' particles cross only every other substep -- half the hand-overs on the substep's critical chain
-     * (DESIGN.md 6).  Needs the peer-to-peer halo (tetsim_halo_p2p_connect) before the first step; dt must stay fixed. */
+     * (DESIGN.md 7).  Needs the peer-to-peer halo (tetsim_halo_p2p_connect) before the first step; dt must stay fixed. */
     TETSIM_FLAG_DEEP_GHOSTS = 1u << 5,
     /* POLAR_JACOBI + TETSIM_FAST: end a tet's rotation iterations only where the reference does (|omega| < 1e-9,
      * SoftbodyGPU.js:131 -- unreachable in f32 unless the tet is exactly rigid, so all nine run).  Without the flag FAST ends the
@@ -124,7 +124,7 @@ typedef struct TetSimOptions {
     double density;     /* physicsParams.density, consumed at construction (Softbody.js:32,74) */
     /* Domain decomposition (POLAR_JACOBI).  part_count <= 1: whole mesh on this handle.  Otherwise this
      * handle owns the vertices v with vert_owner[v] == part_index (vert_owner == NULL: the built-in
-     * partitioner, tetsim_prep_partition without coordinates) plus a ghost layer; see DESIGN.md "Multi-GPU". */
+     * partitioner, tetsim_prep_partition without coordinates) plus a ghost layer; see DESIGN.md 7. */
     int32_t part_count;
     int32_t part_index;
     const int32_t *vert_owner;
@@ -151,7 +151,7 @@ typedef struct TetSimInfo {
     uint32_t num_vis_verts;      /* visual vertices attached by tetsim_set_visual_mesh / a .tetsim file (0 = none); since ABI 3 */
     uint32_t num_bodies;         /* independent bodies behind this handle (tetsim_create_batch), 1 otherwise; since ABI 3 */
     uint32_t fused_particle_pass; /* 1: tetsim_step_n runs ONE kernel per substep (particle update fused into the tet kernel's staging,
-                                     DESIGN.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel.
+                                     HISTORY.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel.
                                      2: ... and the body is small enough for tetsim_step_n to run ONE persistent kernel per CALL (every
                                      tile's workgroup resident for all n substeps); tetsim_step / tetsim_profile still
                                      use the per-substep kernels, whose results are the same bit for bit.
@@ -358,7 +358,7 @@ int tetsim_comm_info(tetsim_handle h, TetSimCommInfo *out);
 int tetsim_comm_selftest(tetsim_handle h);
 /* Measurement helper: `reps` grouped ncclSend+ncclRecv of `bytes` to this rank itself on the halo stream, issued eagerly
  * (use_graph = 0) or captured per_graph at a time into a HIP graph and replayed (use_graph = 1); checks the bytes.
- * host_us = host time to issue one group, total_us = wall time per group.  Design input for DESIGN.md "Multi-GPU". */
+ * host_us = host time to issue one group, total_us = wall time per group.  Design input for DESIGN.md 7. */
 int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph,
                       double *host_us, double *total_us);
 /* Peer-to-peer halo (opt-in; POLAR_JACOBI + TETSIM_FAST blocked partitions).  The per-substep ghost exchange without a transfer
@@ -410,7 +410,7 @@ int tetsim_prep_colours(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *
  * launch[a] < launch[b], or the same launch AND lane with step[a] < step[b]. */
 int tetsim_prep_clusters(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t *order, int32_t *launch, int32_t *lane,
                          int32_t *step, uint32_t *num_launches, uint32_t *num_clusters);
-/* The tile plan of the blocked polar kernels (DESIGN.md 5.2) for a mesh or a batch of meshes (body_first_tet / body_first_vert
+/* The tile plan of the blocked polar kernels (DESIGN.md 5.1) for a mesh or a batch of meshes (body_first_tet / body_first_vert
  * [bodies + 1] as tetsim_create_batch lays them out; NULL = one body): tets in tile order (tile_tets[i] = input tet at position
  * i), tile offsets into it (tile_off [tiles + 1]; pass NULL arrays to query *num_tiles first: at most nt of them), and per
  * position the tile-local particle slot of each corner (corner_slot [4 * nt], < 256).  Host only; what the property tests check:
@@ -470,7 +470,7 @@ int tetsim_plan_create(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t pa
 /* The same plan with a ghost region `depth` layers deep (1 or 2).  Depth 2: the second layer holds the particles that share a tet
  * with a first-layer ghost, the local tets include the tets of the first-layer ghosts that touch no owned particle, and every
  * neighbour has a second pair of lists -- what lets a partition advance its first ghost layer itself and exchange ghosts only every
- * other substep (DESIGN.md 6; exercised on the CPU by tests/test_partition_gloo.py).  Local numbering: owned boundary | owned
+ * other substep (DESIGN.md 7; exercised on the CPU by tests/test_partition_gloo.py).  Local numbering: owned boundary | owned
  * interior | first-layer ghosts by owner | second-layer ghosts by owner. */
 int tetsim_plan_create_deep(const int32_t *tets, uint32_t nt, uint32_t nv, int32_t part_count, int32_t part_index,
                             const int32_t *vert_owner, int32_t depth, tetsim_plan *out);

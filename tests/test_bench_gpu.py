@@ -50,7 +50,7 @@ def test_headline_line_carries_every_baseline_config():
     for k in ("neohookean_clustered_gs_fast", "neohookean_clustered_gs_precise", "polar_jacobi_fast"):
         r = c4[k]["mean_abs_detF_minus_1_after_1_5_30_frames"]
         assert c4[k]["value"] > 1000 and len(r) == 3 and all(0 <= x < 0.5 for x in r)
-    # Gauss-Seidel holds the volume under contact where one Jacobi iteration per substep goes soft (DESIGN.md 4)
+    # Gauss-Seidel holds the volume under contact where one Jacobi iteration per substep goes soft (DESIGN.md 6)
     assert c4["neohookean_clustered_gs_precise"]["mean_abs_detF_minus_1_after_1_5_30_frames"][2] < c4["polar_jacobi_fast"]["mean_abs_detF_minus_1_after_1_5_30_frames"][2]
     import hashlib  # noqa: F401
     tr = d["roofline"]["traffic"]

@@ -1,4 +1,4 @@
-"""The persistent frame kernel (pj_blocked.hip: pjb_frame_kernel, DESIGN.md 5.6): small unpartitioned FAST bodies run a whole
+"""The persistent frame kernel (pj_blocked.hip: pjb_frame_kernel, DESIGN.md 5.3): small unpartitioned FAST bodies run a whole
 tetsim_step_n call as ONE launch -- every tile's workgroup resident for all n substeps, tet records and particles in registers,
 tile partial sums exchanged through memory with the substep's sequence number in the fourth float.  Its contract: a call of n
 substeps equals n tetsim_step calls (one tet and one particle kernel each) BIT FOR BIT, whatever n, and across calls."""

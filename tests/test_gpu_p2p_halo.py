@@ -1,4 +1,4 @@
-"""Peer-to-peer halo (tetsim_halo_p2p_export / _connect, DESIGN.md 6): the boundary-particle kernel stores the ghost positions straight
+"""Peer-to-peer halo (tetsim_halo_p2p_export / _connect, DESIGN.md 7): the boundary-particle kernel stores the ghost positions straight
 into the neighbours' ghost ranges, double buffered by substep parity, and a word per neighbour says "arrived" -- no transfer kernel.
 The arithmetic is untouched, so a decomposition stepped with it must equal the same decomposition stepped with the copy transport
 BIT FOR BIT -- any number of substeps per call (the buffers alternate by parity), across calls, across dt changes (refresh

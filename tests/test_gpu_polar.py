@@ -70,7 +70,7 @@ def test_fast_tolerance(gather):
 
 @pytest.mark.parametrize("gather", [False, True])
 def test_reference_rotation_exit_flag(gather):
-    """FAST ends a tet's correction iterations 2..9 below |omega| = 1e-6 rad (DESIGN.md 5.3, profiles/r04_rotation_iterations.txt);
+    """FAST ends a tet's correction iterations 2..9 below |omega| = 1e-6 rad (DESIGN.md 5.2, profiles/r04_rotation_iterations.txt);
     TETSIM_FLAG_REF_ROTATION_EXIT keeps the reference's 1e-9 (SoftbodyGPU.js:131: all nine iterations in f32).  Both must sit inside
     the same FAST envelope against the oracle (which runs all nine), the two stay within the envelope of each other, and the flag is
     a no-op for PRECISE."""

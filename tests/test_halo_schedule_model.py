@@ -6,7 +6,7 @@ a MODEL on the CPU: every interleaving of the queues of two neighbouring ranks i
   * every kernel reads exactly the version of every buffer it is meant to read, for its whole duration, and nobody writes a
     buffer somebody else is still reading or writing.
 
-The model restates the order of submission by hand -- it is not generated from the C++ -- so it pins the DESIGN (DESIGN.md 6):
+The model restates the order of submission by hand -- it is not generated from the C++ -- so it pins the DESIGN (DESIGN.md 7):
 what runs on which queue, which kernel raises which word as it starts, which wait sits where, and what the end of a call adds.
 Queues are in order (an operation starts when its predecessor on the queue has ended); a kernel is two events, START and END:
 reads last from START to END, writes too (conservatively), a raise happens at START.  The transfer of substep s is a rendezvous

@@ -106,7 +106,7 @@ def test_plan_is_symmetric_and_complete(world):
         assert len(p.neighbours) <= 2
 
 
-# ---- a two-layer ghost region: ghosts cross only EVERY OTHER substep (DESIGN.md 6) -------------------------------------------------
+# ---- a two-layer ghost region: ghosts cross only EVERY OTHER substep (DESIGN.md 7) -------------------------------------------------
 # The algorithm, with the product's depth-2 plan and the oracle as the compute body.  Layers of a rank: owned O, first ghost layer G1
 # (shares a tet with O), second layer G2 (shares a tet with G1); tets T1 (touch O) and L2 (touch G1, not O).  Entering an EVEN substep s
 # everything local is valid.  Substep s: O and G1 come out right (all their tets are local and had valid inputs), G2 does not.  Substep

@@ -46,7 +46,7 @@ def test_one_owner_balance_and_fewer_ghosts_than_index_ranges(mesh, parts, coord
 
 
 def test_quality_table():
-    """The figures DESIGN.md 6 quotes (ghost particles / ghost tets, partitioner vs index ranges)."""
+    """The figures DESIGN.md 7 quotes (ghost particles / ghost tets, partitioner vs index ranges)."""
     v, t = load_mesh("dragon")
     got = {p: partition_quality(t, len(v), p) for p in (3, 4, 8)}
     rng = {p: partition_quality(t, len(v), p, index_range_owner(len(v), p)) for p in (3, 4, 8)}

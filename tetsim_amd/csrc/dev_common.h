@@ -43,7 +43,7 @@ struct PJDev {
     float rot_exit_w2 = 1.0e-18f; // FAST: squared |omega| that ends a tet's correction iterations (pj_math.inc)
 };
 
-// ---- POLAR_JACOBI, blocked formulation (FAST mode; DESIGN.md "Blocked formulation") -----------------------
+// ---- POLAR_JACOBI, blocked formulation (FAST mode) -----------------------
 // Tets are tiled into workgroups of <= 256 tets touching <= 256 distinct particles.  The tile's particle
 // positions are staged in LDS, the 4 goals of every tet are reduced IN LDS to one partial sum per tile
 // particle (fixed order: deterministic), and the per-particle pass adds the few partial sums of the tiles

@@ -52,7 +52,7 @@ struct Incidence {
 };
 Incidence build_incidence(const int32_t* tets, uint32_t nt, uint32_t nv, bool ref_quirk, bool ref_cap);
 
-// Domain decomposition plan for one partition (DESIGN.md "Multi-GPU").
+// Domain decomposition plan for one partition.
 struct Partition {
     uint32_t nv_global = 0, nt_global = 0;
     int part_count = 1, part_index = 0;
@@ -76,7 +76,7 @@ struct Partition {
     };
     std::vector<Neighbour> neigh;
     // depth 2 (a two-layer ghost region: the partition can advance its first ghost layer itself, so that ghosts need to cross
-    // only every other substep -- DESIGN.md 6): ghosts [n_owned, n_owned + n_ghost1) are the first layer (share a tet with an
+    // only every other substep -- DESIGN.md 7): ghosts [n_owned, n_owned + n_ghost1) are the first layer (share a tet with an
     // owned particle), the rest the second (share a tet with a first-layer ghost); local tets with tet_layer 1 touch no owned
     // particle (first-layer ghost tets' outer neighbours).  depth 1: n_ghost1 = all ghosts, tet_layer all 0.
     int depth = 1;
@@ -102,7 +102,7 @@ std::string build_partition(const int32_t* tets, uint32_t nt, uint32_t nv, int p
 // close in space are close in memory (tile staging and partial-sum gathers then touch near-contiguous runs).
 std::vector<uint32_t> morton_vertex_order(const float* xyz, uint32_t n, uint32_t first, uint32_t count);
 
-// Workgroup tiling for the blocked POLAR_JACOBI formulation (DESIGN.md "Blocked formulation").
+// Workgroup tiling for the blocked POLAR_JACOBI formulation.
 // Tets are sorted along a Morton curve of their rest centroids and cut into tiles of <= 256 tets that touch
 // <= 256 distinct vertices, so a tile's vertex set fits an LDS tile addressed by 8-bit local indices.
 #ifndef TETSIM_TILE
@@ -145,7 +145,7 @@ struct BlockPlan {
 // nv_boundary: particles [0, nv_boundary) are the partition's BOUNDARY particles (the ones it sends to neighbours).  A tile is
 // "halo-side" -- ordered last, counted out of num_interior_blocks -- if it touches a ghost (id >= nv_sum) OR a boundary particle:
 // then every tile that contributes to a boundary particle is halo-side, and the halo queue can finish the boundary particles
-// and start the transfer without waiting for the interior tiles (DESIGN.md 6).
+// and start the transfer without waiting for the interior tiles (DESIGN.md 7).
 // Partitions: tet_class[e] (0..2) keeps tets of different classes in different tiles, class after class.  1 = the tets that touch a
 // boundary or a ghost particle: with tiles of their own the halo-side tiles are exactly those tets -- two or three cell layers
 // along an interface instead of every cube-shaped tile that happens to reach it (14.5% -> 7% of a 1 M-tet slab's tets on the halo

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
-// ... raising a hand-over word as they START (partitioned bodies, DESIGN.md 6): a kernel starts only when everything in front
+// ... raising a hand-over word as they START (partitioned bodies, DESIGN.md 7): a kernel starts only when everything in front
 // of it in its in-order queue is complete, so "the previous kernel of this queue is done" costs one store of one thread here
 // instead of a signal kernel of its own (~2.7 us of queue time each, and the two-queue substep had two of them)
 __device__ __forceinline__ void raise(uint32_t* sig) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(P
     pjb_tet_body<true, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 
-// ---- one persistent launch per tetsim_step_n call (small bodies; DESIGN.md 5.6) -------------------------------------------
+// ---- one persistent launch per tetsim_step_n call (small bodies; DESIGN.md 5.3) -------------------------------------------
 // A Dragon-sized body (15 tiles) occupies 15 of the chip's 2,048 workgroup slots: its substep is launch boundaries and dependent
 // memory trips and nothing else.  Here every tile's workgroup stays resident for all n substeps of a call:
 //   * a lane keeps ITS tet's record -- carried rest shape, quaternion, volume, corner slots -- in registers from substep to
@@ -629,7 +629,7 @@ __global__ void pjb_probe_xcd_kernel(uint32_t* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
 }
 
-// ---- cross-queue hand-over of partitioned bodies (DESIGN.md 6) ----------------------------------------------------------
+// ---- cross-queue hand-over of partitioned bodies (DESIGN.md 7) ----------------------------------------------------------
 // A partitioned substep runs on two queues (halo-side tiles, boundary particles and the transfer on the halo stream, everything
 // else on the main stream; tetsim_halo.hip: enqueue_phase_a).  A dependency between the queues costs ~15 us as an event (eager) and ~6 us as a fork/join edge of a captured graph
 // on this stack (tools/micro/xq_latency.hip), and the cycle  particles(s) -> transfer(s) -> H tiles(s+1) -> particles(s+1)
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t 
 }
 // ... waiting for a hand-over word ITSELF: every wave looks at the word before it touches a partial sum (one lane, agent-scope loads,
 // bounded like the wait kernels) and nobody puts it back -- the next kernel of this queue does, as it starts (clear_then_raise).  The
-// one-wave wait kernel this replaces cost the main queue a third launch boundary per substep (DESIGN.md 6).
+// one-wave wait kernel this replaces cost the main queue a third launch boundary per substep (DESIGN.md 7).
 __global__ __launch_bounds__(64) void pjb_vertex_kernel_await(PJBlk d, uint32_t first, uint32_t count, uint32_t* flag, uint32_t* error, uint32_t timeout_ms) {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64(), limit = 100000ll * timeout_ms;   // 100 MHz ticks

@@ -130,7 +130,7 @@ void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0, hi
     else if (h->blocked) pjb_launch_vertex(h->stream, h->blk, first, count, e0, e1);
     else h->fast ? pj_launch_vertex_fast(h->stream, h->pj, first, count, e0, e1) : pj_launch_vertex_precise(h->stream, h->pj, first, count, e0, e1);
 }
-// One substep of a fused body inside a run of substeps with one dt:
+// One substep of a fused body inside a run of substeps with one dt (HISTORY.md 5.4):
 //   first substep:  plain tet kernel (predictions of the previous call's particle kernel)          -> partial sums A
 //   substep s >= 1: fused kernel = particle update of s-1 (partial sums of s-1, positions in/out double buffered) + tet pass s
 //   last substep:   ... followed by the particle kernel, which always leaves the positions in pj.pos_final
@@ -547,7 +547,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         // RCCL bodies: the first call runs eagerly (RCCL sets its connections up on first use, which must not happen inside a
         // capture); afterwards the n substeps -- both streams, the grouped send/recv included -- are one captured graph:
         // eager cross-stream dependencies cost ~10 us each on this stack and there are three per substep on the halo's
-        // critical path (DESIGN.md 6).  TETSIM_HALO_GRAPH=0 keeps everything eager.
+        // critical path (DESIGN.md 7).  TETSIM_HALO_GRAPH=0 keeps everything eager.
         const bool use_graph = h->halo_use_graph;
         const bool own_rank = h->group.empty() && (h->comm || h->p2p);   // one rank per process: RCCL and / or the peer-to-peer halo
         if (own_rank && use_graph && h->halo_warm && !h->halo_graph_broken && uses_flag_sync(h)) {

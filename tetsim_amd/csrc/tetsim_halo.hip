@@ -1,4 +1,4 @@
-// tetsim_halo.hip -- multi-GPU: the per-substep halo choreography of partitioned POLAR_JACOBI bodies (DESIGN.md 6) and the stepping of
+// tetsim_halo.hip -- multi-GPU: the per-substep halo choreography of partitioned POLAR_JACOBI bodies (DESIGN.md 7) and the stepping of
 // in-process groups.  Communicator set-up and probes: tetsim_comm.hip; peer-to-peer halo (export / connect): tetsim_p2p.hip.
 #include "body.h"
 
@@ -193,7 +193,7 @@ int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particle
             PJBlk kb = h->blk;   // kernels of the halo queue read the halo queue's copy of the parameters
             if (h->d_params_halo) kb.params = h->d_params_halo;
             if (h->p2p && h->deep) {
-                // Two-layer ghost region: ghosts cross only every other substep (DESIGN.md 6; the algorithm is
+                // Two-layer ghost region: ghosts cross only every other substep (DESIGN.md 7; the algorithm is
                 // tests/test_partition_gloo.py's).  r = substeps since the connection, set = (r / 2) & 1 the exchange's buffer set.
                 //   EVEN r:  wait [V, arrived(set, even)] - tiles: halo-side + second-layer ghost tets, ghosts from the set's EVEN buffers -
                 //            boundary particles [their second-layer share -> the neighbours' ODD buffer of this set: the early message] -

@@ -1,4 +1,4 @@
-// tetsim_p2p.hip -- C ABI, peer-to-peer halo (include/tetsim.h: tetsim_halo_p2p_export / _connect, DESIGN.md 6): a rank describes its ghost
+// tetsim_p2p.hip -- C ABI, peer-to-peer halo (include/tetsim.h: tetsim_halo_p2p_export / _connect, DESIGN.md 7): a rank describes its ghost
 // buffers and "arrived" words in a blob, the caller gathers the blobs, every rank maps its neighbours' (HIP IPC, or plain pointers for
 // ranks of one process).  What the boundary-particle kernel does with the mappings is in tetsim_halo.hip / pj_blocked.hip.
 #include "body.h"

@@ -28,7 +28,7 @@ timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/b
 timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-beyond-mall > "$OUT/stats.log" 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
-# 7. one interior rank in loopback (the stand-in for a multi-GPU rank; DESIGN.md 6): RCCL transfer and peer-to-peer stores, 0 / 10 / 20 us of injected delay
+# 7. one interior rank in loopback (the stand-in for a multi-GPU rank; DESIGN.md 7): RCCL transfer and peer-to-peer stores, 0 / 10 / 20 us of injected delay
 timeout 900 bash tools/halo_slack.sh "$OUT/halo_slack.txt" > /dev/null 2>&1
 # 7b. round 4: how many rotation iterations move anything, the four-lane kernels of small bodies, the streaming probes
 timeout 900 python tools/rotation_iterations.py > "$OUT/rotation_iterations.txt" 2> "$OUT/rotation_iterations.err"
