@@ -158,3 +158,29 @@ def test_tile_plan_of_the_headline_lattice():
     assert len(sizes) <= -(-len(t) // 256) + len(t) // 2000          # the Morton runs fill their tiles (a few short ones at most)
     with __import__("pytest").raises(AssertionError):
         _tiles(v, t, [0, len(t)], [0, len(v) - 1])                    # body ranges must cover the mesh
+
+
+@settings(max_examples=150, deadline=None)
+@given(meshes(), st.integers(1, 6), st.booleans())
+def test_partitioner_on_arbitrary_connectivity(m, parts, with_coords):
+    """tetsim_prep_partition on ANY connectivity -- duplicated tets, isolated particles, disconnected pieces, more parts than pieces:
+    one owner per particle, in range, deterministic; the weight it balances (1 + valence) stays within one particle's weight of the
+    refinement's +-3% band; the quality counts are those of the partition plans built from the same map."""
+    from tetsim_amd.partition import partition, partition_quality
+    nv, t = m
+    coords = None
+    if with_coords:
+        coords = (np.arange(3 * nv, dtype=np.float32).reshape(nv, 3) * np.float32(0.37)) % np.float32(1.0)
+    own = partition(t, nv, parts, coords)
+    assert own.shape == (nv,) and own.min() >= 0 and own.max() < parts
+    assert np.array_equal(own, partition(t, nv, parts, coords))
+    w = np.bincount(t.reshape(-1), minlength=nv) + 1
+    load = np.bincount(own, weights=w, minlength=parts)
+    assert load.max() <= 1.03 * load.mean() + w.max() + 1e-9
+    q = partition_quality(t, nv, parts, own)
+    assert sum(p["owned_particles"] for p in q["parts"]) == nv and sum(p["owned_elems"] for p in q["parts"]) == len(t)
+    for r in range(parts):
+        plan = PartitionPlan(t, nv, parts, r, own)
+        p = q["parts"][r]
+        assert (plan.n_owned, plan.n_boundary, plan.n_local - plan.n_owned, plan.n_local_tets, plan.n_owned_tets, len(plan.neighbours)) == \
+               (p["owned_particles"], p["boundary_particles"], p["ghost_particles"], p["local_elems"], p["owned_elems"], p["num_neighbours"])
