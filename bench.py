@@ -70,6 +70,7 @@ def parse_args():
                     help="N > 1: append BASELINE config 5 literally (the --config5-cells^3 lattice cut into N slabs, strong scaling) as "
                          "`config5_strong` of the same JSON line; auto = when N == 8")
     ap.add_argument("--config5-cells", type=int, default=110, help="cells per side of the config-5 body (110 = 7,986,000 tets)")
+    ap.add_argument("--no-replay", action="store_true", help="N = 1: time the dominant kernel in the 180 substeps AFTER the timed region only (rounds 1-3), not over a replay of the timed frames")
     ap.add_argument("--no-beyond-mall", action="store_true", help="N = 1: skip `roofline.beyond_mall` (the 8 M-tet body on this GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
     ap.add_argument("--halo", default="rccl", choices=["rccl", "p2p", "deep"],

@@ -36,6 +36,8 @@ def test_single_gpu_line():
     lib = d["library"]
     assert lib["abi"] == 3 and lib["ablation"] is False and lib["debug_env"] == [] and len(lib["kernel_sha"]) == 16
     assert rf["traffic"] is None          # not the headline lattice: no counter figure is attached to it
+    # the dominant kernel is timed over a replay of the timed frames, which must retrace them bit for bit; the window after them beside it
+    assert "bit-equal to the timed one: True" in rf["window"] and rf["after_timed_region"]["kernel_us"] > 0
 
 
 def test_headline_line_carries_every_baseline_config():
@@ -43,6 +45,7 @@ def test_headline_line_carries_every_baseline_config():
     (config 3), and roofline.traffic is either null or keyed to this very kernel build."""
     d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     assert d["config"]["tets"] == 998250
+    assert "bit-equal to the timed one: True" in d["roofline"]["window"] and "(60 launches)" in d["roofline"]["window"]
     oc = d["other_configs"]
     c1, c2, c4 = oc["config1_dragon_neohookean_cpu_path"], oc["config2_dragon_polar_jacobi"], oc["config4_lattice_1m_neohookean_gs_vs_jacobi"]
     assert c1["hip_original_order_precise"]["value"] > 0 and c1["hip_coloured_precise"]["value"] > c1["hip_original_order_precise"]["value"]
