@@ -116,6 +116,38 @@ def test_long_partial_lists_keep_the_256_tet_tiles():
         assert _same(a.pos, b.pos) and _same(a.quats, b.quats) and np.isfinite(a.pos).all(), spokes
 
 
+def test_lists_of_more_than_nine_partial_sums_stay_on_the_fused_paths():
+    """The fused and frame kernels gather up to nine partial sums per particle in one trip and longer lists entry by entry behind them
+    (irregular meshes; a 28^3-cell lattice has lists of ten).  A wheel of 3,600 tets puts its two axis particles into 15 tiles of 256
+    tets: one persistent launch per call (mode 2), equal bit for bit to its stepwise fused kernel AND to the two-kernel substep of a
+    process that has the fused pass switched off."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    v, t = _wheel(3600)
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_slot_table=False)
+    b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_slot_table=False)
+    assert a.info.fused_particle_pass == 2
+    a.simulateSubsteps(25, DT, PP)
+    for _ in range(25):
+        b.simulate(DT, PP)
+    assert _same(a.pos, b.pos) and _same(a.quats, b.quats) and np.isfinite(a.pos).all()
+    with tempfile.TemporaryDirectory() as tmp:
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "from test_gpu_frame_kernel import _wheel, PP, DT; from tetsim_amd import SoftBodyHIP\n"
+                "v, t = _wheel(3600); c = SoftBodyHIP(v, t, None, dict(PP), solver='polar', precision='fast', ref_slot_table=False)\n"
+                "assert c.info.fused_particle_pass == 0\n"
+                "c.simulateSubsteps(25, DT, PP); np.save(%r, c.pos)\n"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), os.path.join(tmp, "two.npy")))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TETSIM_FUSED_PARTICLE_PASS="0", TETSIM_QUAD="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert _same(np.load(os.path.join(tmp, "two.npy")), a.pos)
+    v, t = make_lattice(28)                        # 131,712 tets = 515 tiles, lists of up to ten: one fused kernel per substep or one launch per call
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    assert body.info.fused_particle_pass in (1, 2)
+
+
 def test_quad_tiles_with_loose_particles_fall_back():
     """A particle no tet touches is summed by no tile: the fused / frame / four-lane paths cannot serve it (it integrates to NaN in the
     reference too, 0 / 0) and the body keeps the two-kernel substep -- also for a body small enough for the four-lane kernels."""

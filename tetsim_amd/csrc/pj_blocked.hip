@@ -13,7 +13,7 @@
 //     3. lanes switch roles -- one lane per tile PARTICLE -- and add up the corner goals of that particle in
 //        LDS, in a fixed host-built order (deterministic, no atomics), storing ONE partial sum per
 //        (tile, particle), coalesced.
-//   pjb_vertex_kernel  one lane per particle: adds the 1..9 (2.9 on average) partial sums of the tiles that touch
+//   pjb_vertex_kernel  one lane per particle: adds the 1..9 (2.9 on average; irregular meshes: more) partial sums of the tiles that touch
 //        it instead of gathering ~23 goals, then collides / integrates exactly like the gather formulation.
 //
 // Tried and dropped in round 2 (profiles/r02b_kernel_variants.txt): the staged positions as three f32 planes instead of float4
@@ -232,6 +232,14 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
         if (src8 != 0xffffffffu) { acc.x += t8.x; acc.y += t8.y; acc.z += t8.z; }
+        if (maxsrc > 9u) {   // (uniform, rare: a tile with a particle at the corner of more than nine tiles -- irregular meshes; one trip per entry)
+            const uint32_t* col = d.slot_src + slot;
+            for (uint32_t j = 9u; j < maxsrc; j++) {
+                const uint32_t sj = col[static_cast<size_t>(j) * d.ns_pad];
+                const float4 tj = d.partial_prev[sj == 0xffffffffu ? 0u : sj];
+                if (sj != 0xffffffffu) { acc.x += tj.x; acc.y += tj.y; acc.z += tj.z; }
+            }
+        }
         const VertexOut o = pjb_vertex_update(acc, wsum, xyz(prev4), *d.params, vid);
         pos_stage = make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f);
         if (has_slot && ((range >> 15) & 1u)) {   // one writer per particle
@@ -527,6 +535,25 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
 #pragma unroll
         for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
         if (src[8] != 0xffffffffu) { acc.x += g[8].x; acc.y += g[8].y; acc.z += g[8].z; }
+        if (maxsrc > 9u) {   // (uniform, rare: lists of more than nine partial sums -- irregular meshes; entry by entry, the ids re-read from the table)
+            const uint32_t* col = d.slot_src + slot;
+            for (uint32_t j = 9u; j < maxsrc; j++) {
+                const uint32_t sj = has_slot ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;
+                bool miss = sj != 0xffffffffu;
+                f3 gj = F3(0.0f, 0.0f, 0.0f);
+                while (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
+                    if (miss) {
+                        const float4 t = kLocal ? load_l2(buf, sj) : load_coherent(buf, sj);
+                        if (__float_as_uint(t.w) == expect) { gj = xyz(t); miss = false; }
+                    }
+                    if (limit && miss && wall_clock64() - w0 > limit) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        miss = false;
+                    }
+                }
+                acc.x += gj.x; acc.y += gj.y; acc.z += gj.z;
+            }
+        }
         return pjb_vertex_update(acc, wsum, prev, P, vid);
     };
 

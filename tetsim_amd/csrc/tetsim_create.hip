@@ -269,8 +269,9 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = dev_alloc(h, &dws, wsum.size()))) return rc;
         if ((rc = upload(h, dws, wsum))) return rc;
         k.wsum = dws;
-        // fused particle pass: unpartitioned bodies whose every particle is summed by some tile, lists of at most 9 partial sums
-        // (8 in one trip + 1), TETSIM_FUSED_PARTICLE_PASS=0 keeps the two-kernel substep (development A/B)
+        // fused particle pass: unpartitioned bodies whose every particle is summed by some tile (lists of up to 9 partial sums are
+        // gathered in one trip, 8 + 1; longer ones -- irregular meshes -- entry by entry behind them), TETSIM_FUSED_PARTICLE_PASS=0 keeps
+        // the two-kernel substep (development A/B)
         static const bool allow_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return !(e && e[0] == '0'); }();
         // ... and only where it pays: a body of fewer tiles than the chip has workgroup slots (2,048) is bound by launches and
         // dependency bubbles, and one kernel per substep instead of two is worth +21% on the Dragon (15 tiles; profiles/r02h_*); the
@@ -278,7 +279,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         // (32.0 us against 25.6 + 5.8), needs 74 registers instead of 49 (6 waves per SIMD instead of 8) and reads lower on the
         // roofline -- and keeps the two-kernel substep.  TETSIM_FUSED_PARTICLE_PASS=1 forces it on (A/B).
         static const bool force_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return e && e[0] == '1'; }();
-        h->fused = allow_fused && !h->quad && !h->partitioned && nvo == nvl && B.every_owned_particle_has_a_partial && B.max_partials <= 9 && ntl > 0 &&
+        h->fused = allow_fused && !h->quad && !h->partitioned && nvo == nvl && B.every_owned_particle_has_a_partial && ntl > 0 &&
                    (B.num_blocks < 2048u || force_fused);
         k.fin_in = d.pos_final; k.fin_out = d.pos_final;
         h->info.fused_particle_pass = h->fused ? 1u : 0u;
