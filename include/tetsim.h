@@ -156,7 +156,10 @@ typedef struct TetSimInfo {
                                      tile's workgroup resident for all n substeps); tetsim_step / tetsim_profile still
                                      use the per-substep kernels, whose results are the same bit for bit.
                                      3: as 2, on 64-tet tiles with one tet and one particle on FOUR lanes (pj_quad.hip: the default for
-                                     small carried-rest-shape bodies); tetsim_step / tetsim_profile run the same substep as two launches */
+                                     small carried-rest-shape bodies); tetsim_step / tetsim_profile run the same substep as two launches
+                                     4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles: they all
+                                     fit one CU's LDS and tetsim_step_n runs a whole call as ONE single-workgroup launch (nh_kernels.inc);
+                                     tetsim_step / tetsim_profile keep one launch per level, same arithmetic, same results bit for bit */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
@@ -498,7 +501,7 @@ int tetsim_abi_version(void);
  * {TETSIM_DEBUG_LOOPBACK_HALO, TETSIM_DEBUG_LOOPBACK_COPY, TETSIM_DEBUG_ONE_STREAM, TETSIM_DEBUG_GROUP_SYNC,
  * TETSIM_DEBUG_HOSTPROF, TETSIM_DEBUG_TRACE, TETSIM_HALO_SYNC, TETSIM_HALO_GRAPH, TETSIM_DEBUG_LOOPBACK_DELAY_US, TETSIM_NH_QUADS,
  * TETSIM_FUSED_PARTICLE_PASS, TETSIM_FRAME_KERNEL, TETSIM_FRAME_LOCAL, TETSIM_NH_FOLD, TETSIM_HALO_ALIGNED_TILES, TETSIM_HALO_FOLD_WAIT, TETSIM_QUAD,
- * TETSIM_QUAD_POLL_DELAY} is set in the
+ * TETSIM_QUAD_POLL_DELAY, TETSIM_NH_FRAME} is set in the
  * environment.  bench.py records all of it in its JSON line. */
 typedef struct TetSimLibraryInfo {
     int32_t abi;

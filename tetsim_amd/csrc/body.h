@@ -252,6 +252,10 @@ struct tetsim_body {
     uint32_t* d_nh_untouched = nullptr;
     uint32_t nh_untouched = 0;
     std::vector<uint32_t> level_off;
+    // small bodies (all particles fit one CU's LDS, level schedules): tetsim_step_n runs a call as ONE single-workgroup launch
+    bool nh_frame = false;
+    uint32_t* d_level_off = nullptr;
+    uint32_t nh_frame_block = 0;
     std::vector<int32_t> order;
     std::vector<float> h_inv_mass;
 };

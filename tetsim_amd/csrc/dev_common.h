@@ -136,6 +136,11 @@ void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
 void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
 // the same pass for the particles no cluster touches (list of particle ids), when the sweeps fold the rest
+// small bodies: a whole call as one workgroup with every particle in LDS (nh_kernels.inc); `block` threads <= 512, nv * 40 bytes of LDS
+void nh_launch_frame_precise(hipStream_t s, const NHDev& d, const uint32_t* level_off, uint32_t levels, uint32_t n, uint32_t block);
+void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const uint32_t* level_off, uint32_t levels, uint32_t n, uint32_t block);
+uint32_t nh_frame_lds_limit_precise();
+uint32_t nh_frame_lds_limit_fast();
 void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 void nh_launch_post_predict_list_fast(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);
 // raise_word != nullptr: the kernel sets that hand-over word (PJSync::flag) as it STARTS, i.e. "everything in front of this kernel

@@ -368,9 +368,6 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d
 // ... raising a hand-over word as they START (partitioned bodies): a kernel starts only when everything in front
 // of it in its in-order queue is complete, so "the previous kernel of this queue is done" costs one store of one thread here
 // instead of a signal kernel of its own (~2.7 us of queue time each, and the two-queue substep had two of them)
-__device__ __forceinline__ void raise(uint32_t* sig) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
 // ... and, in front of the raise, putting back a word whose waiters were the waves of the kernel in front of this one in its queue (the
 // interior particle kernel that waits for G itself, pjb_vertex_kernel_await: all of its waves are through when this kernel starts)
 __device__ __forceinline__ void clear_then_raise(uint32_t* clear, uint32_t* sig) {

@@ -272,6 +272,13 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         else pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    } else if (h->nh_frame) {
+        // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
+        const uint32_t levels = static_cast<uint32_t>(h->level_off.size() - 1);
+        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->d_level_off, levels, n, h->nh_frame_block)
+                : nh_launch_frame_precise(h->stream, h->nh, h->d_level_off, levels, n, h->nh_frame_block);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else
         for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
     if (halo && !rc) {

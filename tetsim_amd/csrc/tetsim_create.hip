@@ -583,6 +583,20 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             h->cluster_launch.push_back(L);
         }
     }
+    // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle fits one CU's LDS (40 B each)
+    // and tetsim_step_n runs a whole call as ONE single-workgroup launch (nh_kernels.inc: nh_frame_kernel); tetsim_step and
+    // tetsim_profile keep the level kernels, whose arithmetic it shares.  TETSIM_NH_FRAME=0: never (development A/B).
+    static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
+    if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 &&
+        static_cast<uint64_t>(nv) * 40u <= (h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise())) {
+        uint32_t widest = 0;
+        for (uint32_t l = 0; l < nl; l++) widest = std::max(widest, h->level_off[l + 1] - h->level_off[l]);
+        h->nh_frame_block = std::min(512u, std::max(256u, (widest + 63u) / 64u * 64u));
+        if ((rc = dev_alloc(h, &h->d_level_off, h->level_off.size()))) return rc;
+        if ((rc = upload(h, h->d_level_off, h->level_off))) return rc;
+        h->nh_frame = true;
+        h->info.fused_particle_pass = 4u;
+    }
     return 0;
 }
 
