@@ -1,8 +1,8 @@
-"""Small Neo-Hookean bodies (BASELINE config 1: the Dragon through the reference's CPU algorithm): tetsim_step_n runs a whole call as ONE
-single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel, TetSimInfo.fused_particle_pass == 4).  Its contract:
-a call of n substeps equals n tetsim_step calls (one launch per level) BIT FOR BIT in both arithmetics -- positions, velocities,
-previous positions, volError -- and therefore the reference's Softbody.js where the level kernels do (tests/test_gpu_neohookean.py
-runs its golden hashes through this kernel)."""
+"""Small Neo-Hookean bodies (BASELINE config 1: the Dragon through the reference's CPU algorithm): tetsim_step_n and tetsim_step run a
+whole call as ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel, TetSimInfo.fused_particle_pass
+== 4).  Its contract: a call of n substeps equals n calls of one substep and equals the level kernels (one launch per level, what
+tetsim_profile steps with) BIT FOR BIT in both arithmetics -- positions, velocities, previous positions, volError -- and therefore
+the reference's Softbody.js where the level kernels do (tests/test_gpu_neohookean.py runs its golden hashes through this kernel)."""
 import numpy as np
 import pytest
 
@@ -25,19 +25,23 @@ def test_one_launch_per_call_equals_one_launch_per_level(order, precision):
     v = v - np.float32([0.0, v[:, 1].min() - 0.003, 0.0])      # 3 mm above the floor: contact and friction from the second frame on
     a = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order=order, precision=precision)
     b = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order=order, precision=precision)
+    c = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order=order, precision=precision)
     assert a.info.fused_particle_pass == 4
     for k, n in enumerate((10, 1, 3, 10, 7)):
         if k == 1:
-            for body in (a, b):
+            for body in (a, b, c):
                 body.setGrab(100, [0.1, 0.9, -0.1])
         if k == 3:
-            for body in (a, b):
+            for body in (a, b, c):
                 body.endGrab()
-        a.simulateSubsteps(n, DT, PP)
+        a.simulateSubsteps(n, DT, PP)          # one launch for the n substeps
         for _ in range(n):
-            b.simulate(DT, PP)
-        assert _same(a.pos, b.pos) and _same(a.vel, b.vel) and _same(a.prevPos, b.prevPos), (k, n)
-        assert a.volError == b.volError, (k, n)
+            b.simulate(DT, PP)                 # one launch per substep
+        pr = c.profile(n, DT, PP)              # the level kernels: one launch per level, a prediction and a particle pass per substep
+        assert pr["tet_launches"] == n * c.info.num_levels
+        for other in (b, c):
+            assert _same(a.pos, other.pos) and _same(a.vel, other.vel) and _same(a.prevPos, other.prevPos), (k, n)
+            assert a.volError == other.volError, (k, n)
     assert np.isfinite(a.pos).all() and a.pos[:, 1].min() == 0.0
 
 

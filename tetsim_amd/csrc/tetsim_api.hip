@@ -533,6 +533,15 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
+    if (h->nh_frame) {
+        // small Neo-Hookean bodies: also a single substep is ONE single-workgroup launch (a host that keeps the reference's loop,
+        // main.js:79-84, pays one enqueue per substep instead of one per level: 34 on the Dragon); tetsim_profile keeps the level kernels
+        const uint32_t levels = static_cast<uint32_t>(h->level_off.size() - 1);
+        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->d_level_off, levels, 1u, h->nh_frame_block)
+                : nh_launch_frame_precise(h->stream, h->nh, h->d_level_off, levels, 1u, h->nh_frame_block);
+        const hipError_t le = hipGetLastError();
+        return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    }
     rc = enqueue_substep(h);
     if (!rc) rc = flush_v(h);
     return rc;

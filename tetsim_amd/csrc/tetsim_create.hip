@@ -584,8 +584,8 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         }
     }
     // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle fits one CU's LDS (40 B each)
-    // and tetsim_step_n runs a whole call as ONE single-workgroup launch (nh_kernels.inc: nh_frame_kernel); tetsim_step and
-    // tetsim_profile keep the level kernels, whose arithmetic it shares.  TETSIM_NH_FRAME=0: never (development A/B).
+    // and tetsim_step_n / tetsim_step run a whole call as ONE single-workgroup launch (nh_kernels.inc: nh_frame_kernel);
+    // tetsim_profile keeps the level kernels, whose arithmetic it shares.  TETSIM_NH_FRAME=0: never (development A/B).
     static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
     if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 &&
         static_cast<uint64_t>(nv) * 40u <= (h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise())) {
