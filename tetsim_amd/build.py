@@ -49,7 +49,10 @@ UNITS = {
     "nh_precise.hip": ["-ffp-contract=off"],
     # kernarg preload: the four-lane cluster kernel's leading scalar arguments (ids, particles, mask, count) arrive in SGPRs with the
     # wave instead of through a scalar load at the head of every colour's chain: 66.8 -> 65.4 us per substep (profiles/r03_neohookean.txt)
-    "nh_fast.hip": ["-ffp-contract=fast", "-mllvm", "-amdgpu-kernarg-preload-count=9"],
+    # contract=on, not fast: with fast the BACKEND fuses any multiply with any add it finds, whatever `#pragma clang fp contract` says, and
+    # picks the pairs by the surrounding code -- kernels that share their arithmetic (a body's fused launch and its stepwise twin) then
+    # round differently in one tet out of a few hundred.  on = only a * b + c written as one expression (or fmaf) fuses.
+    "nh_fast.hip": ["-ffp-contract=on", "-mllvm", "-amdgpu-kernarg-preload-count=9"],
     "util_kernels.hip": ["-ffp-contract=off"],
     "skin_kernels.hip": ["-ffp-contract=off"],
     "build_info.cpp": ["-x", "hip"],

@@ -172,7 +172,9 @@ void nh_sweep(tetsim_body* h, bool fold) {
     }
     for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
         const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-        h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        // (small FAST bodies, narrow levels: the four-lane level kernel, the stepwise twin of their single-workgroup launch -- nh_kernels.inc)
+        if (h->nh_frame && h->fast && count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, h->nh, first, count);
+        else h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
     }
 }
 

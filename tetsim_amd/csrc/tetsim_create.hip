@@ -589,9 +589,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
     if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 &&
         static_cast<uint64_t>(nv) * 40u <= (h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise())) {
-        uint32_t widest = 0;
-        for (uint32_t l = 0; l < nl; l++) widest = std::max(widest, h->level_off[l + 1] - h->level_off[l]);
-        h->nh_frame_block = std::min(512u, std::max(256u, (widest + 63u) / 64u * 64u));
+        h->nh_frame_block = 512u;   // 128 quads for the narrow levels (kNHQuadLevel), one lane per tet for the wide ones; wider than 512: several trips
         if ((rc = dev_alloc(h, &h->d_level_off, h->level_off.size()))) return rc;
         if ((rc = upload(h, h->d_level_off, h->level_off))) return rc;
         h->nh_frame = true;
