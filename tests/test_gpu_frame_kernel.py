@@ -91,6 +91,25 @@ def test_large_bodies_keep_one_kernel_per_substep():
     assert body.info.fused_particle_pass == 1
 
 
+def test_many_independent_small_bodies_step_concurrently():
+    """Every body has its own stream, and a persistent frame kernel needs all its workgroups resident at once: launches of DIFFERENT
+    bodies that overlap on the device must not starve each other (the dispatcher hands out workgroups kernel by kernel; 40 bodies x 100
+    substeps per call and 24 x 400 were run the same way on the builder's box: no wait ever gave up).  Twelve Dragons stepped round-robin
+    without synchronising equal a Dragon stepped alone, bit for bit, and stay on the four-lane path."""
+    v, t = load_mesh("dragon")
+    v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])
+    solo = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    many = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast") for _ in range(12)]
+    for _ in range(30):
+        for b in many:
+            b.simulateSubsteps(20, DT, PP)
+    for _ in range(30):
+        solo.simulateSubsteps(20, DT, PP)
+    ref = solo.pos
+    for b in many:
+        assert _same(b.pos, ref) and b.info.fused_particle_pass == 3
+
+
 def _wheel(spokes):
     """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
     ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)
