@@ -110,6 +110,32 @@ def test_many_independent_small_bodies_step_concurrently():
         assert _same(b.pos, ref) and b.info.fused_particle_pass == 3
 
 
+def test_bodies_of_more_than_half_the_device_take_turns():
+    """A body whose tiles need MORE than half the device's resident workgroups (131,712 tets = 515 tiles of 768) still runs a call as one
+    persistent launch, equal to its stepwise kernels bit for bit; while it lives, the persistent launches of the device's bodies take
+    turns: two such bodies and a Dragon stepped round-robin without synchronising equal the same bodies stepped alone."""
+    v, t = make_lattice(28, y0=0.02)
+    dv, dt_ = load_mesh("dragon")
+    big = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast") for _ in range(3)]
+    dragons = [SoftBodyHIP(dv, dt_, None, dict(PP), solver="polar", precision="fast") for _ in range(2)]
+    assert all(b.info.fused_particle_pass == 2 for b in big) and all(d.info.fused_particle_pass == 3 for d in dragons)
+    for n in (20, 3, 20, 20):
+        big[0].simulateSubsteps(n, DT, PP)
+        for _ in range(n):
+            big[1].simulate(DT, PP)
+    assert _same(big[0].pos, big[1].pos) and _same(big[0].quats, big[1].quats)
+    for _ in range(10):                      # interleaved, no synchronisation in between
+        big[1].simulateSubsteps(20, DT, PP)
+        dragons[0].simulateSubsteps(20, DT, PP)
+        big[2].simulateSubsteps(20, DT, PP)
+    for _ in range(10):
+        big[0].simulateSubsteps(20, DT, PP)
+        dragons[1].simulateSubsteps(20, DT, PP)
+    big[2].simulateSubsteps(63, DT, PP)      # (catches up with the 63 substeps the other two did first)
+    assert _same(big[0].pos, big[1].pos) and _same(big[0].pos, big[2].pos) and _same(dragons[0].pos, dragons[1].pos)
+    assert all(b.info.fused_particle_pass == 2 for b in big)
+
+
 def _wheel(spokes):
     """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
     ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)

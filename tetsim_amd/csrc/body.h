@@ -187,6 +187,8 @@ struct tetsim_body {
     int32_t* d_block_tile = nullptr;  // [frame_blocks] tile of every block of the frame kernel's grid, -1 = none
     uint32_t frame_blocks = 0;
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
+    bool frame_turn_counted = false;  // this body is in its device's count of exclusive bodies
+    bool frame_exclusive = false;     // needs MORE than half the device's resident workgroups: persistent launches of this device take turns (tetsim_api.hip: FrameTurn)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     size_t partial_slots = 0;         // float4s in each of the two
     float4* pos_final_b = nullptr;    // second buffer of the end-of-substep positions (a call always ENDS in pj.pos_final)

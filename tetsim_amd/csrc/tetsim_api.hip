@@ -1,6 +1,8 @@
 // tetsim_api.hip -- C ABI of libtetsim_hip.so, part 1 (include/tetsim.h): handle lifecycle and stepping (stream / graph
 // orchestration of the gfx950 kernels).  State read-back: tetsim_state.hip; visual mesh and grab: tetsim_visual.hip;
 // measurement: tetsim_measure.hip.  See body.h for all translation units.
+#include <mutex>
+
 #include "body.h"
 
 using namespace tetsim;
@@ -177,6 +179,18 @@ void nh_sweep(tetsim_body* h, bool fold) {
         else h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
     }
 }
+
+// Persistent frame kernels need every workgroup of their grid resident at once.  Bodies of at most half the device's slots fit side
+// by side; once a body that needs MORE lives on a device (`frame_exclusive`), the frame launches of that device's bodies take turns:
+// a launch waits for the previous one (of another body) to finish.  Nothing happens, and nothing is paid, without such a body.
+struct FrameTurn {
+    std::mutex m;
+    hipEvent_t done = nullptr;       // recorded behind the last frame launch on this device
+    const tetsim_body* last = nullptr;
+    int exclusive_bodies = 0;
+};
+FrameTurn g_frame_turn[64];
+FrameTurn& frame_turn(const tetsim_body* h) { return g_frame_turn[h->opt.device & 63]; }
 
 // one substep's launches (parameters already on the device)
 // first / last: position inside a run of substeps enqueued back to back with one dt (NEOHOOKEAN_GS fuses the particle pass
@@ -502,6 +516,12 @@ void tetsim_destroy(tetsim_handle h) {
             }
     }
 #endif
+    {
+        FrameTurn& t = frame_turn(h);
+        std::lock_guard<std::mutex> lock(t.m);
+        if (h->frame_turn_counted) t.exclusive_bodies--;
+        if (t.last == h) t.last = nullptr;   // (its stream is drained: nothing to wait for)
+    }
     // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
@@ -607,6 +627,19 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
             return rc;
         }
         it = h->graphs.emplace(n, exec).first;
+    }
+    if (h->frame) {
+        FrameTurn& t = frame_turn(h);
+        std::lock_guard<std::mutex> lock(t.m);
+        if (h->frame_exclusive && !h->frame_turn_counted) { t.exclusive_bodies++; h->frame_turn_counted = true; }
+        if (t.exclusive_bodies > 0) {
+            if (t.done && t.last && t.last != h) HIPCHK(h, hipStreamWaitEvent(h->stream, t.done, 0));
+            HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+            if (!t.done) HIPCHK(h, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(t.done, h->stream));
+            t.last = h;
+            return 0;
+        }
     }
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return 0;

@@ -312,7 +312,12 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const uint32_t per_cu = !allow_frame ? 0u : h->quad ? pjq_frame_capacity(&cus) : pjb_frame_capacity(k.lean, &cus);
             const uint32_t nbk = B.num_blocks;
             std::vector<int32_t> block_tile;
-            if (per_cu != 0u && nbk != 0u && nbk <= per_cu * cus / 2u) {
+            // Up to HALF the device's resident workgroups two such bodies fit side by side whatever the dispatcher does.  A body that
+            // needs more (up to all of them: 100 k-200 k tets) still takes the persistent launch -- 6.9 against 9.0 us per substep at
+            // 131 k tets, 7.5 against 9.6 at 197 k -- but is `exclusive`: while one lives on a device, the persistent launches of ALL
+            // bodies of that device take turns (tetsim_step_n), so that two of them are never half resident next to each other.
+            if (per_cu != 0u && nbk != 0u && nbk <= per_cu * cus) {
+                h->frame_exclusive = nbk > per_cu * cus / 2u;
                 static const bool allow_local = [] { const char* e = getenv("TETSIM_FRAME_LOCAL"); return !(e && e[0] == '0'); }();
                 static int xcd_rule[64] = {};   // per device: 0 = not probed, 1 = round-robin over 8 XCDs verified, 2 = no
                 int& rule = xcd_rule[o.device & 63];
