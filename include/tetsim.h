@@ -157,7 +157,7 @@ typedef struct TetSimInfo {
                                      use the per-substep kernels, whose results are the same bit for bit.
                                      3: as 2, on 64-tet tiles with one tet and one particle on FOUR lanes (pj_quad.hip: the default for
                                      small carried-rest-shape bodies); tetsim_step / tetsim_profile run the same substep as two launches
-                                     4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles: they all
+                                     4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles (PRECISE: and 12,288 tets): they all
                                      fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE single-workgroup launch
                                      (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit */
 } TetSimInfo;

@@ -56,5 +56,7 @@ def test_which_bodies_take_it():
     for _ in range(12):
         b.simulate(DT, PP)
     assert _same(a.pos, b.pos) and _same(a.vel, b.vel) and a.volError == b.volError
+    # PRECISE stops at 12,288 tets (f64 on one CU is throughput-bound beyond): the same 20,250-tet body keeps one launch per level
+    assert SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured", precision="precise").info.fused_particle_pass == 0
     v, t = make_lattice(16)      # 4,913 particles: one launch per level
     assert SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured", precision="fast").info.fused_particle_pass == 0

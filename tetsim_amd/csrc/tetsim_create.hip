@@ -592,7 +592,10 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     // and tetsim_step_n / tetsim_step run a whole call as ONE single-workgroup launch (nh_kernels.inc: nh_frame_kernel);
     // tetsim_profile keeps the level kernels, whose arithmetic it shares.  TETSIM_NH_FRAME=0: never (development A/B).
     static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
-    if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 &&
+    // (PRECISE: up to 12 k tets -- f64 at half rate on ONE CU is throughput-bound beyond that: 157 us per substep at 20 k tets against
+    // 117 with one launch per level, 92 against ~115 at 10 k; FAST stays ahead up to the LDS limit: 60 against 87 us at 20 k tets --
+    // tools/nh_size_sweep.py)
+    if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 && (h->fast || nt <= 12288u) &&
         static_cast<uint64_t>(nv) * 40u <= (h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise())) {
         h->nh_frame_block = 512u;   // 128 quads for the narrow levels (kNHQuadLevel), one lane per tet for the wide ones; wider than 512: several trips
         if ((rc = dev_alloc(h, &h->d_level_off, h->level_off.size()))) return rc;

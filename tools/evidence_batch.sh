@@ -39,5 +39,6 @@ timeout 120 python tools/frame_trace.py 20 > "$OUT/frame_trace.txt" 2>&1
 timeout 300 python tools/dragon_time.py > "$OUT/dragon.txt" 2>&1
 timeout 300 python tools/nh_time.py 55 clustered > "$OUT/nh_time.txt" 2>&1
 timeout 400 python tools/size_sweep.py > "$OUT/size_sweep.txt" 2>&1
+timeout 400 python tools/nh_size_sweep.py > "$OUT/nh_size_sweep.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head
 tail -3 "$OUT/pytest_calibration.log"; tail -6 "$OUT/pytest_with_table.log"; tail -12 "$OUT/mutation.txt"; head -c 600 "$OUT/bench.json"
