@@ -186,6 +186,8 @@ struct tetsim_body {
     uint32_t* d_frame_err = nullptr;  // raised by a tile whose neighbour's partial sums never arrived (bounded wait)
     int32_t* d_block_tile = nullptr;  // [frame_blocks] tile of every block of the frame kernel's grid, -1 = none
     uint32_t frame_blocks = 0;
+    DevParams params_on_device;       // what d_params holds (valid while params_known)
+    bool params_known = false;
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     bool frame_turn_counted = false;  // this body is in its device's count of exclusive bodies
     bool frame_exclusive = false;     // needs MORE than half the device's resident workgroups: persistent launches of this device take turns (tetsim_api.hip: FrameTurn)
@@ -298,7 +300,9 @@ inline int upload(tetsim_body* h, Tp* dst, const std::vector<Tp>& src) {
 // SoftbodyGPU.js:335-338,345: texel (px,py) of the R x R position texture is pinned when
 
 void ref_grab_texels(int32_t grab_id, uint32_t num_elems, uint32_t num_particles, int32_t out[2]);
-int push_params(tetsim_body* h, double dt, const TetSimParams* params);
+// reuse_ok: the caller's kernels do not need a fresh block of sequence numbers (tetsim_step) -- if the parameters equal what the device
+// already holds, nothing is uploaded
+int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reuse_ok = false);
 
 // Development: TETSIM_DEBUG_HOSTPROF=1 accumulates the host time of every call in the eager halo path, printed at destroy.
 struct HostProf {

@@ -84,10 +84,18 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
 }
 
 // Stage the parameters of this call into a pinned ring slot and copy them to the device in stream order.
-int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
+int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reuse_ok) {
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
     HIPCHK(h, hipSetDevice(h->opt.device));  // group stepping walks over handles that may live on different devices
+    if (reuse_ok && h->params_known && !h->comm_stream && !h->partitioned) {   // (a halo queue keeps a copy of its own: always refreshed)
+        // A host that keeps the reference's loop (main.js:79-84: simulate(dt, physicsParams) per substep) sends the same numbers again
+        // and again: the copy and its event are most of what such a call costs (22 -> 12 us per tetsim_step on the Dragon).
+        DevParams now;
+        fill_params(h, dt, *params, &now);
+        now.epoch = h->params_on_device.epoch;
+        if (std::memcmp(&now, &h->params_on_device, sizeof now) == 0) { h->fork_needed = true; return 0; }
+    }
     const int slot = h->ring_pos;
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
@@ -106,6 +114,8 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params) {
     h->frame_epoch += 65536u;
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
+    h->params_on_device = h->h_ring[slot];
+    h->params_known = true;
     HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
     if (h->comm_stream && h->d_params_halo) {
@@ -552,7 +562,7 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (!h) return TETSIM_EINVAL;
     if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     HIPCHK(h, hipSetDevice(h->opt.device));
-    int rc = push_params(h, dt, params);
+    int rc = push_params(h, dt, params, true);   // (a single substep never runs a kernel that numbers its partial sums)
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
     if (h->nh_frame) {
