@@ -153,10 +153,11 @@ typedef struct TetSimInfo {
     uint32_t fused_particle_pass; /* 1: tetsim_step_n runs ONE kernel per substep (particle update fused into the tet kernel's staging,
                                      HISTORY.md 5.4: unpartitioned POLAR_JACOBI + FAST blocked bodies); tetsim_profile then times that kernel.
                                      2: ... and the body is small enough for tetsim_step_n to run ONE persistent kernel per CALL (every
-                                     tile's workgroup resident for all n substeps); tetsim_step / tetsim_profile still
-                                     use the per-substep kernels, whose results are the same bit for bit.
+                                     tile's workgroup resident for all n substeps); tetsim_profile still
+                                     uses the per-substep kernels, whose results are the same bit for bit.
                                      3: as 2, on 64-tet tiles with one tet and one particle on FOUR lanes (pj_quad.hip: the default for
-                                     small carried-rest-shape bodies); tetsim_step / tetsim_profile run the same substep as two launches
+                                     small carried-rest-shape bodies); tetsim_profile runs the same substep as two launches.  (2 and 3:
+                                     tetsim_step is the persistent kernel for ONE substep -- one launch per call.)
                                      4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles (PRECISE: and 12,288 tets): they all
                                      fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE single-workgroup launch
                                      (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit */

@@ -1,7 +1,8 @@
 """The persistent frame kernel (pj_blocked.hip: pjb_frame_kernel): small unpartitioned FAST bodies run a whole
 tetsim_step_n call as ONE launch -- every tile's workgroup resident for all n substeps, tet records and particles in registers,
 tile partial sums exchanged through memory with the substep's sequence number in the fourth float.  Its contract: a call of n
-substeps equals n tetsim_step calls (one tet and one particle kernel each) BIT FOR BIT, whatever n, and across calls."""
+substeps equals n tetsim_step calls (the same kernel for one substep) and equals the stepwise kernels (one tet and one particle kernel
+per substep: what tetsim_profile steps with) BIT FOR BIT, whatever n, and across calls."""
 import numpy as np
 import pytest
 
@@ -32,13 +33,17 @@ def test_frame_kernel_equals_stepwise_kernels_bit_for_bit(kw):
     v, t = load_mesh("dragon")
     v = v - np.float32([0.0, v[:, 1].min() - 0.01, 0.0])      # start just above the floor: contact and friction from the first frame
     a, b = _pair(v, t, **kw)
+    c = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
     total = 0
     for n in (20, 1, 2, 7, 20, 20, 33):          # odd and even counts: the partial-sum buffers alternate by substep parity
-        a.simulateSubsteps(n, DT, PP)
+        a.simulateSubsteps(n, DT, PP)            # one persistent launch for the n substeps
         for _ in range(n):
-            b.simulate(DT, PP)
+            b.simulate(DT, PP)                   # one persistent launch per substep (tetsim_step)
+        pr = c.profile(n, DT, PP)                # the stepwise kernels: a tet and a particle kernel per substep (256-tet tiles: tet | fused x (n - 1) | particle)
+        assert pr["substeps"] == n and pr["tet_launches"] + pr["vertex_launches"] >= n
         total += n
-        assert _same(a.pos, b.pos) and _same(a.vel, b.vel) and _same(a.quats, b.quats), "after %d substeps (last call: %d)" % (total, n)
+        for other in (b, c):
+            assert _same(a.pos, other.pos) and _same(a.vel, other.vel) and _same(a.quats, other.quats), "after %d substeps (last call: %d)" % (total, n)
     assert a.pos[:, 1].min() < 0.02             # the Dragon has landed: floor contact and friction were exercised
 
 

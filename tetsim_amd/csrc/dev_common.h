@@ -88,6 +88,7 @@ struct PJBlk {
     uint32_t n_ghost1 = 0xffffffffu;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
     float rot_exit_w2 = 1.0e-18f;            // squared |omega| that ends a tet's correction iterations 2..9 (pj_math.inc; 1e-18 = the reference's 1e-9)
+    uint32_t epoch = 0;                      // persistent frame kernels: first sequence number of this launch; 0 = DevParams::epoch (graph launches: tetsim_step_n)
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
     unsigned long long* iter_hist = nullptr; // development (ablation build): rotation-iteration statistics, TETSIM_DEBUG_ITER_HIST (pj_blocked.hip: pjb_log_iterations)
 };

@@ -496,7 +496,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
     const float wsum = d.wsum[vid];
     f3 stage = xyz(d.pos_pred[vid]);     // substep 0 starts from the prediction the previous call left
     const DevParams& P = *d.params;
-    const uint32_t epoch = P.epoch;
+    const uint32_t epoch = d.epoch ? d.epoch : P.epoch;   // (a direct launch -- tetsim_step -- brings its own block of sequence numbers)
     const uint32_t first = range & 0x7ffu, last = range >> 16;
     const bool owner = has_slot && ((range >> 15) & 1u);
     float4* const pbuf[2] = {pbuf0, pbuf1};

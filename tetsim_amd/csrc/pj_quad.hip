@@ -243,7 +243,7 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
     if constexpr (kMode != kModeTet) { prev = comp(d.pos_final[vid], c); wsum = d.wsum[vid]; }
     if constexpr (kMode != kModeVertex) stage = comp(d.pos_pred[vid], c);   // substep 0 starts from the prediction the previous call left
     const QParams qp = load_qparams(P, c);
-    const uint32_t epoch = P.epoch;
+    const uint32_t epoch = d.epoch ? d.epoch : P.epoch;   // (a direct launch -- tetsim_step -- brings its own block of sequence numbers)
     const int32_t poll_delay = P.poll_delay;
     const uint32_t first = range & 0x7ffu, last = range >> 16;
     const bool owner = has_slot && ((range >> 15) & 1u);

@@ -83,6 +83,22 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
     o->d_vol_compliance = p.volCompliance;
 }
 
+// A fresh block of 65,536 sequence numbers for the partial sums of a persistent frame kernel (h->frame_epoch + the substep's index
+// inside the launch; tetsim_step_n chunks longer calls): stale sums of an earlier launch never match.  Before the 32-bit counter wraps
+// -- 65,535 blocks, minutes at interactive rates -- the numbers left in both buffers are wiped (in stream order, behind every kernel
+// that reads them) and the count restarts: a sum of 65,536 launches ago can never pass for a fresh one.
+int next_epoch_block(tetsim_body* h) {
+    if (h->frame_epoch >= 0xfffe0000u) {
+        if (h->partial_b && h->partial_slots) {
+            HIPCHK(h, hipMemsetAsync(h->blk.partial, 0, h->partial_slots * sizeof(float4), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->partial_b, 0, h->partial_slots * sizeof(float4), h->stream));
+        }
+        h->frame_epoch = 1u;
+    }
+    h->frame_epoch += 65536u;
+    return 0;
+}
+
 // Stage the parameters of this call into a pinned ring slot and copy them to the device in stream order.
 int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reuse_ok) {
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
@@ -100,18 +116,7 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     h->ring_pos = (h->ring_pos + 1) % kRing;
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
     if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
-    // every call gets a fresh block of 65,536 sequence numbers for the partial sums of the frame kernel (DevParams::epoch + the substep's
-    // index inside the call; tetsim_step_n chunks longer calls): stale sums of an earlier call never match.  Before the 32-bit
-    // counter wraps -- 65,535 pushes, minutes at interactive rates -- the numbers left in both buffers are wiped (in stream order,
-    // behind every kernel that reads them) and the count restarts: a sum of 65,536 calls ago can never pass for a fresh one.
-    if (h->frame_epoch >= 0xfffe0000u) {
-        if (h->partial_b && h->partial_slots) {
-            HIPCHK(h, hipMemsetAsync(h->blk.partial, 0, h->partial_slots * sizeof(float4), h->stream));
-            HIPCHK(h, hipMemsetAsync(h->partial_b, 0, h->partial_slots * sizeof(float4), h->stream));
-        }
-        h->frame_epoch = 1u;
-    }
-    h->frame_epoch += 65536u;
+    if (int rc = next_epoch_block(h)) return rc;
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     h->params_on_device = h->h_ring[slot];
@@ -201,6 +206,29 @@ struct FrameTurn {
 };
 FrameTurn g_frame_turn[64];
 FrameTurn& frame_turn(const tetsim_body* h) { return g_frame_turn[h->opt.device & 63]; }
+// `launch` puts a persistent frame kernel of body h into h->stream (a graph replay or a direct launch); its turn is taken first if needed
+template <class F>
+int launch_in_turn(tetsim_body* h, F&& launch) {
+    FrameTurn& t = frame_turn(h);
+    std::lock_guard<std::mutex> lock(t.m);
+    if (h->frame_exclusive && !h->frame_turn_counted) { t.exclusive_bodies++; h->frame_turn_counted = true; }
+    if (t.exclusive_bodies == 0) return launch();
+    if (t.done && t.last && t.last != h) HIPCHK(h, hipStreamWaitEvent(h->stream, t.done, 0));
+    if (int rc = launch()) return rc;
+    if (!t.done) HIPCHK(h, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(t.done, h->stream));
+    t.last = h;
+    return 0;
+}
+// the persistent frame kernel of a small polar body for n substeps; epoch 0 = the block DevParams::epoch names (graph capture)
+int launch_frame_kernel(tetsim_body* h, uint32_t n, uint32_t epoch) {
+    PJBlk k = h->blk;
+    k.epoch = epoch;
+    if (h->quad) pjq_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+    else pjb_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+    const hipError_t le = hipGetLastError();
+    return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+}
 
 // one substep's launches (parameters already on the device)
 // first / last: position inside a run of substeps enqueued back to back with one dt (NEOHOOKEAN_GS fuses the particle pass
@@ -294,10 +322,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
     if (h->frame) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
-        if (h->quad) pjq_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
-        else pjb_launch_frame(h->stream, h->blk, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        rc = launch_frame_kernel(h, n, 0u);
     } else if (h->nh_frame) {
         // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
         const uint32_t levels = static_cast<uint32_t>(h->level_off.size() - 1);
@@ -574,6 +599,13 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
         const hipError_t le = hipGetLastError();
         return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     }
+    if (h->frame) {
+        // small polar bodies: a single substep is ONE launch too -- the persistent frame kernel for n = 1, with a block of sequence
+        // numbers of its own as a kernel argument (the parameters on the device may be the previous call's: see push_params)
+        if ((rc = next_epoch_block(h))) return rc;
+        const uint32_t epoch = h->frame_epoch;
+        return launch_in_turn(h, [&]() -> int { return launch_frame_kernel(h, 1u, epoch); });
+    }
     rc = enqueue_substep(h);
     if (!rc) rc = flush_v(h);
     return rc;
@@ -638,19 +670,8 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         }
         it = h->graphs.emplace(n, exec).first;
     }
-    if (h->frame) {
-        FrameTurn& t = frame_turn(h);
-        std::lock_guard<std::mutex> lock(t.m);
-        if (h->frame_exclusive && !h->frame_turn_counted) { t.exclusive_bodies++; h->frame_turn_counted = true; }
-        if (t.exclusive_bodies > 0) {
-            if (t.done && t.last && t.last != h) HIPCHK(h, hipStreamWaitEvent(h->stream, t.done, 0));
-            HIPCHK(h, hipGraphLaunch(it->second, h->stream));
-            if (!t.done) HIPCHK(h, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-            HIPCHK(h, hipEventRecord(t.done, h->stream));
-            t.last = h;
-            return 0;
-        }
-    }
+    if (h->frame)
+        return launch_in_turn(h, [&]() -> int { HIPCHK(h, hipGraphLaunch(it->second, h->stream)); return 0; });
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return 0;
 }
