@@ -22,8 +22,8 @@
 //   pjq_frame_kernel    one launch per tetsim_step_n call: every tile's workgroup stays resident for the n substeps, tet and
 //                       particle state in registers, the tile partial sums carry the substep's sequence number in their fourth
 //                       float and are exchanged without a barrier (the choreography of pjb_frame_kernel, pj_blocked.hip);
-//   pjq_tet_kernel, pjq_vertex_kernel    the same substep as two launches through memory: tetsim_step, tetsim_profile, and what a
-//                       body falls back to if a frame kernel's bounded wait ever gives up.
+//   pjq_tet_kernel, pjq_vertex_kernel    the same substep as two launches through memory: tetsim_profile, and what a body falls back
+//                       to if a frame kernel's bounded wait ever gives up (tetsim_step is the frame kernel for n = 1).
 // Differences from the other FAST formulations are summation order only (64-tet tiles, component-wise sums): tolerance level.
 #include <cstdint>
 
