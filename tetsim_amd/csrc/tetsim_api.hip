@@ -106,7 +106,8 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     HIPCHK(h, hipSetDevice(h->opt.device));  // group stepping walks over handles that may live on different devices
     if (reuse_ok && h->params_known && !h->comm_stream && !h->partitioned) {   // (a halo queue keeps a copy of its own: always refreshed)
         // A host that keeps the reference's loop (main.js:79-84: simulate(dt, physicsParams) per substep) sends the same numbers again
-        // and again: the copy and its event are most of what such a call costs (22 -> 12 us per tetsim_step on the Dragon).
+        // and again: the copy and its event were most of what such a call cost (22.5 -> 7.8 us per tetsim_step on the Dragon,
+        // profiles/r04_step_call_cost.txt).
         DevParams now;
         fill_params(h, dt, *params, &now);
         now.epoch = h->params_on_device.epoch;
@@ -587,7 +588,7 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (!h) return TETSIM_EINVAL;
     if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     HIPCHK(h, hipSetDevice(h->opt.device));
-    int rc = push_params(h, dt, params, true);   // (a single substep never runs a kernel that numbers its partial sums)
+    int rc = push_params(h, dt, params, true);   // (unchanged parameters stay where they are; a frame kernel launched below brings its own sequence numbers)
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
     if (h->nh_frame) {
