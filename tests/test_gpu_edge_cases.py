@@ -215,19 +215,22 @@ def test_state_blob_of_another_mesh_with_the_same_counts_is_rejected():
         d.loadState(c.saveState())        # the density is part of what the blob belongs to (inverse masses)
 
 
-def test_collapsed_tet_does_not_poison_the_fast_clustered_sweep():
+@pytest.mark.parametrize("order,cells", [("clustered", 3), ("coloured", 3), ("coloured", 17)])
+def test_collapsed_tet_does_not_poison_the_fast_sweeps(order, cells):
     """A tet whose four corners coincide has tr(F^T F) = 0: Softbody.js leaves it alone (C == 0 returns early, :176); the FAST
-    four-lane kernel's rsq(0) * 0 must not turn that into NaN positions."""
-    v, t = make_lattice(3, y0=0.3)
-    v = v.copy()
-    cell0 = np.unique(t[:6].ravel())
-    # collapse ALL of the first tet's corners onto one point, in the current positions only (the rest pose stays regular)
-    body = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order="clustered")
+    kernels' rsq(0) * 0 must not turn that into NaN positions -- the four-lane cluster kernel, the single-workgroup launch of small
+    bodies (one lane and four lanes per tet) and the level kernels of larger ones (17^3 cells: 5,832 particles)."""
+    v, t = make_lattice(cells, y0=0.3)
+    # collapse ALL of one tet's corners onto one point, in the current positions only (the rest pose stays regular)
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order=order)
     pos = body.pos
-    pos[t[body.tetOrder[0]]] = pos[t[body.tetOrder[0], 0]]
+    for k in (0, len(t) - 1):      # the first of the sweep (a wide level) and the last (a narrow one)
+        pos[t[body.tetOrder[k]]] = pos[t[body.tetOrder[k], 0]]
     body.writeState(pos, np.zeros_like(pos))
     body.simulateSubsteps(3, DT, PP)
-    assert np.isfinite(body.pos).all() and len(cell0) == 8
+    assert np.isfinite(body.pos).all()
+    body.simulate(DT, PP)
+    assert np.isfinite(body.pos).all()
 
 
 def test_neohookean_save_load_state():
