@@ -159,7 +159,7 @@ typedef struct TetSimInfo {
                                      small carried-rest-shape bodies); tetsim_profile runs the same substep as two launches.  (2 and 3:
                                      tetsim_step is the persistent kernel for ONE substep -- one launch per call.)
                                      4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles (PRECISE: and 12,288 tets): they all
-                                     fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE single-workgroup launch
+                                     fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE launch of one workgroup (one per body of a batch)
                                      (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit */
 } TetSimInfo;
 

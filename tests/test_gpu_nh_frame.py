@@ -60,3 +60,51 @@ def test_which_bodies_take_it():
     assert SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured", precision="precise").info.fused_particle_pass == 0
     v, t = make_lattice(16)      # 4,913 particles: one launch per level
     assert SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", order="coloured", precision="fast").info.fused_particle_pass == 0
+
+
+@pytest.mark.parametrize("precision", ["precise", "fast"])
+def test_batch_runs_one_workgroup_per_body(precision):
+    """tetsim_create_batch: every body of the batch gets a workgroup (and a CU's LDS) of its own in the one launch of a call.  Each body
+    equals its solo run bit for bit through tetsim_step_n and tetsim_step, and the stepwise kernels (tetsim_profile) agree with both."""
+    meshes = []
+    for name, lift in (("dragon", 0.0), ("lat4", 0.0), ("dragon", -0.3), ("lat4", 0.5)):
+        v, t = load_mesh(name)
+        meshes.append((v + np.float32([0.0, lift, 0.0]), t))
+    lv, lt = make_lattice(6, y0=0.0002)          # on the floor within the first substeps
+    meshes.append((lv, lt))
+    kw = dict(solver="neohookean", order="coloured", precision=precision)
+    batch = SoftBodyHIP.batch(meshes, dict(PP), **kw)
+    twin = SoftBodyHIP.batch(meshes, dict(PP), **kw)
+    solos = [SoftBodyHIP(v, t, None, dict(PP), **kw) for v, t in meshes]
+    assert batch.info.fused_particle_pass == 4 and batch.info.num_bodies == len(meshes)
+    for n in (10, 3):
+        for body in [batch] + solos:
+            body.simulateSubsteps(n, DT, PP)
+            body.simulate(DT, PP)
+        twin.profile(n + 1, DT, PP)
+    pos, vel = batch.pos, batch.vel
+    assert _same(pos, twin.pos) and _same(vel, twin.vel) and batch.volError == twin.volError
+    for (prange, _), solo in zip(batch.bodyRanges, solos):
+        assert _same(pos[prange[0]:prange[1]], solo.pos) and _same(vel[prange[0]:prange[1]], solo.vel)
+    assert np.isfinite(pos).all() and pos[:, 1].min() == 0.0
+
+
+def test_batch_of_dragons_throughput():
+    """The Dragon through the reference's CPU algorithm is one workgroup's chain of levels; 64 of them in one batch are 64 workgroups on 64
+    CUs: >= 20x the tet-solves/s of a single one, bit-exact arithmetic."""
+    import time
+    v, t = load_mesh("dragon")
+
+    def rate(body, frames):
+        body.simulateSubsteps(10, DT, PP); body.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            body.simulateSubsteps(10, DT, PP)
+        body.sync()
+        return body.info.num_elems * 10 * frames / (time.perf_counter() - t0)
+
+    kw = dict(solver="neohookean", order="coloured", precision="precise")
+    one = rate(SoftBodyHIP(v, t, None, dict(PP), **kw), 50)
+    many = rate(SoftBodyHIP.batch([(v, t)] * 64, dict(PP), **kw), 50)
+    print("single Dragon %.1f M tet-solves/s, 64 Dragons in one batch %.1f M (%.1fx)" % (one / 1e6, many / 1e6, many / one))
+    assert many >= 20.0 * one, (one, many)

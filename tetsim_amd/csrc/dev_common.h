@@ -137,9 +137,15 @@ void nh_launch_post_predict_fast(hipStream_t s, const NHDev& d);
 void nh_launch_cluster_precise(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
 void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch& L, bool fold = false);
 // the same pass for the particles no cluster touches (list of particle ids), when the sweeps fold the rest
-// small bodies: a whole call as one workgroup with every particle in LDS (nh_kernels.inc); `block` threads <= 512, nv * 40 bytes of LDS
-void nh_launch_frame_precise(hipStream_t s, const NHDev& d, const uint32_t* level_off, uint32_t levels, uint32_t n, uint32_t block);
-void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const uint32_t* level_off, uint32_t levels, uint32_t n, uint32_t block);
+// small bodies: a whole call as ONE workgroup per body with every particle of the body in LDS (nh_kernels.inc: nh_frame_kernel)
+struct NHFrameLaunch {
+    const uint32_t* seg = nullptr;         // [levels][bodies + 1]: per level, the first solve position of every body's tets (the last column: the level's end)
+    const uint32_t* first_vert = nullptr;  // [bodies + 1]
+    uint32_t levels = 0, bodies = 0, block = 512;   // threads per workgroup, <= 512
+    uint32_t max_body_particles = 0;       // x 40 bytes of LDS per workgroup
+};
+void nh_launch_frame_precise(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n);
+void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n);
 // levels of at most this many tets are solved on four lanes per tet by the single-workgroup launch of small bodies (and, FAST, by its
 // stepwise twin): 128 quads = two waves per SIMD in f32; f64 (PRECISE) runs at half rate, one wave per SIMD
 constexpr uint32_t kNHQuadLevelFast = 128, kNHQuadLevelPrecise = 64;

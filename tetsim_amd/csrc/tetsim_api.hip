@@ -188,11 +188,21 @@ void nh_sweep(tetsim_body* h, bool fold) {
         for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L, fold) : nh_launch_cluster_precise(h->stream, h->nh, L, fold);
         return;
     }
+    if (h->nh_frame && h->fast) {
+        // small FAST bodies: the stepwise twin of their single-workgroup launch (nh_kernels.inc) makes ITS choice for every body's
+        // piece of a level -- narrow: four lanes per tet, wide: one -- so that the two agree bit for bit
+        const uint32_t bodies = h->nh_frame_launch.bodies;
+        for (size_t l = 0; l + 1 < h->level_off.size(); l++)
+            for (uint32_t b = 0; b < bodies; b++) {
+                const uint32_t first = h->nh_seg[l * (bodies + 1u) + b], count = h->nh_seg[l * (bodies + 1u) + b + 1u] - first;
+                if (count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, h->nh, first, count);
+                else nh_launch_level_fast(h->stream, h->nh, first, count);
+            }
+        return;
+    }
     for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
         const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-        // (small FAST bodies, narrow levels: the four-lane level kernel, the stepwise twin of their single-workgroup launch -- nh_kernels.inc)
-        if (h->nh_frame && h->fast && count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, h->nh, first, count);
-        else h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
     }
 }
 
@@ -326,9 +336,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         rc = launch_frame_kernel(h, n, 0u);
     } else if (h->nh_frame) {
         // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
-        const uint32_t levels = static_cast<uint32_t>(h->level_off.size() - 1);
-        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->d_level_off, levels, n, h->nh_frame_block)
-                : nh_launch_frame_precise(h->stream, h->nh, h->d_level_off, levels, n, h->nh_frame_block);
+        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, n) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, n);
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else
@@ -594,9 +602,7 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (h->nh_frame) {
         // small Neo-Hookean bodies: also a single substep is ONE single-workgroup launch (a host that keeps the reference's loop,
         // main.js:79-84, pays one enqueue per substep instead of one per level: 34 on the Dragon); tetsim_profile keeps the level kernels
-        const uint32_t levels = static_cast<uint32_t>(h->level_off.size() - 1);
-        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->d_level_off, levels, 1u, h->nh_frame_block)
-                : nh_launch_frame_precise(h->stream, h->nh, h->d_level_off, levels, 1u, h->nh_frame_block);
+        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, 1u) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, 1u);
         const hipError_t le = hipGetLastError();
         return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     }

@@ -477,6 +477,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     prep_rest(verts, nv, ptets.data(), nt, o.density, h->h_inv_mass.data(), irp.data(), irv.data());
     // 3. dependency levels of that order; solve order = stable sort by level
     std::vector<int32_t> pos_in(nt);
+    std::vector<uint32_t> body_of;   // level schedules: the body of the tet at sequential position i (batches)
     uint32_t nl = 0;
     if (clustered) {  // the plan IS the schedule: one launch per cluster colour, storage order = step after step
         nl = static_cast<uint32_t>(plan.launch_off.size() - 1);
@@ -486,7 +487,13 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         std::vector<int32_t> level(nt);
         nl = prep_levels(ptets.data(), nt, nv, level.data());
         for (uint32_t i = 0; i < nt; i++) pos_in[i] = static_cast<int32_t>(i);
-        std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+        // (a batch: inside a level the tets lie body by body -- any order inside a level gives the sequential result, and the
+        // single-workgroup launch below walks ITS body's piece of every level)
+        body_of.assign(nt, 0);
+        if (!h->batch_first_tet.empty())
+            for (uint32_t i = 0; i < nt; i++)
+                body_of[i] = static_cast<uint32_t>(std::upper_bound(h->batch_first_tet.begin(), h->batch_first_tet.end(), static_cast<uint32_t>(pre[i])) - h->batch_first_tet.begin()) - 1u;
+        std::stable_sort(pos_in.begin(), pos_in.end(), [&](int32_t a, int32_t b) { return level[a] != level[b] ? level[a] < level[b] : body_of[a] < body_of[b]; });
         h->level_off.assign(nl + 1, 0);
         for (uint32_t i = 0; i < nt; i++) h->level_off[level[i] + 1]++;
         for (uint32_t l = 0; l < nl; l++) h->level_off[l + 1] += h->level_off[l];
@@ -588,20 +595,43 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             h->cluster_launch.push_back(L);
         }
     }
-    // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle fits one CU's LDS (40 B each)
-    // and tetsim_step_n / tetsim_step run a whole call as ONE single-workgroup launch (nh_kernels.inc: nh_frame_kernel);
-    // tetsim_profile keeps the level kernels, whose arithmetic it shares.  TETSIM_NH_FRAME=0: never (development A/B).
+    // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle of a body fits one CU's LDS (40 B
+    // each) and tetsim_step_n / tetsim_step run a whole call as ONE launch, one workgroup per body (nh_kernels.inc: nh_frame_kernel;
+    // tetsim_create_batch: every body of the batch must fit); tetsim_profile keeps the level kernels, whose arithmetic it shares.
+    // TETSIM_NH_FRAME=0: never (development A/B).
+    // (PRECISE: bodies of up to 12 k tets -- f64 at half rate on ONE CU is throughput-bound beyond that: 157 us per substep at 20 k tets
+    // against 117 with one launch per level, 92 against ~115 at 10 k; FAST stays ahead up to the LDS limit: 60 against 87 us at 20 k
+    // tets -- tools/nh_size_sweep.py)
     static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
-    // (PRECISE: up to 12 k tets -- f64 at half rate on ONE CU is throughput-bound beyond that: 157 us per substep at 20 k tets against
-    // 117 with one launch per level, 92 against ~115 at 10 k; FAST stays ahead up to the LDS limit: 60 against 87 us at 20 k tets --
-    // tools/nh_size_sweep.py)
-    if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0 && (h->fast || nt <= 12288u) &&
-        static_cast<uint64_t>(nv) * 40u <= (h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise())) {
-        h->nh_frame_block = 512u;   // 128 quads for the narrow levels (kNHQuadLevel), one lane per tet for the wide ones; wider than 512: several trips
-        if ((rc = dev_alloc(h, &h->d_level_off, h->level_off.size()))) return rc;
-        if ((rc = upload(h, h->d_level_off, h->level_off))) return rc;
-        h->nh_frame = true;
-        h->info.fused_particle_pass = 4u;
+    if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0) {
+        std::vector<uint32_t> first_vert = h->batch_first_vert, first_tet = h->batch_first_tet;
+        if (first_vert.empty()) { first_vert = {0u, nv}; first_tet = {0u, nt}; }
+        const uint32_t bodies = static_cast<uint32_t>(first_vert.size() - 1);
+        uint32_t most_v = 0, most_t = 0;
+        for (uint32_t b = 0; b < bodies; b++) { most_v = std::max(most_v, first_vert[b + 1] - first_vert[b]); most_t = std::max(most_t, first_tet[b + 1] - first_tet[b]); }
+        const uint32_t lds_limit = h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise();
+        if (most_v > 0 && static_cast<uint64_t>(most_v) * 40u <= lds_limit && (h->fast || most_t <= 12288u) && bodies <= 65535u) {
+            // per level, where every body's tets begin (solve positions; the tets of a level lie body by body)
+            std::vector<uint32_t> seg(static_cast<size_t>(nl) * (bodies + 1u));
+            for (uint32_t l = 0; l < nl; l++) {
+                uint32_t sp = h->level_off[l];
+                for (uint32_t b = 0; b <= bodies; b++) {
+                    while (b < bodies && sp < h->level_off[l + 1] && body_of[static_cast<uint32_t>(pos_in[sp])] < b) sp++;
+                    seg[static_cast<size_t>(l) * (bodies + 1u) + b] = b == bodies ? h->level_off[l + 1] : sp;
+                }
+            }
+            uint32_t *dseg = nullptr, *dfv = nullptr;
+            if ((rc = dev_alloc(h, &dseg, seg.size()))) return rc;
+            if ((rc = upload(h, dseg, seg))) return rc;
+            if ((rc = dev_alloc(h, &dfv, first_vert.size()))) return rc;
+            if ((rc = upload(h, dfv, first_vert))) return rc;
+            h->nh_seg = seg;
+            NHFrameLaunch& f = h->nh_frame_launch;
+            f.seg = dseg; f.first_vert = dfv; f.levels = nl; f.bodies = bodies; f.max_body_particles = most_v;
+            f.block = 512u;   // 128 quads for the narrow levels (kNHQuadLevel), one lane per tet for the wide ones; wider than 512: several trips
+            h->nh_frame = true;
+            h->info.fused_particle_pass = 4u;
+        }
     }
     return 0;
 }
