@@ -259,7 +259,7 @@ struct tetsim_body {
     // small bodies (all particles fit one CU's LDS, level schedules): tetsim_step_n runs a call as ONE single-workgroup launch
     bool nh_frame = false;
     NHFrameLaunch nh_frame_launch;
-    std::vector<uint32_t> nh_seg;      // host copy of nh_frame_launch.seg ([levels][bodies + 1]): the stepwise FAST twin makes the frame kernel's choice per piece
+    std::vector<uint32_t> nh_seg;      // host copy of nh_frame_launch.seg ([levels][bodies][2]): the stepwise FAST twin makes the frame kernel's choice per piece
     std::vector<int32_t> order;
     std::vector<float> h_inv_mass;
 };

@@ -139,7 +139,7 @@ void nh_launch_cluster_fast(hipStream_t s, const NHDev& d, const NHClusterLaunch
 // the same pass for the particles no cluster touches (list of particle ids), when the sweeps fold the rest
 // small bodies: a whole call as ONE workgroup per body with every particle of the body in LDS (nh_kernels.inc: nh_frame_kernel)
 struct NHFrameLaunch {
-    const uint32_t* seg = nullptr;         // [levels][bodies + 1]: per level, the first solve position of every body's tets (the last column: the level's end)
+    const uint32_t* seg = nullptr;         // [levels][bodies][2]: per level and body, first and end solve position of the body's tets (8-byte aligned pairs)
     const uint32_t* first_vert = nullptr;  // [bodies + 1]
     uint32_t levels = 0, bodies = 0, block = 512;   // threads per workgroup, <= 512
     uint32_t max_body_particles = 0;       // x 40 bytes of LDS per workgroup

@@ -194,7 +194,7 @@ void nh_sweep(tetsim_body* h, bool fold) {
         const uint32_t bodies = h->nh_frame_launch.bodies;
         for (size_t l = 0; l + 1 < h->level_off.size(); l++)
             for (uint32_t b = 0; b < bodies; b++) {
-                const uint32_t first = h->nh_seg[l * (bodies + 1u) + b], count = h->nh_seg[l * (bodies + 1u) + b + 1u] - first;
+                const uint32_t first = h->nh_seg[2u * (l * bodies + b)], count = h->nh_seg[2u * (l * bodies + b) + 1u] - first;
                 if (count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, h->nh, first, count);
                 else nh_launch_level_fast(h->stream, h->nh, first, count);
             }

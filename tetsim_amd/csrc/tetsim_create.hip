@@ -612,12 +612,16 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         const uint32_t lds_limit = h->fast ? nh_frame_lds_limit_fast() : nh_frame_lds_limit_precise();
         if (most_v > 0 && static_cast<uint64_t>(most_v) * 40u <= lds_limit && (h->fast || most_t <= 12288u) && bodies <= 65535u) {
             // per level, where every body's tets begin (solve positions; the tets of a level lie body by body)
-            std::vector<uint32_t> seg(static_cast<size_t>(nl) * (bodies + 1u));
+            std::vector<uint32_t> seg(2ull * nl * bodies);   // (first, end) pairs
             for (uint32_t l = 0; l < nl; l++) {
                 uint32_t sp = h->level_off[l];
-                for (uint32_t b = 0; b <= bodies; b++) {
-                    while (b < bodies && sp < h->level_off[l + 1] && body_of[static_cast<uint32_t>(pos_in[sp])] < b) sp++;
-                    seg[static_cast<size_t>(l) * (bodies + 1u) + b] = b == bodies ? h->level_off[l + 1] : sp;
+                for (uint32_t b = 0; b < bodies; b++) {
+                    while (sp < h->level_off[l + 1] && body_of[static_cast<uint32_t>(pos_in[sp])] < b) sp++;
+                    uint32_t ep = sp;
+                    while (ep < h->level_off[l + 1] && body_of[static_cast<uint32_t>(pos_in[ep])] == b) ep++;
+                    seg[2ull * (static_cast<size_t>(l) * bodies + b)] = sp;
+                    seg[2ull * (static_cast<size_t>(l) * bodies + b) + 1u] = ep;
+                    sp = ep;
                 }
             }
             uint32_t *dseg = nullptr, *dfv = nullptr;
