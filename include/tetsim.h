@@ -440,8 +440,9 @@ int tetsim_prep_rest(const float *verts, uint32_t nv, const int32_t *tets, uint3
  * partition owns each particle, vert_owner_out [nv], values in [0, part_count).  Recursive bisection at the weighted median
  * (weights 1 + valence: a part's tets ~ the corners it owns / 4) of the key that cuts the fewest tets -- breadth-first distances
  * from the two ends of a pseudo-diameter and their difference (topology only), plus x / y / z when `verts` is not NULL -- then
- * k-way boundary refinement (a particle moves to the part holding more of its tet-mates) with every part kept within +-3% of the
- * mean weight.  Deterministic.  tetsim_create and tetsim_plan_create* with part_count > 1 and vert_owner == NULL use this WITHOUT
+ * k-way boundary refinement (a particle moves to the part holding more of its tet-mates) which keeps every part within +-3% of the
+ * mean weight of what the cuts gave it (a cut lands on a particle boundary: one particle's weight per bisection level on top, which
+ * only shows on meshes of a few dozen particles).  Deterministic.  tetsim_create and tetsim_plan_create* with part_count > 1 and vert_owner == NULL use this WITHOUT
  * coordinates (verts == NULL: the plan entry points have none, and a plan must equal what tetsim_create builds); pass the
  * result of a call WITH coordinates as vert_owner to both for planar cuts on lattice-like meshes, or store it in a .tetsim
  * container (TetSimMeshArrays.vert_owner). */
