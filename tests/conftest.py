@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Property tests: the suite draws the SAME examples on every run (a red run must be reproducible, a green one must stay green);
+    # TETSIM_HYPOTHESIS=explore draws fresh ones (--hypothesis-seed picks the seed) -- what it finds becomes an @example.
+    try:
+        from hypothesis import settings
+        settings.register_profile("suite", derandomize=True, database=None)
+        settings.register_profile("explore", derandomize=False)
+        settings.load_profile("explore" if os.environ.get("TETSIM_HYPOTHESIS") == "explore" else "suite")
+    except ImportError:
+        pass
 
 
 def pytest_sessionstart(session):
