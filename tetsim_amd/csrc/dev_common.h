@@ -149,7 +149,8 @@ void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const NHFrameLaunch& f,
 // levels of at most this many tets are solved on four lanes per tet by the single-workgroup launch of small bodies (and, FAST, by its
 // stepwise twin): 128 quads = two waves per SIMD in f32; f64 (PRECISE) runs at half rate, one wave per SIMD
 constexpr uint32_t kNHQuadLevelFast = 128, kNHQuadLevelPrecise = 64;
-void nh_launch_level4_fast(hipStream_t s, const NHDev& d, uint32_t first, uint32_t count);   // FAST stepwise twin of the frame kernel's sweep
+void nh_launch_level4_fast(hipStream_t s, const NHDev& d, uint32_t first, uint32_t count);   // one tet per quad: FAST stepwise twin of the frame kernel's sweep; small levels
+void nh_launch_level4_precise(hipStream_t s, const NHDev& d, uint32_t first, uint32_t count);
 uint32_t nh_frame_lds_limit_precise();
 uint32_t nh_frame_lds_limit_fast();
 void nh_launch_post_predict_list_precise(hipStream_t s, const NHDev& d, const uint32_t* list, uint32_t n);

@@ -200,9 +200,15 @@ void nh_sweep(tetsim_body* h, bool fold) {
             }
         return;
     }
+    // A level of up to 8,192 tets is a few waves wherever it runs: its time is the dependent chain of ONE tet solve, and one tet on four
+    // lanes (nh_level4_kernel: the same bits in PRECISE, tolerance-level re-association in FAST) shortens it -- COLOURED bodies of
+    // 25 k-200 k tets: 117-129 -> 102-115 us per substep bit-exact, 88-100 -> 80-93 FAST; the 1 M-tet lattice's levels (32 k tets)
+    // fill the chip and keep one lane per tet (190 against 234 us).
+    constexpr uint32_t level4_max = 8192u;
     for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
         const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-        h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        if (count <= level4_max) h->fast ? nh_launch_level4_fast(h->stream, h->nh, first, count) : nh_launch_level4_precise(h->stream, h->nh, first, count);
+        else h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
     }
 }
 
