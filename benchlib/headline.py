@@ -160,18 +160,22 @@ def run(args, rank, world, local_rank, ranks):
         # so the same W + K frames are stepped once more on a second body with the library's per-launch events (tetsim_profile: begin /
         # end events around every kernel, on the handle's stream, same kernels in the same order).  The trajectory is deterministic:
         # the second body must end bit-equal to the first, and the line says whether it did.
-        pos_timed = body.pos
-        body2, _, _, pp2, _, _ = make_body(args, cells, args.scaling, rank, world, local_rank, None)
-        for _ in range(args.warmup):
-            body2.profile(SUBSTEPS, DT, pp2)
-        acc = {"tet_ms": 0.0, "tet_launches": 0, "vertex_ms": 0.0, "vertex_launches": 0}
-        for _ in range(args.steps):
-            p = body2.profile(SUBSTEPS, DT, pp2)
-            for k in acc:
-                acc[k] += p[k]
-            acc["tets_per_tet_launch"] = p["tets_per_tet_launch"]
-        replay = dict(acc, bit_equal=bool(np.array_equal(body2.pos, pos_timed)))
-        body2.close()
+        try:
+            pos_timed = body.pos
+            body2, _, _, pp2, _, _ = make_body(args, cells, args.scaling, rank, world, local_rank, None)
+            for _ in range(args.warmup):
+                body2.profile(SUBSTEPS, DT, pp2)
+            acc = {"tet_ms": 0.0, "tet_launches": 0, "vertex_ms": 0.0, "vertex_launches": 0}
+            for _ in range(args.steps):
+                p = body2.profile(SUBSTEPS, DT, pp2)
+                for k in acc:
+                    acc[k] += p[k]
+                acc["tets_per_tet_launch"] = p["tets_per_tet_launch"]
+            replay = dict(acc, bit_equal=bool(np.array_equal(body2.pos, pos_timed)))
+            body2.close()
+        except Exception as e:  # noqa: BLE001  (the line then reports the window after the timed region, as rounds 1-3 did)
+            print("[bench] the replay of the timed frames failed: %r" % (e,), file=sys.stderr)
+            replay = None
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
         # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
         # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
@@ -276,10 +280,17 @@ def run(args, rank, world, local_rank, ranks):
     GUARD.disarm()
     if world == 1:
         body.close()
+
+        def side_leg(fn):   # (nothing behind the headline and its roofline may cost the line: a failing side leg reports itself)
+            try:
+                return fn()
+            except Exception as e:  # noqa: BLE001
+                print("[bench] side leg failed: %r" % (e,), file=sys.stderr)
+                return {"error": repr(e)[:300]}
         if not args.no_beyond_mall and args.precision == "fast" and cells == CELLS and args.solver == "polar" and "roofline" in out:
-            out["roofline"]["beyond_mall"] = beyond_mall(args, local_rank, out["roofline"].get("measured_copy_peak", {}))
+            out["roofline"]["beyond_mall"] = side_leg(lambda: beyond_mall(args, local_rank, out["roofline"].get("measured_copy_peak", {})))
         if not args.no_other_configs and args.precision == "fast" and cells == CELLS:
-            out["other_configs"] = other_configs(args.steps, args.warmup)
+            out["other_configs"] = side_leg(lambda: other_configs(args.steps, args.warmup))
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(verts, tets)
+            out["cpu_baseline"] = side_leg(lambda: cpu_baseline(verts, tets))
     return out, body
