@@ -207,6 +207,11 @@ def run(args, rank, world, local_rank, ranks):
                            "substep_frac": round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
         # which launches kernel_us averages over; and the same kernel in the 60 substeps AFTER the timed region (the body lies on the
         # floor by then: every tet runs all nine rotation iterations), the only window rounds 1-3 reported
+        if win is replay and world == 1:
+            # cross-check against the wall clock of the timed region itself: a substep there is the two kernels plus two launch boundaries
+            sub_us = elapsed / (args.steps * SUBSTEPS) * 1e6
+            out["roofline"]["timed_region_check"] = {"substep_us": round(sub_us, 2), "kernels_us": round(tet_us + vert_us, 2),
+                                                     "two_launch_boundaries_us": round(sub_us - tet_us - vert_us, 2)}
         if win is replay:
             out["roofline"]["window"] = ("the %d timed frames (%d launches), stepped again on a second body with per-launch events; "
                                          "trajectory bit-equal to the timed one: %s" % (args.steps, replay["tet_launches"], replay["bit_equal"]))

@@ -77,7 +77,20 @@ def visible_devices():
         return 0
 
 def free_port():
+    """A rendezvous port that is free now AND stays free until the rank processes bind it: drawn below the kernel's ephemeral range
+    (32768+), from which any outgoing connection of this box may take a port between our probe and torch's bind (seen once:
+    EADDRINUSE on a port bind(0) had just handed out)."""
+    import random
     import socket
+    rng = random.Random(os.getpid() ^ int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        port = rng.randrange(20000, 30000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", port))
+                return port
+            except OSError:
+                continue
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]

@@ -46,6 +46,8 @@ def test_headline_line_carries_every_baseline_config():
     d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     assert d["config"]["tets"] == 998250
     assert "bit-equal to the timed one: True" in d["roofline"]["window"] and "(60 launches)" in d["roofline"]["window"]
+    chk = d["roofline"]["timed_region_check"]      # the replayed kernels fit the timed region's own wall clock: what is left are two launch boundaries
+    assert 0.0 < chk["two_launch_boundaries_us"] < 0.35 * chk["substep_us"] and abs(chk["substep_us"] - d["ms_per_step"] * 1e3 / 20) < 0.01
     oc = d["other_configs"]
     c1, c2, c4 = oc["config1_dragon_neohookean_cpu_path"], oc["config2_dragon_polar_jacobi"], oc["config4_lattice_1m_neohookean_gs_vs_jacobi"]
     assert c1["hip_original_order_precise"]["value"] > 0 and c1["hip_coloured_precise"]["value"] > c1["hip_original_order_precise"]["value"]

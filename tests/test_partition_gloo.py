@@ -61,6 +61,17 @@ def _worker(rank, world, port, kind, nsteps, out_dir):
 
 
 def _free_port():
+    # (below the kernel's ephemeral range: a port that bind(0) hands out may be taken by any outgoing connection before the workers bind it)
+    import random
+    rng = random.Random(os.getpid() ^ int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        port = rng.randrange(20000, 30000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+                return port
+            except OSError:
+                continue
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]

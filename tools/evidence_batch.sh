@@ -27,6 +27,7 @@ cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json   # keyed by kernel_sha: th
 timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout 300 python bench.py > "$OUT/bench_200.json" 2>> "$OUT/bench.err"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-beyond-mall > "$OUT/stats.log" 2>&1 )
+python tools/trace_windows.py "$OUT/stats/s_kernel_trace.csv" > "$OUT/kernel_windows.txt" 2>&1; grep -o '"value": [0-9.]*, "unit": "M tet-solves/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": [0-9.]*' "$OUT/stats.log" | head -1 | sed 's/^/  the line of this profiled run: /' >> "$OUT/kernel_windows.txt"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_nh" -o s -- python "$ROOT/bench.py" --solver neohookean --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_nh.log" 2>&1 )
 # 7. one interior rank in loopback (the stand-in for a multi-GPU rank): RCCL transfer and peer-to-peer stores, 0 / 10 / 20 us of injected delay
 timeout 900 bash tools/halo_slack.sh "$OUT/halo_slack.txt" > /dev/null 2>&1
