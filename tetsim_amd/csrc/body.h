@@ -190,6 +190,7 @@ struct tetsim_body {
     bool params_known = false;
     bool frame_local = false;         // every body's tiles share one XCD: the exchange is coherent in that XCD's L2 (pjb_frame_kernel_local)
     bool frame_turn_counted = false;  // this body is in its device's count of exclusive bodies
+    bool epoch_block_fresh = false;   // push_params took a block of sequence numbers that no launch has used yet
     bool frame_exclusive = false;     // needs MORE than half the device's resident workgroups: persistent launches of this device take turns (tetsim_api.hip: FrameTurn)
     float4* partial_b = nullptr;      // second buffer of the tile partial sums
     size_t partial_slots = 0;         // float4s in each of the two
@@ -350,6 +351,7 @@ int enqueue_phase_b(tetsim_body* h, bool refresh = false);      // halo start (p
 float4* ghost_buffer(tetsim_body* h, uint32_t parity);          // where ghost particle nv_owned + i of that substep parity lives (+ i)
 int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
 int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains
+void frame_turn_enter(tetsim_body* h);                         // an exclusive persistent-launch body joins its device's turn-taking (tetsim_api.hip)
 void drop_flag_graphs(tetsim_body* h);                          // destroy the captured chains (queues turned out not to be independent)
 
 }  // namespace tetsim

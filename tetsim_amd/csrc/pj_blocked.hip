@@ -871,9 +871,15 @@ uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    // the smaller answer of the two placements' kernels: which one a body launches is decided after this query (a body too large for the
+    // one-XCD placement takes the other), and their register counts need not stay equal
+    int per_cu_any = 0;
     const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_constant_rest_local, static_cast<int>(kTile), 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_local, static_cast<int>(kTile), 0);
-    if (e != hipSuccess || per_cu <= 0) return 0;
+    const hipError_t e2 = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, pjb_frame_kernel_constant_rest, static_cast<int>(kTile), 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, pjb_frame_kernel, static_cast<int>(kTile), 0);
+    if (e != hipSuccess || e2 != hipSuccess || per_cu <= 0 || per_cu_any <= 0) return 0;
+    per_cu = std::min(per_cu, per_cu_any);
     if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
     return static_cast<uint32_t>(per_cu);
 }

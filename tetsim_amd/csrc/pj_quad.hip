@@ -420,7 +420,10 @@ uint32_t pjq_frame_capacity(uint32_t* compute_units) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    int per_cu_any = 0;   // (the smaller answer of the two placements' kernels: which one a body launches is decided after this query)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjq_frame_kernel<true>, static_cast<int>(kQThreads), 0) != hipSuccess || per_cu <= 0) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, pjq_frame_kernel<false>, static_cast<int>(kQThreads), 0) != hipSuccess || per_cu_any <= 0) return 0;
+    per_cu = per_cu < per_cu_any ? per_cu : per_cu_any;
     if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
     return static_cast<uint32_t>(per_cu);
 }

@@ -118,6 +118,8 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
     if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
     if (int rc = next_epoch_block(h)) return rc;
+    h->epoch_block_fresh = reuse_ok;   // (only tetsim_step passes reuse_ok: its frame launch may use this block instead of taking another;
+                                       //  every other caller's launches consume the block the upload names)
     fill_params(h, dt, *params, &h->h_ring[slot]);
     HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
     h->params_on_device = h->h_ring[slot];
@@ -215,22 +217,45 @@ void nh_sweep(tetsim_body* h, bool fold) {
 // Persistent frame kernels need every workgroup of their grid resident at once.  Bodies of at most half the device's slots fit side
 // by side; once a body that needs MORE lives on a device (`frame_exclusive`), the frame launches of that device's bodies take turns:
 // a launch waits for the previous one (of another body) to finish.  Nothing happens, and nothing is paid, without such a body.
+// The count is taken when the exclusive body is CREATED (frame_turn_enter, from create_polar) -- not at its first launch: persistent
+// launches of other bodies issued before that were untracked, and the exclusive body's first launch could land half resident beside
+// one of them (advisor, round 4).  The first launch after the count leaves zero therefore drains the device once; from then on
+// every launch records `done`.  The count is given back when the body dies or falls back to one kernel per substep.
 struct FrameTurn {
     std::mutex m;
     hipEvent_t done = nullptr;       // recorded behind the last frame launch on this device
     const tetsim_body* last = nullptr;
     int exclusive_bodies = 0;
+    bool drain = false;              // launches issued while the count was zero may still be in flight: wait for the device once
 };
 FrameTurn g_frame_turn[64];
 FrameTurn& frame_turn(const tetsim_body* h) { return g_frame_turn[h->opt.device & 63]; }
+void frame_turn_enter(tetsim_body* h) {
+    if (!h->frame_exclusive || h->frame_turn_counted) return;
+    FrameTurn& t = frame_turn(h);
+    std::lock_guard<std::mutex> lock(t.m);
+    if (t.exclusive_bodies++ == 0) t.drain = true;
+    h->frame_turn_counted = true;
+}
+void frame_turn_leave(tetsim_body* h) {
+    FrameTurn& t = frame_turn(h);
+    std::lock_guard<std::mutex> lock(t.m);
+    if (h->frame_turn_counted && --t.exclusive_bodies == 0) {
+        if (t.done) { (void)hipEventDestroy(t.done); t.done = nullptr; }   // (an event destroyed while pending is released when it completes)
+        t.last = nullptr;
+        t.drain = false;
+    }
+    h->frame_turn_counted = false;
+    if (t.last == h) t.last = nullptr;   // (the caller has drained or abandoned its stream: nothing to wait for)
+}
 // `launch` puts a persistent frame kernel of body h into h->stream (a graph replay or a direct launch); its turn is taken first if needed
 template <class F>
 int launch_in_turn(tetsim_body* h, F&& launch) {
     FrameTurn& t = frame_turn(h);
     std::lock_guard<std::mutex> lock(t.m);
-    if (h->frame_exclusive && !h->frame_turn_counted) { t.exclusive_bodies++; h->frame_turn_counted = true; }
     if (t.exclusive_bodies == 0) return launch();
-    if (t.done && t.last && t.last != h) HIPCHK(h, hipStreamWaitEvent(h->stream, t.done, 0));
+    if (t.drain) { HIPCHK(h, hipDeviceSynchronize()); t.drain = false; }
+    else if (t.done && t.last && t.last != h) HIPCHK(h, hipStreamWaitEvent(h->stream, t.done, 0));
     if (int rc = launch()) return rc;
     if (!t.done) HIPCHK(h, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
     HIPCHK(h, hipEventRecord(t.done, h->stream));
@@ -566,12 +591,7 @@ void tetsim_destroy(tetsim_handle h) {
             }
     }
 #endif
-    {
-        FrameTurn& t = frame_turn(h);
-        std::lock_guard<std::mutex> lock(t.m);
-        if (h->frame_turn_counted) t.exclusive_bodies--;
-        if (t.last == h) t.last = nullptr;   // (its stream is drained: nothing to wait for)
-    }
+    frame_turn_leave(h);
     // graphs first: a captured halo graph holds RCCL work, and ncclCommDestroy waits for (hangs on) captured work that still exists
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
@@ -615,7 +635,10 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (h->frame) {
         // small polar bodies: a single substep is ONE launch too -- the persistent frame kernel for n = 1, with a block of sequence
         // numbers of its own as a kernel argument (the parameters on the device may be the previous call's: see push_params)
-        if ((rc = next_epoch_block(h))) return rc;
+        // (push_params took a fresh block when it uploaded: the launch uses that one -- with a moving grab every call uploads, and a
+        // second block per call halved the time to the wrap of the sequence numbers; unchanged parameters: a block of its own)
+        if (!h->epoch_block_fresh && (rc = next_epoch_block(h))) return rc;
+        h->epoch_block_fresh = false;
         const uint32_t epoch = h->frame_epoch;
         return launch_in_turn(h, [&]() -> int { return launch_frame_kernel(h, 1u, epoch); });
     }
@@ -700,6 +723,7 @@ int tetsim_sync(tetsim_handle h) {
         if (err) {
             HIPCHK(h, hipMemset(h->d_frame_err, 0, sizeof err));
             h->frame = false;   // step with one kernel per substep from now on
+            frame_turn_leave(h);   // ... and no longer makes the device's persistent launches take turns
             for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
             h->graphs.clear();
             return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "

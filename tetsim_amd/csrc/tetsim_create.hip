@@ -316,8 +316,12 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             // needs more (up to all of them: 100 k-200 k tets) still takes the persistent launch -- 6.9 against 9.0 us per substep at
             // 131 k tets, 7.5 against 9.6 at 197 k -- but is `exclusive`: while one lives on a device, the persistent launches of ALL
             // bodies of that device take turns (tetsim_step_n), so that two of them are never half resident next to each other.
-            if (per_cu != 0u && nbk != 0u && nbk <= per_cu * cus) {
-                h->frame_exclusive = nbk > per_cu * cus / 2u;
+            // An exclusive body may take up to 90% of the slots (not all: a compute-unit mask, or a kernel of another queue holding a
+            // few, must not leave a tile without a slot), and none at all on a device where a partitioned body's folded halo waits
+            // may be holding slots of their own (tetsim_halo.hip: pjb_wait_capacity).
+            const uint32_t slots = per_cu * cus, exclusive_max = slots - slots / 10u;
+            if (per_cu != 0u && nbk != 0u && nbk <= (h->partitioned ? slots / 2u : exclusive_max)) {
+                h->frame_exclusive = nbk > slots / 2u;
                 static const bool allow_local = [] { const char* e = getenv("TETSIM_FRAME_LOCAL"); return !(e && e[0] == '0'); }();
                 static int xcd_rule[64] = {};   // per device: 0 = not probed, 1 = round-robin over 8 XCDs verified, 2 = no
                 int& rule = xcd_rule[o.device & 63];
@@ -355,6 +359,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                 for (uint32_t x = 0; x < 8u; x++)
                     for (uint32_t j = 0; j < on_xcd[x].size(); j++) block_tile[8ull * j + x] = static_cast<int32_t>(on_xcd[x][j]);
                 h->frame = true;
+                frame_turn_enter(h);   // (an exclusive body is counted from its creation on: tetsim_api.hip, FrameTurn)
                 h->frame_local = local;
                 h->frame_blocks = static_cast<uint32_t>(block_tile.size());
             }

@@ -138,6 +138,7 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     for (PeerLink& l : h->links) for (void*& m : l.ipc) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
     h->links.clear();
     h->p2p = false;
+    drop_flag_graphs(h);   // the captured chains hold kernel nodes with the closed peer pointers baked in: gone with the mappings, also on an error return below
     std::vector<PeerLink> links(h->neigh.size());
     struct CloseOnError {
         std::vector<PeerLink>& v; bool armed = true;

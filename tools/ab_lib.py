@@ -1,5 +1,7 @@
 """In-session A/B of several builds of libtetsim_hip.so through bench.py (alternating runs, 3 rounds):
-    python tools/ab_lib.py libA.so libB.so [libC.so ...] [-- extra bench args]"""
+    python tools/ab_lib.py libA.so libB.so [libC.so ...] [-- extra bench args]
+Per run: the line's value, the tet kernel over the timed frames and in the window after them (the body lies on the floor there:
+nine rotation iterations everywhere), the particle kernel."""
 import json
 import os
 import subprocess
@@ -12,12 +14,14 @@ libs = args[:args.index("--")] if "--" in args else args
 for rep in range(3):
     for lib in libs:
         env = dict(os.environ, TETSIM_HIP_LIB=os.path.abspath(lib))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"] + extra,
-                             env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs",
+                              "--no-beyond-mall"] + extra, env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception:
             print("%-32s FAILED: %s" % (os.path.basename(lib), out.stderr[-300:]), flush=True)
             continue
         r = d["roofline"]
-        print("%-32s value %.1f  ms/frame %.4f  tet %.2f us  vertex %.2f us  frac %.3f" % (os.path.basename(lib), d["value"], d["ms_per_step"], r["kernel_us"], r["vertex_kernel_us"], r["frac"]), flush=True)
+        after = r.get("after_timed_region", {}).get("kernel_us", float("nan"))
+        print("%-32s value %.1f  ms/frame %.4f  tet %.2f us (after the timed frames %.2f us)  vertex %.2f us  frac %.3f" % (
+            os.path.basename(lib), d["value"], d["ms_per_step"], r["kernel_us"], after, r["vertex_kernel_us"], r["frac"]), flush=True)
