@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--order", default="clustered", choices=["coloured", "clustered"], help="--solver neohookean: Gauss-Seidel schedule")
     ap.add_argument("--constant-rest-shape", action="store_true",
                     help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
+    ap.add_argument("--reference-rotation-exit", action="store_true",
+                    help="the HEADLINE body with TETSIM_FLAG_REF_ROTATION_EXIT (|omega| < 1e-9: nine rotation iterations in every tet, the reference's "
+                         "work) -- counter passes of the equal-work kernel; the default line already carries value_reference_threshold beside value")
     ap.add_argument("--cells", type=int, default=CELLS, help="lattice cells per side (default 55 = the 1 M-tet headline; 110 = 8 M tets)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, what the driver measures): cells^2 x (cells*N) lattice, one slab per GPU; strong: the cells^3 "

@@ -94,6 +94,37 @@ def pmc_traffic(kname, kernel_sha):
     except Exception:
         return None
 
+def rocprof_kernel_stats(kname, kernel_sha):
+    """The committed `rocprofv3 --kernel-trace --stats` summary of this very command (profiles/bench_kernel_stats.json names the CSV of
+    the round and the kernel_sha it was taken on): average duration of `kname` over EVERY launch of the command, profiler attached.
+    The line carries it beside its own event timings so that the two cannot drift apart unnoticed; a summary taken on another kernel
+    build is reported as stale."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "bench_kernel_stats.json")) as f:
+            meta = json.load(f)
+        import csv
+        with open(os.path.join(ROOT, "profiles", meta["csv"])) as f:
+            for row in csv.DictReader(f):
+                if ("::" + kname + "(") in row["Name"]:
+                    return {"file": "profiles/" + meta["csv"], "launches": int(row["Calls"]), "kernel_us": round(float(row["AverageNs"]) / 1e3, 2),
+                            "stale": meta.get("kernel_sha") != kernel_sha}
+    except Exception:
+        pass
+    return None
+
+
+def tet_kernel_ceiling(kernel_sha):
+    """profiles/tet_kernel_ceiling.json (tools/tet_kernel_ceiling.py, ablation build + counters): what bounds pjb_tet_kernel on this
+    workload -- its memory floor (the kernel with the rotation iterations switched off) and its vector-issue floor (VALU
+    wave-instructions per SIMD x the issue rate this chip sustains)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "tet_kernel_ceiling.json")) as f:
+            c = json.load(f)
+        return dict(c, stale=c.get("kernel_sha") != kernel_sha)
+    except Exception:
+        return None
+
+
 def run(args, rank, world, local_rank, ranks):
     """One rank of the benchmark.  `ranks` is None (single process, no communicator) or an adapter with broadcast_bytes /
     barrier / max_float / min_float."""
@@ -138,8 +169,8 @@ def run(args, rank, world, local_rank, ranks):
                                    "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
                        "solver": "polar_jacobi", "arithmetic": args.precision,
                        "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
-                       "rotation_exit": ("iteration 1: |omega| < 1e-9 (the reference's, SoftbodyGPU.js:131); correction iterations 2..9: |omega| < 1e-6 rad "
-                                         "(FAST default; other_configs.config3_reference_threshold has the same frames with 1e-9 throughout)") if args.precision == "fast"
+                       "rotation_exit": "|omega| < 1e-9 throughout (--reference-rotation-exit: the reference's, SoftbodyGPU.js:131)" if getattr(args, "reference_rotation_exit", False) else ("iteration 1: |omega| < 1e-9 (the reference's, SoftbodyGPU.js:131); correction iterations 2..9: |omega| < 1e-6 rad "
+                                         "(FAST default; value_reference_threshold at the top level has the same frames with 1e-9 throughout, and roofline.frac is quoted on THAT kernel)") if args.precision == "fast"
                                         else "|omega| < 1e-9 (the reference's, SoftbodyGPU.js:131)",
                        "tets": nt_global, "particles": nv_global,
                        "parallelism": "single GPU" if world == 1 else "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world},
@@ -176,12 +207,51 @@ def run(args, rank, world, local_rank, ranks):
         except Exception as e:  # noqa: BLE001  (the line then reports the window after the timed region, as rounds 1-3 did)
             print("[bench] the replay of the timed frames failed: %r" % (e,), file=sys.stderr)
             replay = None
+    # EQUAL WORK: the FAST default ends a tet's correction iterations below 1e-6 rad, which removes ~40% of the
+    # iterations while the body falls and none once it lies on the floor.  The same W + K frames once more with the REFERENCE's
+    # threshold (TETSIM_FLAG_REF_ROTATION_EXIT: |omega| < 1e-9, all nine iterations in f32, SoftbodyGPU.js:131): wall clock (median of
+    # three bodies from rest) -> value_reference_threshold, and per-launch events on a fourth -> the kernel the roofline fraction leads with.
+    equal = None
+    if world == 1 and args.solver == "polar" and args.precision == "fast" and not args.no_replay and rank == 0:
+        try:
+            from tetsim_amd import SoftBodyHIP
+            kw = dict(constant_rest_shape=True) if args.constant_rest_shape else {}
+            runs = []
+            for _ in range(3):
+                b3 = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, ref_rotation_exit=True, **kw)
+                el3, _ = timed_frames(b3, pp, args.steps, args.warmup, None)
+                runs.append(el3)
+                b3.close()
+            b4 = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, ref_rotation_exit=True, **kw)
+            for _ in range(args.warmup):
+                b4.profile(SUBSTEPS, DT, pp)
+            acc4 = {"tet_ms": 0.0, "tet_launches": 0}
+            for _ in range(args.steps):
+                p4 = b4.profile(SUBSTEPS, DT, pp)
+                for k in acc4:
+                    acc4[k] += p4[k]
+            b4.close()
+            equal = {"elapsed": sorted(runs)[1], "runs": runs, "tet_us": acc4["tet_ms"] / acc4["tet_launches"] * 1e3, "launches": acc4["tet_launches"]}
+        except Exception as e:  # noqa: BLE001
+            print("[bench] the equal-work (reference threshold) leg failed: %r" % (e,), file=sys.stderr)
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
         # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
         # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
         batches = sorted((body.profile(SUBSTEPS * 3, DT, pp) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])
         pr = batches[1]
         body.sync()
+        floor_graph_us = None
+        if world == 1 and args.solver == "polar":
+            # ... and what a substep costs there INSIDE the graphs (the regime of the timed region: kernels back to back, no per-launch events)
+            try:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    body.simulateSubsteps(SUBSTEPS, DT, pp)
+                body.sync()
+                floor_graph_us = (time.perf_counter() - t0) / (10 * SUBSTEPS) * 1e6
+            except Exception as e:  # noqa: BLE001
+                print("[bench] the on-floor graph frames failed: %r" % (e,), file=sys.stderr)
         if use_dist:
             ranks.barrier()
     tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)   # constant rest shape: read only, never written back
@@ -195,31 +265,78 @@ def run(args, rank, world, local_rank, ranks):
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
         if body.info.fused_particle_pass in (1, 2):   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
             kname, tet_bytes = "pjb_tet_fused_kernel", b_alg
-        achieved = tet_bytes * units / (tet_us * 1e-6) / 1e9
         traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
+        alg = tet_bytes * units
+
+        def window(us, what, **more):
+            return dict({"kernel_us": round(us, 2), "achieved": round(alg / (us * 1e-6) / 1e9, 1), "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "window": what}, **more)
+        # Which duration `frac` is quoted on.  EQUAL WORK FIRST: nine rotation iterations in every tet, as the reference does
+        # (SoftbodyGPU.js:122-139).  The line LEADS with the window after the timed frames: the body lies on the floor, every tet runs
+        # nine iterations whatever the threshold, the clocks have settled -- the window rounds 1-4 can be compared on.  Beside it:
+        # the timed frames with the reference's threshold (equal work while the body falls; by events, and what the wall clock of those
+        # graphs implies -- the two disagree on the first frames after a body's creation) and the FAST-exit kernel `value` ran.
+        fast_win = window(tet_us, ("the %d timed frames (%d launches) of the headline body's trajectory, stepped again on a second body with per-launch "
+                                   "events; trajectory bit-equal to the timed one: %s" % (args.steps, replay["tet_launches"], replay["bit_equal"]))
+                          if win is replay else "180 substeps after the timed region, median of three batches of 60",
+                          rotation_exit="FAST default: correction iterations end below 1e-6 rad (~40% fewer iterations while the body falls)")
+        floor_win = window(after_us, "180 substeps after the timed region (the body lies on the floor: nine iterations in every tet whatever the threshold), "
+                                     "per-launch events, median of three batches of 60")
+        lead = floor_win
+        boundaries_us = (elapsed / (args.steps * SUBSTEPS) * 1e6 - tet_us - vert_us) if (win is replay and world == 1) else None
+        if floor_graph_us is not None and boundaries_us is not None:
+            floor_win["in_graph"] = {"substep_us": round(floor_graph_us, 2), "kernel_us_implied": round(floor_graph_us - vert_us - boundaries_us, 2),
+                                     "frac_implied": round(alg / ((floor_graph_us - vert_us - boundaries_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "what": "10 more frames as graph replays (wall clock) minus the particle kernel and the two launch boundaries of timed_region_check"}
+        ref_win = None
+        if equal is not None:
+            ref_win = window(equal["tet_us"], "the %d timed frames (%d launches) with the reference's rotation threshold (|omega| < 1e-9), per-launch events on a "
+                                              "body of its own" % (args.steps, equal["launches"]))
+            sub_ref = equal["elapsed"] / (args.steps * SUBSTEPS) * 1e6
+            if boundaries_us is not None:
+                imp = sub_ref - vert_us - boundaries_us
+                ref_win["in_graph"] = {"substep_us": round(sub_ref, 2), "kernel_us_implied": round(imp, 2), "frac_implied": round(alg / (imp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "what": "wall clock of the same frames as graph replays (value_reference_threshold) minus the particle kernel and the two launch "
+                                               "boundaries of timed_region_check; on the first frames after a body's creation the graphs run the iteration-heavy kernel "
+                                               "slower than its per-launch events say (tools/frame_series.py)"}
+        achieved = lead["achieved"]
         out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
-                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel_us": round(tet_us, 2), "vertex_kernel_us": round(vert_us, 2),
-                           "alg_bytes_per_launch": tet_bytes * units,
+                           "achieved": lead["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": lead["frac"], "traffic": traffic,
+                           "kernel_us": lead["kernel_us"], "window": lead["window"],
+                           "work": "equal to the reference's: nine rotation iterations in every tet (SoftbodyGPU.js:122-139)" if args.precision == "fast" else "the reference's",
+                           "vertex_kernel_us": round(vert_us, 2),
+                           "alg_bytes_per_launch": alg,
                            "substep_alg_bytes_per_tet": round(b_alg, 1),
                            "substep_achieved": round(b_alg * out["value"] * 1e6 / 1e9, 1),
                            "substep_frac": round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)}
-        # which launches kernel_us averages over; and the same kernel in the 60 substeps AFTER the timed region (the body lies on the
-        # floor by then: every tet runs all nine rotation iterations), the only window rounds 1-3 reported
+        if args.precision == "fast" and world == 1:
+            out["roofline"]["on_floor"] = floor_win
+            if ref_win is not None:
+                out["roofline"]["timed_frames_reference_threshold"] = ref_win
+            out["roofline"]["fast_exit"] = fast_win
+            out["roofline"]["after_timed_region"] = floor_win       # (the name rounds 1-4 used)
+            rp = rocprof_kernel_stats(kname, lib["kernel_sha"])
+            if rp is not None:
+                rp["frac"] = round(alg / (rp["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                rp["what"] = ("rocprofv3 --kernel-trace --stats over this very command, profiler attached: the average over EVERY launch of the kernel "
+                              "(headline frames with the FAST exit, the replays, the reference-threshold bodies, the on-floor window)")
+                out["roofline"]["frac_rocprof"] = rp["frac"]
+                out["roofline"]["rocprof"] = rp
+            ce = tet_kernel_ceiling(lib["kernel_sha"])
+            if ce is not None:
+                ceil_us = max(ce["memory_floor_us"], ce["valu_issue_floor_us"])
+                out["roofline"]["ceiling"] = dict(ce, ceiling_us=ceil_us, frac_at_ceiling=round(alg / (ceil_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  kernel_vs_ceiling=round(ceil_us / lead["kernel_us"], 4))
+        if equal is not None:
+            out["value_reference_threshold"] = round(nt_global * SUBSTEPS * args.steps / equal["elapsed"] / 1e6, 1)
+            out["value_reference_threshold_runs"] = [round(nt_global * SUBSTEPS * args.steps / r / 1e6, 1) for r in equal["runs"]]
+        # the FAST-exit replay against the wall clock of the timed region itself: a substep there is the two kernels plus two launch boundaries
         if win is replay and world == 1:
-            # cross-check against the wall clock of the timed region itself: a substep there is the two kernels plus two launch boundaries
             sub_us = elapsed / (args.steps * SUBSTEPS) * 1e6
             out["roofline"]["timed_region_check"] = {"substep_us": round(sub_us, 2), "kernels_us": round(tet_us + vert_us, 2),
-                                                     "two_launch_boundaries_us": round(sub_us - tet_us - vert_us, 2)}
-        if win is replay:
-            out["roofline"]["window"] = ("the %d timed frames (%d launches), stepped again on a second body with per-launch events; "
-                                         "trajectory bit-equal to the timed one: %s" % (args.steps, replay["tet_launches"], replay["bit_equal"]))
-            out["roofline"]["after_timed_region"] = {"kernel_us": round(after_us, 2), "achieved": round(tet_bytes * units / (after_us * 1e-6) / 1e9, 1),
-                                                     "frac": round(tet_bytes * units / (after_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                     "window": "180 substeps after the timed region, median of three batches of 60"}
-        else:
-            out["roofline"]["window"] = "180 substeps after the timed region, median of three batches of 60"
+                                                     "two_launch_boundaries_us": round(sub_us - tet_us - vert_us, 2),
+                                                     "what": "the headline's own frames (FAST exit): wall clock per substep against the replayed kernels"}
         if world == 1:
             # SURVEY.md 8(d) "bounding roofline": the peak is also MEASURED on this box -- a device copy at the footprint class of
             # the 1 M-tet working set (fits the 256 MB Infinity Cache) and at 1 GiB (streams from HBM)

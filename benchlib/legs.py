@@ -67,27 +67,7 @@ def other_configs(steps=20, warmup=5):
                     "every tile's workgroup resident for the 20 substeps; PRECISE: a tet and a particle kernel per substep)",
         "fast": hip_rate(dv, dtets, 20, 400, solver="polar", precision="fast"),
         "precise": hip_rate(dv, dtets, 20, 200, solver="polar", precision="precise")}
-    # config 3 once more with the REFERENCE's rotation-exit threshold (TETSIM_FLAG_REF_ROTATION_EXIT: |omega| < 1e-9, i.e. all nine iterations
-    # in f32, SoftbodyGPU.js:131) -- the headline's FAST default ends a tet's correction iterations below 1e-6 rad.  Same lattice, same
-    # protocol as the headline (warm-up + timed frames from rest); what the threshold is worth depends on the phase of the fall.
-    lv, lt = make_lattice(CELLS)
-    runs = []
-    for _ in range(3):   # (three bodies from rest, the median: a side leg of 25 frames is at the mercy of one clock dip -- 15.6 G was seen once among 25-26 G)
-        body = SoftBodyHIP(lv, lt, None, dict(PP), solver="polar", precision="fast", ref_rotation_exit=True)
-        for _ in range(warmup):
-            body.simulateSubsteps(SUBSTEPS, DT, PP)
-        body.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            body.simulateSubsteps(SUBSTEPS, DT, PP)
-        body.sync()
-        runs.append(time.perf_counter() - t0)
-        body.close()
-    el = sorted(runs)[1]
-    out["config3_reference_threshold"] = {
-        "workload": "the headline's lattice and frames (%d warm-up + %d timed, from rest) with rotation_exit = the reference's |omega| < 1e-9; median of three bodies" % (warmup, steps),
-        "value": round(len(lt) * SUBSTEPS * steps / el / 1e6, 1), "unit": "M tet-solves/s", "ms_per_step": round(el / steps * 1e3, 4),
-        "runs": [round(len(lt) * SUBSTEPS * steps / r / 1e6, 1) for r in runs]}
+    # (config 3 with the REFERENCE's rotation-exit threshold is at the top level of the line: value_reference_threshold, headline.py)
     # config 4: Neo-Hookean Gauss-Seidel on the 1 M-tet lattice + convergence against Jacobi (dropped 2 cm onto the floor)
     v, t = make_lattice(CELLS, y0=0.02)
     Dm_inv = np.linalg.inv((v[t[:, 1:]] - v[t[:, :1]]).astype(np.float64).transpose(0, 2, 1))

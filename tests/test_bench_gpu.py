@@ -37,7 +37,12 @@ def test_single_gpu_line():
     assert lib["abi"] == 3 and lib["ablation"] is False and lib["debug_env"] == [] and len(lib["kernel_sha"]) == 16
     assert rf["traffic"] is None          # not the headline lattice: no counter figure is attached to it
     # the dominant kernel is timed over a replay of the timed frames, which must retrace them bit for bit; the window after them beside it
-    assert "bit-equal to the timed one: True" in rf["window"] and rf["after_timed_region"]["kernel_us"] > 0
+    assert "bit-equal to the timed one: True" in rf["fast_exit"]["window"] and rf["after_timed_region"]["kernel_us"] > 0
+    # ... and the fraction the line LEADS with is the equal-work one: nine rotation iterations per tet (the reference's threshold over the
+    # timed frames), the FAST-exit kernel the value ran and the on-floor window beside it, each with its own achieved / frac
+    assert "lies on the floor" in rf["window"] and "nine rotation iterations" in rf["work"] and rf["on_floor"]["frac"] == rf["frac"]
+    assert rf["timed_frames_reference_threshold"]["kernel_us"] >= 0.97 * rf["fast_exit"]["kernel_us"] and d["value_reference_threshold"] > 0
+    assert len(d["value_reference_threshold_runs"]) == 3
 
 
 def test_headline_line_carries_every_baseline_config():
@@ -45,7 +50,19 @@ def test_headline_line_carries_every_baseline_config():
     (config 3), and roofline.traffic is either null or keyed to this very kernel build."""
     d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     assert d["config"]["tets"] == 998250
-    assert "bit-equal to the timed one: True" in d["roofline"]["window"] and "(60 launches)" in d["roofline"]["window"]
+    rf = d["roofline"]
+    assert "bit-equal to the timed one: True" in rf["fast_exit"]["window"] and "(60 launches)" in rf["fast_exit"]["window"]
+    rt = rf["timed_frames_reference_threshold"]
+    assert "(60 launches)" in rt["window"] and rt["in_graph"]["substep_us"] > rt["kernel_us"] and rf["on_floor"]["in_graph"]["kernel_us_implied"] > 0
+    # equal work leads (the on-floor window); the reference-threshold kernel is never faster than the FAST-exit one by more than noise, and
+    # the value with the reference's threshold stands at top level next to `value`
+    assert rf["frac"] == rf["on_floor"]["frac"] and rt["frac"] <= rf["fast_exit"]["frac"] * 1.03 and 0 < d["value_reference_threshold"] <= d["value"] * 1.05
+    # the committed rocprofv3 summary of this command and the kernel's ceiling, keyed to the kernel build they were taken on
+    meta = json.load(open(os.path.join(ROOT, "profiles", "bench_kernel_stats.json")))
+    assert rf["rocprof"]["file"] == "profiles/" + meta["csv"] and rf["rocprof"]["stale"] == (meta["kernel_sha"] != d["library"]["kernel_sha"])
+    assert abs(rf["frac_rocprof"] - rf["alg_bytes_per_launch"] / (rf["rocprof"]["kernel_us"] * 1e-6) / 1e9 / 8000.0) < 1e-3
+    ce = rf["ceiling"]
+    assert ce["ceiling_us"] == max(ce["memory_floor_us"], ce["valu_issue_floor_us"]) and 0.5 < ce["kernel_vs_ceiling"] <= 1.0
     chk = d["roofline"]["timed_region_check"]      # the replayed kernels fit the timed region's own wall clock: what is left are two launch boundaries
     assert 0.0 < chk["two_launch_boundaries_us"] < 0.35 * chk["substep_us"] and abs(chk["substep_us"] - d["ms_per_step"] * 1e3 / 20) < 0.01
     oc = d["other_configs"]

@@ -141,6 +141,33 @@ def test_bodies_of_more_than_half_the_device_take_turns():
     assert all(b.info.fused_particle_pass == 2 for b in big)
 
 
+def test_an_exclusive_body_is_counted_from_its_creation():
+    """Advisor, round 4: an exclusive body used to join its device's turn-taking at its own FIRST launch, so a persistent launch another
+    body issued between its creation and that launch was untracked, and the two could sit half resident next to each other.  The
+    body is counted when it is created: a Dragon's long call issued right after (5,000 substeps, milliseconds on the device) is
+    already taking turns, the exclusive body's first call waits for it, and both equal bodies stepped alone.  When the exclusive body
+    dies the count is given back (later launches no longer wait for each other: the twelve-Dragons test above is that state)."""
+    v, t = make_lattice(28, y0=0.02)
+    dv, dt_ = load_mesh("dragon")
+    solo_big = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    solo_big.simulateSubsteps(20, DT, PP)
+    ref_big = solo_big.pos
+    solo_big.close()
+    solo_dragon = SoftBodyHIP(dv, dt_, None, dict(PP), solver="polar", precision="fast")
+    solo_dragon.simulateSubsteps(5000, DT, PP)
+    ref_dragon = solo_dragon.pos
+    solo_dragon.close()
+    big = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")          # exclusive: counted here
+    dragon = SoftBodyHIP(dv, dt_, None, dict(PP), solver="polar", precision="fast")
+    assert big.info.fused_particle_pass == 2 and dragon.info.fused_particle_pass == 3
+    dragon.simulateSubsteps(5000, DT, PP)      # in flight ...
+    big.simulateSubsteps(20, DT, PP)           # ... when the exclusive body launches for the first time
+    assert _same(big.pos, ref_big) and _same(dragon.pos, ref_dragon)
+    big.close()
+    dragon.simulateSubsteps(20, DT, PP)        # the count is back at zero: a plain launch
+    assert np.isfinite(dragon.pos).all()
+
+
 def _wheel(spokes):
     """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
     ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)

@@ -237,6 +237,7 @@ struct tetsim_body {
     uint64_t p2p_round = 0;               // substeps enqueued since the connection; its parity selects the buffers
     bool p2p_raise_pending = false;       // the last boundary-particle kernel's "arrived" has not been raised yet (no kernel behind it)
     bool halo_pending = false;            // a halo was started and nobody has waited for it yet
+    bool final_ghosts_fresh = false;      // pos_final's ghost range holds the neighbours' END-OF-SUBSTEP positions of the current state (tetsim_halo_refresh_final)
     std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
 
     SkinDev skin;  // embedded visual mesh

@@ -91,6 +91,15 @@ uint64_t mesh_digest(const tetsim_body* h) {
     mix(&h->opt.density, sizeof(h->opt.density));
     mix(h->batch_first_vert.data(), h->batch_first_vert.size() * sizeof(uint32_t));
     mix(h->batch_first_tet.data(), h->batch_first_tet.size() * sizeof(uint32_t));
+    if (h->partitioned) {
+        // a partition's blob belongs to THIS cut of the mesh: which part of how many, which particles it holds in which local order
+        // (owned boundary | owned interior | ghosts by owner -- i.e. the owner map as far as this part sees it), which tets, how deep
+        const int32_t id[3] = {h->opt.part_count, h->opt.part_index, h->part.depth};
+        mix(id, sizeof id);
+        mix(&h->part.n_owned, sizeof(h->part.n_owned));
+        mix(h->part.local_to_global_vert.data(), h->part.local_to_global_vert.size() * sizeof(int32_t));
+        mix(h->part.local_to_global_tet.data(), h->part.local_to_global_tet.size() * sizeof(int32_t));
+    }
     return d;
 }
 constexpr uint32_t kStateMagic = 0x54535354u;  // "TSST"
@@ -130,8 +139,28 @@ StateHeader state_header(tetsim_body* h) {
     hd.mesh_digest = mesh_digest(h);
     return hd;
 }
+// A PARTITION's blob is its local state in local order: owned particles AND ghosts (the predictions its neighbours sent for the next
+// substep are state -- they are what the next substep's ghost tets read), local tets incl. ghost tets.  Every rank saves its own blob at
+// the same substep count (after tetsim_sync) and loads its own; nothing crosses ranks.  What is NOT in it is transport state: the
+// semaphore words are at rest after a sync, and the peer-to-peer halo's substep parity stays the restored body's own -- so the ghosts
+// are read from the buffer the NEXT substep will read and written back into both.  Two-layer ghost regions keep four more receive
+// buffers in flight between even substeps: not supported (save / load such a decomposition with one layer).
 int state_guard(tetsim_body* h) {
-    if (h->partitioned && h->opt.part_count > 1) return fail(h, TETSIM_ESTATE, "save/load_state is supported on unpartitioned bodies only");
+    if (h->partitioned && h->deep) return fail(h, TETSIM_ESTATE, "save/load_state of a body with a two-layer ghost region (TETSIM_FLAG_DEEP_GHOSTS) is not supported");
+    if (h->partitioned && h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "partitioned bodies are POLAR_JACOBI bodies");
+    return 0;
+}
+// peer-to-peer bodies on an odd substep parity read their ghosts from ghost_alt, not from pos_pred's tail
+int ghosts_to_tail(tetsim_body* h) {
+    const size_t ng = h->pj.nv_local - h->pj.nv_owned;
+    if (h->partitioned && h->p2p && h->ghost_alt && ng && (h->p2p_round & 1u))
+        HIPCHK(h, hipMemcpy(h->pj.pos_pred + h->pj.nv_owned, h->ghost_alt, ng * sizeof(float4), hipMemcpyDeviceToDevice));
+    return 0;
+}
+int ghosts_from_tail(tetsim_body* h) {
+    const size_t ng = h->pj.nv_local - h->pj.nv_owned;
+    if (h->partitioned && h->ghost_alt && ng)
+        HIPCHK(h, hipMemcpy(h->ghost_alt, h->pj.pos_pred + h->pj.nv_owned, ng * sizeof(float4), hipMemcpyDeviceToDevice));
     return 0;
 }
 }  // namespace
@@ -150,6 +179,7 @@ int tetsim_save_state(tetsim_handle h, void* blob, uint64_t bytes) {
     HIPCHK(h, hipSetDevice(h->opt.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (int rc = ghosts_to_tail(h)) return rc;   // (the tail is the other parity's buffer: free until the substep after next writes it)
     char* out = static_cast<char*>(blob);
     std::memcpy(out, &hd, sizeof(hd));
     out += sizeof(hd);
@@ -185,8 +215,10 @@ int tetsim_load_state(tetsim_handle h, const void* blob, uint64_t bytes) {
         if (sec.bytes) HIPCHK(h, hipMemcpy(sec.ptr, src, sec.bytes, hipMemcpyHostToDevice));
         src += sec.bytes;
     }
+    if (int rc = ghosts_from_tail(h)) return rc;
     h->pred_any_dt = in.pred_any_dt != 0;
     h->dt_pred = in.dt_pred;
+    h->final_ghosts_fresh = false;
     return 0;
 }
 

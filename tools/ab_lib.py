@@ -1,6 +1,6 @@
 """In-session A/B of several builds of libtetsim_hip.so through bench.py (alternating runs, 3 rounds):
     python tools/ab_lib.py libA.so libB.so [libC.so ...] [-- extra bench args]
-Per run: the line's value, the tet kernel over the timed frames and in the window after them (the body lies on the floor there:
+Per run: the value (and with the reference threshold), the tet kernel at nine iterations, with the FAST exit, on the floor (
 nine rotation iterations everywhere), the particle kernel."""
 import json
 import os
@@ -22,6 +22,7 @@ for rep in range(3):
             print("%-32s FAILED: %s" % (os.path.basename(lib), out.stderr[-300:]), flush=True)
             continue
         r = d["roofline"]
-        after = r.get("after_timed_region", {}).get("kernel_us", float("nan"))
-        print("%-32s value %.1f  ms/frame %.4f  tet %.2f us (after the timed frames %.2f us)  vertex %.2f us  frac %.3f" % (
-            os.path.basename(lib), d["value"], d["ms_per_step"], r["kernel_us"], after, r["vertex_kernel_us"], r["frac"]), flush=True)
+        fx, rt = r.get("fast_exit", r), r.get("timed_frames_reference_threshold", {})
+        print("%-32s value %.1f (reference threshold %.1f)  ms/frame %.4f  tet: on the floor %.2f us (in graph ~%.2f), timed frames FAST exit %.2f us, with 1e-9 %.2f us  vertex %.2f us  frac %.3f" % (
+            os.path.basename(lib), d["value"], d.get("value_reference_threshold", float("nan")), d["ms_per_step"], r["kernel_us"],
+            r.get("on_floor", {}).get("in_graph", {}).get("kernel_us_implied", float("nan")), fx["kernel_us"], rt.get("kernel_us", float("nan")), r["vertex_kernel_us"], r["frac"]), flush=True)

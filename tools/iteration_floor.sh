@@ -1,0 +1,25 @@
+#!/usr/bin/env bash
+# Iteration ablation of the PRODUCT tet kernel (run ON the GPU box; the variant libraries are built beforehand, without a GPU:
+#   for n in 0 3 6; do python tools/mutant_lib.py it$n pj_blocked.hip '#define TETSIM_DBG_ITERS 9' "#define TETSIM_DBG_ITERS $n /* ABLATION OF THE PRODUCT KERNEL */"; done )
+# Alternating runs of the bench line through each library; prints one line per library: the tet kernel on the floor (per-launch events,
+# median of the runs), inside the graphs there (wall clock minus particle kernel and launch boundaries), and over the timed frames.
+cd "${GRAFT_REPO_ROOT:-.}"
+python - <<'PY'
+import json, os, subprocess, sys, statistics
+libs = [(0, "libtetsim_hip_it0.so"), (3, "libtetsim_hip_it3.so"), (6, "libtetsim_hip_it6.so"), (9, "libtetsim_hip.so")]
+res = {n: [] for n, _ in libs}
+for rep in range(3):
+    for n, lib in libs:
+        env = dict(os.environ, TETSIM_HIP_LIB=os.path.abspath(os.path.join("tetsim_amd", lib)))
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs", "--no-beyond-mall"],
+                             env=env, capture_output=True, text=True)
+        try:
+            r = json.loads(out.stdout.strip().splitlines()[-1])["roofline"]
+            res[n].append((r["on_floor"]["kernel_us"], r["on_floor"]["in_graph"]["kernel_us_implied"], r["fast_exit"]["kernel_us"], r["vertex_kernel_us"]))
+        except Exception as e:
+            print("iters=%d FAILED %r %s" % (n, e, out.stderr[-300:]))
+for n, _ in libs:
+    if res[n]:
+        med = [statistics.median(x[i] for x in res[n]) for i in range(4)]
+        print("iters=%d  tet %.2f us on the floor by events (in the graphs there: ~%.2f us; timed frames: %.2f us)  vertex %.2f us   [%d runs]" % (n, med[0], med[1], med[2], med[3], len(res[n])))
+PY
