@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TETSIM_ABI_VERSION 3
+#define TETSIM_ABI_VERSION 4
 
 typedef struct tetsim_body *tetsim_handle;
 
@@ -217,11 +217,10 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams *params);
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params);
 /* Block until everything enqueued on the handle's stream(s) has finished.  Partitioned bodies: TETSIM_ECOMM if a device-side
  * halo wait gave up (TETSIM_HALO_TIMEOUT_MS, 30 s by default: a stuck peer, or the two chains of a graph replay sharing one
- * hardware queue).  The substeps since then used stale data.  A PARTITIONED body has no checkpoint to go back to
- * (tetsim_save_state / tetsim_load_state take unpartitioned bodies only): rebuild the partitions of every rank from the last state
- * the host holds (tetsim_read_positions / _velocities gathered over the ranks restart a trajectory only approximately -- the
- * polar solver's per-tet state is lost) or stop.  The handle itself stays usable and steps eagerly (no graph replay of the halo
- * chains) from then on. */
+ * hardware queue).  The substeps since then used stale data: go back to the last checkpoint -- every rank loads the blob it saved
+ * with tetsim_save_state at the same substep count (partitions save and load their own, since ABI 4), or rebuilds its partition
+ * (same owner map), loads it there and re-attaches the transport -- and the trajectory continues bit for bit.  The handle itself
+ * stays usable and steps eagerly (no graph replay of the halo chains) from then on. */
 int tetsim_sync(tetsim_handle h);
 
 /* --- state access (synchronising) ------------------------------------------------------------ */
@@ -250,13 +249,19 @@ int tetsim_read_vol_error(tetsim_handle h, double *out);
  * POLAR_JACOBI also carries per-tet state (quaternions and the rotated rest shape, SoftbodyGPU.js:49-55 `elems`/`quats`),
  * which this call leaves untouched: to continue a trajectory use tetsim_save_state / tetsim_load_state. */
 int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
-/* Checkpoint / resume of the COMPLETE solver state of an unpartitioned body (both solvers): positions, velocities and, for
- * POLAR_JACOBI, every tet's quaternion and carried rest shape -- everything the reference keeps in its ping-pong render
- * targets (SoftbodyGPU.js:49-55).  The blob is only meaningful for a body created from the same mesh with the same options by
- * the same library build family (it starts with a header that tetsim_load_state validates: magic, ABI, solver, precision,
- * flags, counts, and a digest of the mesh -- vertices, tets, density, batch layout -- so that a blob of ANOTHER mesh with the
- * same counts is rejected too).  A body restored from a blob continues the original trajectory bit for bit.  Both calls
- * synchronise (both streams). */
+/* Checkpoint / resume of the COMPLETE solver state (both solvers): positions, velocities and, for POLAR_JACOBI, every tet's
+ * quaternion and carried rest shape -- everything the reference keeps in its ping-pong render targets (SoftbodyGPU.js:49-55).
+ * The blob is only meaningful for a body created from the same mesh with the same options by the same library build family (it
+ * starts with a header that tetsim_load_state validates: magic, ABI, solver, precision, flags, counts, and a digest of the mesh --
+ * vertices, tets, density, batch layout -- so that a blob of ANOTHER mesh with the same counts is rejected too).  A body restored
+ * from a blob continues the original trajectory bit for bit.  Both calls synchronise (both streams).
+ * PARTITIONED bodies (since ABI 4): every partition saves and loads ITS OWN blob -- its owned particles, its ghosts (the predictions
+ * its neighbours sent for the next substep are state too) and its local tets incl. ghost tets; the digest also covers the cut
+ * (part_count, part_index, the owner map as this partition sees it), so a blob of another decomposition is rejected.  All ranks save
+ * at the same substep count (after tetsim_sync) and restore together: a multi-GPU run that lost a rank rebuilds its partitions with
+ * the same owner map, loads the last set of blobs, re-attaches the transport and continues bit for bit.  Transport state is not in
+ * the blob (semaphore words are at rest after a sync; the peer-to-peer halo's substep parity stays the restored body's own).  Not
+ * supported: bodies with a two-layer ghost region (TETSIM_FLAG_DEEP_GHOSTS). */
 int tetsim_state_size(tetsim_handle h, uint64_t *bytes_out);
 int tetsim_save_state(tetsim_handle h, void *blob, uint64_t bytes);
 int tetsim_load_state(tetsim_handle h, const void *blob, uint64_t bytes);
@@ -276,13 +281,27 @@ int tetsim_read_inv_mass(tetsim_handle h, float *out);
 
 /* Attach the embedded visual mesh: vis_verts = [4*nvis] rows (tetNr, b0, b1, b2) exactly as the reference's
  * `visVerts` (Dragon.js:1705; Softbody.js:46,263-267).  rest_normals = [3*nvis] object-space normals or NULL.
- * Unpartitioned bodies only. */
+ * PARTITIONED bodies (since ABI 4) take the same, global list on every rank and keep the rows whose tet they OWN (lowest-owner rule,
+ * TetSimInfo.owned_elems: exactly one partition per tet, and that partition solves the tet); TetSimInfo.num_vis_verts is the number
+ * kept, tetsim_get_visual_ids their row numbers -- the union over the partitions is the whole visual mesh, each row once. */
 int tetsim_set_visual_mesh(tetsim_handle h, const float *vis_verts, uint32_t nvis, const float *rest_normals);
-/* Skin on the device and read back.  positions_out [3*nvis]: sum_k b_k * pos[tet corner k] with b3 = 1-b0-b1-b2,
+/* row of the caller's vis_verts behind each attached visual vertex, [num_vis_verts] ascending (identity when unpartitioned) */
+int tetsim_get_visual_ids(tetsim_handle h, int32_t *out);
+/* Skin on the device and read back.  positions_out [3*num_vis_verts]: sum_k b_k * pos[tet corner k] with b3 = 1-b0-b1-b2,
  * evaluated like updateVisMesh (Softbody.js:259-277: f64 accumulate, f32 store per step; NEOHOOKEAN_GS + PRECISE is
  * bit-exact with it) or like the vertex shader of SoftbodyGPU.js:429-435 (POLAR_JACOBI, f32).
- * normals_out [3*nvis] (may be NULL): Rotate(rest_normal, quat[tetNr]) as SoftbodyGPU.js:440 -- POLAR_JACOBI only. */
+ * normals_out [3*num_vis_verts] (may be NULL): Rotate(rest_normal, quat[tetNr]) as SoftbodyGPU.js:440 -- POLAR_JACOBI only.
+ * A PARTITION returns its own rows (tetsim_get_visual_ids order); scattered by row number, the partitions' outputs equal the
+ * unpartitioned body's bit for bit (PRECISE).  Corners it does not own need their owner's END-OF-SUBSTEP position, which the
+ * per-substep halo does not carry (it carries predictions): RCCL bodies fetch them here -- every rank calls this together, once per
+ * frame --, in-process groups call tetsim_group_refresh_final first. */
 int tetsim_read_visual_mesh(tetsim_handle h, float *positions_out, float *normals_out);
+/* The end-of-substep positions of this partition's ghost particles, from their owners, into the ghost range behind
+ * tetsim_read_positions' owned range (what tetsim_read_visual_mesh needs; valid until the next step).  RCCL bodies: a collective of
+ * all ranks (one grouped send / recv per neighbour on the main stream, after a sync).  Unpartitioned: nothing to do. */
+int tetsim_halo_refresh_final(tetsim_handle h);
+/* The same for the partitions of an in-process group (device copies). */
+int tetsim_group_refresh_final(tetsim_handle *handles, uint32_t count);
 /* The visual mesh's triangle list, as the reference hands it to the geometry index (Dragon.js `dragonAttachedTriIds`;
  * Softbody.js:48-50, SoftbodyGPU.js:455-457): [3*ntri] ids of visual vertices.  Needed by tetsim_read_visual_vertex_normals. */
 int tetsim_set_visual_triangles(tetsim_handle h, const int32_t *tri_ids, uint32_t ntri);
@@ -544,7 +563,7 @@ int tetsim_mesh_arrays(tetsim_mesh m, TetSimMeshArrays *out);
 int tetsim_mesh_close(tetsim_mesh m);
 /* tetsim_create from a file: vertices/tets from the mapping; a stored colouring is used when opts->tet_colour is NULL
  * and the solver/order take one; a stored partition map is used when opts->part_count > 1, opts->vert_owner is NULL
- * and the stored part_count matches; a stored visual mesh is attached (tetsim_set_visual_mesh) on unpartitioned bodies. */
+ * and the stored part_count matches; a stored visual mesh is attached (tetsim_set_visual_mesh; partitions keep their rows). */
 int tetsim_create_from_file(const char *path, const TetSimOptions *opts, tetsim_handle *out);
 
 #ifdef __cplusplus

@@ -25,10 +25,14 @@ owner = np.minimum((np.arange(len(v)) // plane) // cells, nranks - 1).astype(np.
 kw = dict(solver="polar", precision=precision, ref_fixed_bounds=False)
 
 dts = [DT * (2.0 if c == 2 else 0.5 if c == 4 else 1.0) for c in range(calls)]   # the time step changes twice mid-run
-mono = SoftBodyHIP(v, t, None, dict(PP), **kw)
+# an embedded visual mesh over the whole body: every rank skins the rows whose tet it owns (ghost corners fetched over the transport)
+rng = np.random.default_rng(11)
+w = rng.dirichlet(np.ones(4), size=5000).astype(np.float32)
+vis = np.concatenate([rng.integers(0, len(t), size=(5000, 1)).astype(np.float32), w[:, :3]], axis=1)
+mono = SoftBodyHIP(v, t, None, dict(PP), vis, **kw)
 for c in range(calls):
     mono.simulateSubsteps(per_call, dts[c], PP)
-want = mono.pos
+want, want_vis = mono.pos, mono.visualPositions()
 
 uid = comm_unique_id()
 results, errors = [None] * nranks, []
@@ -36,7 +40,7 @@ results, errors = [None] * nranks, []
 
 def rank_main(r):
     try:
-        body = SoftBodyHIP(v, t, None, dict(PP), part_count=nranks, part_index=r, vert_owner=owner, **kw)
+        body = SoftBodyHIP(v, t, None, dict(PP), vis, part_count=nranks, part_index=r, vert_owner=owner, **kw)
         comm_init(body, uid, r, nranks)                       # blocks until every rank joined (like ncclCommInitRank)
         for c in range(calls):
             if c % 2:
@@ -44,7 +48,14 @@ def rank_main(r):
                     body.simulate(dts[c], PP)                    # tetsim_step, one substep per call
             else:
                 body.simulateSubsteps(per_call, dts[c], PP)      # tetsim_step_n
-        results[r] = (body.ownedIds, body.pos)
+        results[r] = (body.ownedIds, body.pos, body.visualIds, body.visualPositions())   # (visualPositions: a collective of the ranks)
+        # checkpoint / resume over the RCCL transport: every rank saves its blob, steps on, goes back, steps again -- the same bits
+        blob = body.saveState()
+        body.simulateSubsteps(5, dts[-1], PP)
+        after = body.pos.copy()
+        body.loadState(blob)
+        body.simulateSubsteps(5, dts[-1], PP)
+        assert np.array_equal(body.pos.view(np.uint32), after.view(np.uint32)), "rank %d: the restored partition left the trajectory" % r
         if precision == "fast" and cells >= 20:   # (thinner slabs: some ranks have no interior tiles and refuse, others would wait)
             # tetsim_profile on a body with an RCCL halo: every rank together, interior tet kernel timed
             try:
@@ -68,11 +79,12 @@ for th in threads:
 if errors or any(th.is_alive() for th in threads):
     print("FAILED", errors, [th.is_alive() for th in threads], flush=True)
     os._exit(1)
-got = np.full_like(want, np.nan)
-for ids, pos in results:
+got, got_vis = np.full_like(want, np.nan), np.full_like(want_vis, np.nan)
+for ids, pos, vids, vpos in results:
     got[ids] = pos
-err = float(np.abs(got - want).max())
-exact = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    got_vis[vids] = vpos
+err = max(float(np.abs(got - want).max()), float(np.abs(got_vis - want_vis).max()))
+exact = np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got_vis.view(np.uint32), want_vis.view(np.uint32))
 ok = exact if precision == "precise" else err <= 1e-4   # FAST: tile composition differs between decompositions (summation order)
 print("%s max|dx| = %.3g (bit-exact: %s), ymin %.4f" % ("OK" if ok else "MISMATCH", err, exact, float(want[:, 1].min())))
 sys.exit(0 if ok else 2)

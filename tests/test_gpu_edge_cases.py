@@ -265,25 +265,26 @@ def test_pinned_quaternion_view_equals_copying_read(kw):
 def test_library_info_on_the_gpu_box():
     from tetsim_amd import library_info
     info = library_info()
-    assert info["abi"] == 3 and info["ablation"] is False and len(info["source_sha"]) == 16
+    assert info["abi"] == 4 and info["ablation"] is False and len(info["source_sha"]) == 16
 
 
-def test_partitioned_body_ignores_the_visual_mesh(tmp_path):
-    """A partition owns a subset of the particles; a visual mesh handed to it (arrays or a .tetsim file that stores one) is
-    ignored instead of making the constructor fail."""
+def test_partitioned_bodies_keep_their_rows_of_the_visual_mesh(tmp_path):
+    """A partition owns a subset of the particles; of a visual mesh handed to it (arrays or a .tetsim file that stores one) it keeps
+    the rows whose tet it owns -- both partitions together: every row once (tests/test_gpu_partition_state.py skins them)."""
     from conftest import load_f32
     from tetsim_amd.meshfile import write_mesh
     v, t = load_mesh("dragon")
     vis = load_f32("dragon_vis.f32")
     part = SoftBodyHIP(v, t, None, dict(PP), vis, solver="polar", precision="fast", part_count=2, part_index=1)
-    assert part.info.num_vis_verts == 0 and part.info.owned_particles < len(v)
+    assert 0 < part.info.num_vis_verts < len(vis) // 4 and part.info.owned_particles < len(v)
     path = str(tmp_path / "d.tetsim")
     write_mesh(path, v, t, vis_verts=vis)
     part2 = SoftBodyHIP.fromFile(path, dict(PP), solver="polar", precision="fast", part_count=2, part_index=0)
     part2.simulate(DT, PP)
-    assert part2.info.num_vis_verts == 0 and np.isfinite(part2.pos).all()
+    assert part2.info.num_vis_verts + part.info.num_vis_verts == len(vis) // 4 and np.isfinite(part2.pos).all()
+    assert len(np.intersect1d(part.visualIds, part2.visualIds)) == 0
     whole = SoftBodyHIP.fromFile(path, dict(PP), solver="polar", precision="fast")
-    assert whole.info.num_vis_verts == len(vis) // 4
+    assert whole.info.num_vis_verts == len(vis) // 4 and np.array_equal(whole.visualIds, np.arange(len(vis) // 4))
 
 
 @pytest.mark.parametrize("kw", [dict(solver="polar", precision="precise"), dict(solver="polar", precision="fast"),

@@ -241,6 +241,8 @@ struct tetsim_body {
     std::vector<tetsim_body*> group;      // in-process group transport: partition i of the decomposition (or empty)
 
     SkinDev skin;  // embedded visual mesh
+    std::vector<int32_t> vis_global;   // row of the caller's visVerts behind each attached visual vertex (a partition keeps the rows of the tets it owns)
+    bool vis_attached = false;
     float* pinned_pos = nullptr;   // tetsim_read_positions_pinned: host-pinned xyz
     float* d_packed = nullptr;     //   and its device-side staging
     float* pinned_quat = nullptr;  // tetsim_read_quats_pinned: host-pinned xyzw per local tet
@@ -353,6 +355,7 @@ float4* ghost_buffer(tetsim_body* h, uint32_t parity);          // where ghost p
 int probe_queue_independence(tetsim_body* h);                   // flag path: may the two chains be replayed from graphs?
 int step_n_flag_graphs(tetsim_body* h, uint32_t n);             // n substeps of an RCCL flag-path body as two captured chains
 void frame_turn_enter(tetsim_body* h);                         // an exclusive persistent-launch body joins its device's turn-taking (tetsim_api.hip)
+int refresh_final_rccl(tetsim_body* h);                         // RCCL bodies: the ghosts' end-of-substep positions into pos_final's ghost range (collective)
 void drop_flag_graphs(tetsim_body* h);                          // destroy the captured chains (queues turned out not to be independent)
 
 }  // namespace tetsim

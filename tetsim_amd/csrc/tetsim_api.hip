@@ -104,6 +104,7 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
     HIPCHK(h, hipSetDevice(h->opt.device));  // group stepping walks over handles that may live on different devices
+    h->final_ghosts_fresh = false;           // (every stepping path comes through here: the ghosts' end-of-substep positions fetched for the visual mesh are stale)
     if (reuse_ok && h->params_known && !h->comm_stream && !h->partitioned) {   // (a halo queue keeps a copy of its own: always refreshed)
         // A host that keeps the reference's loop (main.js:79-84: simulate(dt, physicsParams) per substep) sends the same numbers again
         // and again: the copy and its event were most of what such a call cost (22.5 -> 7.8 us per tetsim_step on the Dragon,
@@ -427,7 +428,7 @@ int tetsim_create_from_file(const char* path, const TetSimOptions* opts, tetsim_
         o.vert_owner = a.vert_owner;
     }
     int rc = tetsim_create(a.verts, a.num_particles, a.tets, a.num_elems, &o, out);
-    if (rc == TETSIM_OK && a.vis_verts && a.num_vis_verts && o.part_count <= 1) {
+    if (rc == TETSIM_OK && a.vis_verts && a.num_vis_verts) {
         rc = tetsim_set_visual_mesh(*out, a.vis_verts, a.num_vis_verts, nullptr);
         if (rc != TETSIM_OK) { g_create_error = (*out)->err; tetsim_destroy(*out); *out = nullptr; }
     }

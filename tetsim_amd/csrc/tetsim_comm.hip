@@ -229,3 +229,73 @@ int tetsim_halo_import(tetsim_handle h, uint32_t n, const float* in_xyzw) {
 }
 
 }  // extern "C"
+
+// ---- end-of-substep positions of the ghost particles, on request -------------------------------------------------------------
+// The per-substep halo carries PREDICTIONS (what the next substep's ghost tets read); a ghost particle's end-of-substep position is
+// not needed by the solver and never travels.  The embedded visual mesh needs it: a visual vertex inside a tet that straddles a cut
+// blends four corners of which some belong to a neighbour (SoftbodyGPU.js:429-435).  So it is fetched when asked for -- once per
+// frame, not per substep: every partition sends the pos_final of its send lists into its neighbours' pos_final ghost ranges.
+namespace tetsim {
+int refresh_final_rccl(tetsim_body* h) {
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    for (auto& nb : h->neigh)
+        if (!nb.contiguous && nb.send_count) util_launch_gather4(h->stream, h->pj.pos_final, nb.send_idx, nb.send_buf, nb.send_count);
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
+    for (auto& nb : h->neigh) {
+        const int peer = h->loopback ? h->comm_rank : nb.rank;
+        if (nb.send_count) {
+            r = g_rccl.Send(nb.contiguous ? h->pj.pos_final + nb.send_first : nb.send_buf, 4ull * nb.send_count, ncclFloat, peer, h->comm, h->stream);
+            if (r != ncclSuccess) return rccl_fail(h, r, "ncclSend");
+        }
+        if (nb.recv_count) {
+            r = g_rccl.Recv(h->pj.pos_final + nb.recv_start, 4ull * nb.recv_count, ncclFloat, peer, h->comm, h->stream);
+            if (r != ncclSuccess) return rccl_fail(h, r, "ncclRecv");
+        }
+    }
+    r = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->final_ghosts_fresh = true;
+    return 0;
+}
+}  // namespace tetsim
+
+extern "C" {
+int tetsim_halo_refresh_final(tetsim_handle h) {
+    if (!h) return TETSIM_EINVAL;
+    if (!h->partitioned || h->neigh.empty()) { h->final_ghosts_fresh = true; return 0; }
+    if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
+    if (!h->comm) return fail(h, TETSIM_ESTATE, "no RCCL communicator on this body (in-process groups: tetsim_group_refresh_final)");
+    return refresh_final_rccl(h);
+}
+int tetsim_group_refresh_final(tetsim_handle* hs, uint32_t count) {
+    if (!hs || count == 0) return TETSIM_EINVAL;
+    for (uint32_t i = 0; i < count; i++)
+        if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i) || hs[i]->opt.solver != TETSIM_SOLVER_POLAR_JACOBI)
+            return fail(hs[i], TETSIM_EINVAL, "handles[i] must be partition i of a count-way POLAR_JACOBI decomposition");
+    for (uint32_t i = 0; i < count; i++) {   // every partition has finished its last substep before anyone's ghost range is written
+        HIPCHK(hs[i], hipSetDevice(hs[i]->opt.device));
+        HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream));
+        if (hs[i]->comm_stream) HIPCHK(hs[i], hipStreamSynchronize(hs[i]->comm_stream));
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        tetsim_body* src = hs[i];
+        HIPCHK(src, hipSetDevice(src->opt.device));
+        for (auto& nb : src->neigh) {
+            if (!nb.send_count) continue;
+            tetsim_body* dst = hs[nb.rank];
+            NeighDev* back = nullptr;
+            for (auto& r : dst->neigh) if (r.rank == static_cast<int>(i)) back = &r;
+            if (!back || back->recv_count != nb.send_count) return fail(src, TETSIM_ESTATE, "asymmetric halo plan");
+            if (!nb.contiguous) util_launch_gather4(src->stream, src->pj.pos_final, nb.send_idx, nb.send_buf, nb.send_count);
+            HIPCHK(src, hipMemcpyAsync(dst->pj.pos_final + back->recv_start, nb.contiguous ? src->pj.pos_final + nb.send_first : nb.send_buf,
+                                       nb.send_count * sizeof(float4), hipMemcpyDeviceToDevice, src->stream));
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) { HIPCHK(hs[i], hipSetDevice(hs[i]->opt.device)); HIPCHK(hs[i], hipStreamSynchronize(hs[i]->stream)); hs[i]->final_ghosts_fresh = true; }
+    return 0;
+}
+}  // extern "C"

@@ -8,60 +8,109 @@ extern "C" {
 
 int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvis, const float* rest_normals) {
     if (!h || (nvis && !vis_verts)) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->partitioned) return fail(h, TETSIM_ESTATE, "visual meshes are supported on unpartitioned bodies only");
-    if (h->skin.nvis) return fail(h, TETSIM_ESTATE, "a visual mesh is already attached");
+    if (h->skin.nvis || !h->vis_global.empty()) return fail(h, TETSIM_ESTATE, "a visual mesh is already attached");
     HIPCHK(h, hipSetDevice(h->opt.device));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     const uint32_t nt = h->info.num_elems;
-    std::vector<int32_t> tet_pos;  // caller's tet id -> device tet position (quaternion index)
-    if (pjs) {
-        tet_pos.resize(nt);
-        for (uint32_t i = 0; i < nt; i++) tet_pos[h->blocked ? h->tet_perm[i] : i] = static_cast<int32_t>(i);
+    // A PARTITION takes the same (global) list on every rank and keeps the visual vertices whose tet it OWNS by the lowest-owner rule
+    // (TetSimInfo.owned_elems: every tet has exactly one such partition, and that partition solves it, so the tet's quaternion is
+    // local); the union over the partitions is the whole visual mesh, tetsim_get_visual_ids says which rows a partition kept.
+    // Corners of a kept tet are owned or ghost particles: the ghosts' end-of-substep positions are fetched by
+    // tetsim_read_visual_mesh (tetsim_halo_refresh_final).
+    std::vector<int32_t> g2l_tet, g2l_vert;
+    if (h->partitioned) {
+        g2l_tet.assign(nt, -1);
+        for (size_t i = 0; i < h->part.local_to_global_tet.size(); i++) g2l_tet[h->part.local_to_global_tet[i]] = static_cast<int32_t>(i);
+        g2l_vert.assign(h->info.num_particles, -1);
+        for (size_t i = 0; i < h->part.local_to_global_vert.size(); i++) g2l_vert[h->part.local_to_global_vert[i]] = static_cast<int32_t>(i);
     }
-    std::vector<int4> corner(nvis);
-    std::vector<float4> weight(nvis), n0(nvis);
-    std::vector<int32_t> qidx(nvis, 0);
+    std::vector<int32_t> tet_pos;  // (local) tet id -> device tet position (quaternion index)
+    if (pjs) {
+        const uint32_t ntl = h->partitioned ? h->info.local_elems : nt;
+        tet_pos.resize(ntl);
+        for (uint32_t i = 0; i < ntl; i++) tet_pos[h->blocked ? h->tet_perm[i] : i] = static_cast<int32_t>(i);
+    }
+    std::vector<int4> corner;
+    std::vector<float4> weight, n0;
+    std::vector<int32_t> qidx, kept;
     for (uint32_t i = 0; i < nvis; i++) {
         const float tn = vis_verts[4 * i];
         if (!(tn >= 0.0f) || tn >= static_cast<float>(nt) || tn != std::floor(tn)) return fail(h, TETSIM_EINVAL, "visual vertex " + std::to_string(i) + " references a tet outside the mesh");
         const uint32_t e = static_cast<uint32_t>(tn);
+        uint32_t el = e;   // the tet in this handle's numbering
+        if (h->partitioned) {
+            int lowest = h->opt.part_count;
+            bool all_local = g2l_tet[e] >= 0;
+            for (int k = 0; k < 4 && all_local; k++) {
+                const int32_t lv = g2l_vert[h->h_tets[4 * e + k]];
+                if (lv < 0) { all_local = false; break; }
+                // owner of a local particle: this partition for the owned range, the neighbour whose receive range holds it otherwise
+                int owner = h->opt.part_index;
+                if (static_cast<uint32_t>(lv) >= h->part.n_owned)
+                    for (const auto& nb : h->part.neigh)
+                        if (static_cast<uint32_t>(lv) >= nb.recv_start && static_cast<uint32_t>(lv) < nb.recv_start + nb.recv_count) owner = nb.rank;
+                lowest = std::min(lowest, owner);
+            }
+            if (!all_local || lowest != h->opt.part_index) continue;   // another partition's row
+            el = static_cast<uint32_t>(g2l_tet[e]);
+        }
         int32_t c[4];
         for (int k = 0; k < 4; k++) {
-            const int32_t v = h->h_tets[4 * e + k];
+            int32_t v = h->h_tets[4 * e + k];
+            if (h->partitioned) v = g2l_vert[v];
             c[k] = (pjs && !h->api2dev.empty()) ? static_cast<int32_t>(h->api2dev[v]) : v;
         }
-        corner[i] = make_int4(c[0], c[1], c[2], c[3]);
-        weight[i] = make_float4(vis_verts[4 * i + 1], vis_verts[4 * i + 2], vis_verts[4 * i + 3], 0.0f);
-        if (pjs) qidx[i] = tet_pos[e];
-        if (rest_normals) n0[i] = make_float4(rest_normals[3 * i], rest_normals[3 * i + 1], rest_normals[3 * i + 2], 0.0f);
+        corner.push_back(make_int4(c[0], c[1], c[2], c[3]));
+        weight.push_back(make_float4(vis_verts[4 * i + 1], vis_verts[4 * i + 2], vis_verts[4 * i + 3], 0.0f));
+        qidx.push_back(pjs ? tet_pos[el] : 0);
+        if (rest_normals) n0.push_back(make_float4(rest_normals[3 * i], rest_normals[3 * i + 1], rest_normals[3 * i + 2], 0.0f));
+        kept.push_back(static_cast<int32_t>(i));
     }
+    const uint32_t nk = static_cast<uint32_t>(kept.size());
     SkinDev& k = h->skin;
     int4* dc; float4 *dw, *dn = nullptr; int32_t* dq;
     int rc;
-    if ((rc = dev_alloc(h, &dc, nvis))) return rc;
-    if ((rc = dev_alloc(h, &dw, nvis))) return rc;
-    if ((rc = dev_alloc(h, &dq, nvis))) return rc;
-    if ((rc = dev_alloc(h, &k.out_pos, nvis))) return rc;
+    if ((rc = dev_alloc(h, &dc, nk))) return rc;
+    if ((rc = dev_alloc(h, &dw, nk))) return rc;
+    if ((rc = dev_alloc(h, &dq, nk))) return rc;
+    if ((rc = dev_alloc(h, &k.out_pos, nk))) return rc;
     if ((rc = upload(h, dc, corner))) return rc;
     if ((rc = upload(h, dw, weight))) return rc;
     if ((rc = upload(h, dq, qidx))) return rc;
     if (rest_normals && pjs) {
-        if ((rc = dev_alloc(h, &dn, nvis))) return rc;
-        if ((rc = dev_alloc(h, &k.out_nrm, nvis))) return rc;
+        if ((rc = dev_alloc(h, &dn, nk))) return rc;
+        if ((rc = dev_alloc(h, &k.out_nrm, nk))) return rc;
         if ((rc = upload(h, dn, n0))) return rc;
     }
     k.corner = dc; k.weight = dw; k.qidx = dq; k.normal0 = dn;
-    k.nvis = nvis;
-    h->info.num_vis_verts = nvis;
+    k.nvis = nk;
+    h->vis_global = kept;
+    h->vis_attached = true;
+    h->info.num_vis_verts = nk;
+    return 0;
+}
+
+int tetsim_get_visual_ids(tetsim_handle h, int32_t* out) {
+    if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->vis_attached) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
+    std::copy(h->vis_global.begin(), h->vis_global.end(), out);
     return 0;
 }
 
 int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normals_out) {
     if (!h || !positions_out) return fail(h, TETSIM_EINVAL, "null argument");
-    if (!h->skin.nvis) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
+    if (!h->vis_attached) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
-    if (normals_out && !h->skin.out_nrm) return fail(h, TETSIM_ESTATE, "normals need POLAR_JACOBI and rest normals at tetsim_set_visual_mesh");
+    if (normals_out && h->skin.nvis && !h->skin.out_nrm) return fail(h, TETSIM_ESTATE, "normals need POLAR_JACOBI and rest normals at tetsim_set_visual_mesh");
     HIPCHK(h, hipSetDevice(h->opt.device));
+    if (h->partitioned && !h->neigh.empty() && !h->final_ghosts_fresh) {
+        // the corners this partition does not own: their end-of-substep positions come from the neighbours (a collective of the ranks
+        // when the transport is RCCL -- every rank reads its visual mesh at the frame's end; groups of one process fetch them for all members at once)
+        if (h->comm) { if (int rc = refresh_final_rccl(h)) return rc; }
+        else return fail(h, TETSIM_ESTATE, "the ghost particles' end-of-substep positions are stale: call tetsim_group_refresh_final (in-process group) or "
+                                          "tetsim_halo_refresh_final (RCCL) after the frame's last substep, before reading the visual mesh of a partition");
+    }
+    if (!h->skin.nvis) return 0;   // (a partition that owns no tet with a visual vertex)
     // Softbody.js arithmetic for the solver that mirrors Softbody.js, the vertex-shader arithmetic for the other
     skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -78,6 +127,8 @@ int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normal
 
 int tetsim_set_visual_triangles(tetsim_handle h, const int32_t* tri_ids, uint32_t ntri) {
     if (!h || (ntri && !tri_ids)) return fail(h, TETSIM_EINVAL, "null argument");
+    if (h->partitioned) return fail(h, TETSIM_ESTATE, "visual triangles (computeVertexNormals) are supported on unpartitioned bodies only: a triangle's corners may be "
+                                                      "skinned by different partitions; partitions deliver the quaternion-rotated normals of tetsim_read_visual_mesh");
     if (!h->skin.nvis) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
     if (h->skin.vt_off) return fail(h, TETSIM_ESTATE, "visual triangles are already attached");
     HIPCHK(h, hipSetDevice(h->opt.device));

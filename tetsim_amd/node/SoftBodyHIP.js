@@ -74,14 +74,17 @@ class SoftBodyHIP {
         this.visVerts = visVerts || new Float32Array(0);
         this.numVisVerts = this.visVerts.length / 4;
         this._partitioned = createOptions.partCount > 1;
-        // a partition owns a subset of the particles: the embedded mesh (whose vertices hang on tets anywhere in the body) is
-        // skinned on unpartitioned bodies only; a partitioned body is physics + its own particles, no visual mesh
-        if (this.numVisVerts > 0 && !this._partitioned) {   // skin the embedded mesh on the device (SURVEY.md §8(f)-1); createFromFile attached it already
+        // The embedded mesh is skinned on the device (SURVEY.md §8(f)-1; createFromFile attached it already).  A PARTITION takes the same
+        // list and keeps the rows whose tet it owns (visualIds()): readVisualPositions() then returns ITS rows, and the ranks' outputs,
+        // scattered by row number (scatterVisualPositions), are the whole mesh -- SoftbodyGPU.js:424-448 skins every vertex every frame.
+        if (this.numVisVerts > 0) {
             if (!_meshFile) api.setVisualMesh(this._h, this.visVerts instanceof Float32Array ? this.visVerts : Float32Array.from(this.visVerts), null);
             this._visOnDevice = true;
+            this._visIds = this._partitioned ? api.visualIds(this._h) : null;
             // ... and its vertex normals too: Softbody.js:273 runs geometry.computeVertexNormals() every frame (37 ms of the
-            // CPU path's frame); the device reproduces three.js's result bit for bit (tetsim_read_visual_vertex_normals)
-            this._visTris = visTriIds && visTriIds.length ? (visTriIds instanceof Int32Array ? visTriIds : Int32Array.from(visTriIds)) : null;
+            // CPU path's frame); the device reproduces three.js's result bit for bit (tetsim_read_visual_vertex_normals; a triangle's
+            // corners may be skinned by different partitions, so unpartitioned bodies only)
+            this._visTris = !this._partitioned && visTriIds && visTriIds.length ? (visTriIds instanceof Int32Array ? visTriIds : Int32Array.from(visTriIds)) : null;
             if (this._visTris) api.setVisualTriangles(this._h, this._visTris);
         }
         if (THREE) {
@@ -208,8 +211,20 @@ class SoftBodyHIP {
     }
     readVisualPositions(out) {                          // Float32Array [3*numVisVerts], skinned on the GPU
         out = out || new Float32Array(3 * this.numVisVerts);
-        if (this._visOnDevice) this._api.readVisualMesh(this._h, out, null);
+        if (!this._visOnDevice) return out;
+        if (this._visIds) return this.scatterVisualPositions(out);
+        this._api.readVisualMesh(this._h, out, null);
         return out;
+    }
+    // partitions: which rows of visVerts this rank skins, and its rows written into a full-size [3*numVisVerts] array (the other
+    // ranks' rows are left as they are: a host that gathers the ranks' arrays row by row has the whole mesh).  With an RCCL
+    // transport every rank calls this together (the ghost corners' end-of-substep positions are fetched from their owners).
+    visualIds() { return this._visIds || Int32Array.from({ length: this.numVisVerts }, (_, i) => i); }
+    scatterVisualPositions(full) {
+        const ids = this._visIds, own = new Float32Array(3 * ids.length);
+        this._api.readVisualMesh(this._h, own, null);
+        for (let i = 0; i < ids.length; i++) { const r = 3 * ids[i]; full[r] = own[3 * i]; full[r + 1] = own[3 * i + 1]; full[r + 2] = own[3 * i + 2]; }
+        return full;
     }
 
     // ---- grab (Softbody.js:279-298) ------------------------------------------------------------------------------

@@ -227,15 +227,23 @@ if (process.env.TETSIM_TEST_MESH) {
     b8.dispose();
     console.log('shim hardening: length checks, number checks, detached views after dispose, quaternion view, save/load state ok');
 }
-if (process.env.TETSIM_TEST_MESH) {   // a partitioned body from a file that carries a visual mesh (used to throw)
+if (process.env.TETSIM_TEST_MESH) {   // partitioned bodies from a file that carries a visual mesh: each keeps the rows of the tets it owns
     const nvv = verts.length / 3;
     const owner = new Int32Array(nvv); for (let i = 0; i < nvv; i++) owner[i] = i < nvv / 2 ? 0 : 1;
-    const p10 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'fast', partCount: 2, partIndex: 0, vertOwner: owner } });
-    const part = SoftBodyHIP.fromFile(process.env.TETSIM_TEST_MESH, p10, null, null);
-    assert.strictEqual(part.info().numVisVerts, 0); assert.ok(part.info().ownedParticles < nvv);
-    part.simulate(dt20, p10); part.endFrame();
-    part.dispose();
-    console.log('partitioned fromFile body with a stored visual mesh: constructed, stepped (no visual mesh on partitions)');
+    const seen = new Uint8Array(29800);
+    let total = 0;
+    for (let r = 0; r < 2; r++) {
+        const p10 = Object.assign({}, pp, { numSubsteps: 20, tetsim: { solver: 'polar', precision: 'fast', partCount: 2, partIndex: r, vertOwner: owner } });
+        const part = SoftBodyHIP.fromFile(process.env.TETSIM_TEST_MESH, p10, null, null);
+        const ids = part.visualIds();
+        assert.strictEqual(part.info().numVisVerts, ids.length); assert.ok(ids.length > 0 && ids.length < 29800); assert.ok(part.info().ownedParticles < nvv);
+        for (const i of ids) { assert.strictEqual(seen[i], 0); seen[i] = 1; }
+        total += ids.length;
+        part.simulate(dt20, p10); part.endFrame();
+        part.dispose();
+    }
+    assert.strictEqual(total, 29800);   // every row of the Dragon's visVerts in exactly one partition
+    console.log('partitioned fromFile bodies with a stored visual mesh: the two partitions keep ' + total + ' visual vertices between them, each once');
 }
 // 7. startGrab exactly as SoftbodyGPU.js:692-704 (tetsim.refStartGrab): the search runs over the edge mesh's copy of the positions
 {

@@ -45,6 +45,7 @@ struct Api {
     decltype(&tetsim_get_local_tets) get_local_tets = nullptr;
     decltype(&tetsim_set_visual_mesh) set_visual_mesh = nullptr;
     decltype(&tetsim_read_visual_mesh) read_visual_mesh = nullptr;
+    decltype(&tetsim_get_visual_ids) get_visual_ids = nullptr;
     decltype(&tetsim_set_visual_triangles) set_visual_triangles = nullptr;
     decltype(&tetsim_read_visual_vertex_normals) read_visual_vertex_normals = nullptr;
     decltype(&tetsim_set_grab) set_grab = nullptr;
@@ -69,6 +70,9 @@ bool load_lib(const std::string& hint) {
     g.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!g.lib) { g.err = std::string("cannot load ") + path + ": " + dlerror(); return false; }
 #define SYM(field, name) g.field = reinterpret_cast<decltype(g.field)>(dlsym(g.lib, name)); if (!g.field) { g.err = std::string("libtetsim_hip lacks ") + name; return false; }
+    // the ABI first: an older library lacks newer symbols, and "ABI version mismatch" is the message a maintainer can act on
+    SYM(abi_version, "tetsim_abi_version")
+    if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch: the library is ABI " + std::to_string(g.abi_version()) + ", this addon was built for ABI " + std::to_string(TETSIM_ABI_VERSION); return false; }
     SYM(default_options, "tetsim_default_options") SYM(default_params, "tetsim_default_params") SYM(create, "tetsim_create")
     SYM(destroy, "tetsim_destroy") SYM(last_error, "tetsim_last_error") SYM(get_info, "tetsim_get_info") SYM(step, "tetsim_step")
     SYM(step_n, "tetsim_step_n") SYM(sync, "tetsim_sync") SYM(read_positions, "tetsim_read_positions") SYM(read_positions_pinned, "tetsim_read_positions_pinned")
@@ -77,13 +81,12 @@ bool load_lib(const std::string& hint) {
     SYM(set_visual_mesh, "tetsim_set_visual_mesh") SYM(read_visual_mesh, "tetsim_read_visual_mesh")
     SYM(set_visual_triangles, "tetsim_set_visual_triangles") SYM(read_visual_vertex_normals, "tetsim_read_visual_vertex_normals")
     SYM(create_batch, "tetsim_create_batch") SYM(get_batch_layout, "tetsim_get_batch_layout")
-    SYM(abi_version, "tetsim_abi_version") SYM(read_quats_pinned, "tetsim_read_quats_pinned") SYM(state_size, "tetsim_state_size")
+    SYM(get_visual_ids, "tetsim_get_visual_ids") SYM(read_quats_pinned, "tetsim_read_quats_pinned") SYM(state_size, "tetsim_state_size")
     SYM(save_state, "tetsim_save_state") SYM(load_state, "tetsim_load_state") SYM(library_info, "tetsim_library_info")
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
     SYM(prep_partition, "tetsim_prep_partition") SYM(prep_partition_quality, "tetsim_prep_partition_quality")
 #undef SYM
-    if (g.abi_version() != TETSIM_ABI_VERSION) { g.err = "libtetsim_hip ABI version mismatch"; return false; }
     return true;
 }
 
@@ -577,6 +580,21 @@ napi_value ReadVisualMesh(napi_env env, napi_callback_info info) {
     if (want_normals && nn < 3ull * inf.num_vis_verts) return throw_err(env, "normals output array too small (3 floats per visual vertex)");
     return check(env, g.read_visual_mesh(h, po, want_normals ? no : nullptr), h);
 }
+// visualIds(handle) -> Int32Array: row of the caller's visVerts behind each attached visual vertex (a partition keeps the rows of the tets it owns)
+napi_value VisualIds(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    napi_value ab, out;
+    void* data = nullptr;
+    if (napi_create_arraybuffer(env, sizeof(int32_t) * inf.num_vis_verts, &data, &ab) != napi_ok) return throw_err(env, "cannot allocate");
+    if (inf.num_vis_verts && g.get_visual_ids(h, static_cast<int32_t*>(data)) != 0) return throw_err(env, g.last_error(h));
+    napi_create_typedarray(env, napi_int32_array, inf.num_vis_verts, ab, 0, &out);
+    return out;
+}
 // setVisualTriangles(handle, Int32Array visTriIds)
 napi_value SetVisualTriangles(napi_env env, napi_callback_info info) {
     napi_value a[2];
@@ -712,6 +730,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"readVolError", nullptr, ReadVolError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"visualIds", nullptr, VisualIds, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualTriangles", nullptr, SetVisualTriangles, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualVertexNormals", nullptr, ReadVisualVertexNormals, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

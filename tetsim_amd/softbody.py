@@ -70,7 +70,7 @@ class SoftBodyHIP:
             from .meshfile import MeshFile
             with MeshFile(mesh_file) as mf:
                 vertices, tetIds = mf.verts.copy(), mf.tets.copy()
-                if visVerts is None and mf.vis_verts is not None and part_count <= 1:
+                if visVerts is None and mf.vis_verts is not None:
                     visVerts = mf.vis_verts.copy()
                     if visTriIds is None and mf.vis_tri_ids is not None:
                         visTriIds = mf.vis_tri_ids.copy()
@@ -125,12 +125,12 @@ class SoftBodyHIP:
         capi.check(L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
         self._L = L
         self.numVisVerts = 0
-        if visVerts is not None and len(visVerts) and part_count <= 1:   # Softbody.js:46-47: rows (tetNr, b0, b1, b2); unpartitioned bodies only
+        if visVerts is not None and len(visVerts):   # Softbody.js:46-47: rows (tetNr, b0, b1, b2); a partition keeps the rows of the tets it owns (visualIds)
             if mesh_file is not None:   # tetsim_create_from_file attached the stored visual mesh already
-                self.numVisVerts, self._has_normals = len(np.asarray(visVerts).reshape(-1)) // 4, False
+                self.numVisVerts, self._has_normals = self.info.num_vis_verts, False
             else:
                 self.setVisualMesh(visVerts)
-            if visTriIds is not None and len(visTriIds):   # Softbody.js:48-50: enables visualVertexNormals()
+            if visTriIds is not None and len(visTriIds) and part_count <= 1:   # Softbody.js:48-50: enables visualVertexNormals() (unpartitioned bodies)
                 self.setVisualTriangles(visTriIds)
 
     @classmethod
@@ -282,6 +282,20 @@ class SoftBodyHIP:
         n0 = None if restNormals is None else _f32(restNormals).reshape(-1)
         capi.check(self._L.tetsim_set_visual_mesh(self._h, _fp(vv), self.numVisVerts, _fp(n0) if n0 is not None else None), self._h)
         self._has_normals = n0 is not None
+        capi.check(self._L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
+        self.numVisVerts = self.info.num_vis_verts   # (a partition keeps the rows of the tets it owns: visualIds)
+
+    @property
+    def visualIds(self):
+        """Row of the caller's visVerts behind each attached visual vertex (identity when unpartitioned; a partition: its own rows)."""
+        out = np.empty(self.numVisVerts, dtype=np.int32)
+        capi.check(self._L.tetsim_get_visual_ids(self._h, _ip(out)), self._h)
+        return out
+
+    def refreshFinalGhosts(self):
+        """RCCL partitions, every rank together: the ghost particles' end-of-substep positions from their owners (visualPositions does
+        it by itself; in-process groups: group_refresh_final)."""
+        capi.check(self._L.tetsim_halo_refresh_final(self._h), self._h)
 
     def visualPositions(self, with_normals=False):
         out = np.empty(3 * self.numVisVerts, dtype=np.float32)
@@ -421,6 +435,13 @@ def group_step_n(bodies, n, dt, physicsParams):
     """n substeps of every partition of one decomposition (same choreography as the RCCL path, in-process copies)."""
     arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
     capi.check(capi.lib().tetsim_group_step_n(arr, len(bodies), int(n), float(dt), C.byref(make_params(physicsParams))))
+
+
+def group_refresh_final(bodies):
+    """In-process group: every partition's ghost particles get their END-OF-SUBSTEP positions from their owners (what the visual mesh
+    of a partition needs at the frame's end; the per-substep halo carries predictions)."""
+    arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
+    capi.check(capi.lib().tetsim_group_refresh_final(arr, len(bodies)))
 
 
 P2P_BLOB_BYTES = 512
