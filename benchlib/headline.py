@@ -11,7 +11,7 @@ from .common import CELLS, DT, HBM_PEAK_GBS, PP, ROOT, SUBSTEPS, TET_KERNEL_BYTE
 from .cpu import cpu_baseline
 from .body import make_body, timed_frames
 from .launcher import GUARD
-from .legs import beyond_mall, multi_gpu_report, other_configs, p2p_check, promote_p2p, run_neohookean
+from .legs import beyond_mall, halo_probe_report, multi_gpu_report, other_configs, p2p_check, promote_p2p, run_neohookean
 
 
 # How an N-rank headline run may be repeated when a transport fails on the node it meets: each rung rebuilds every rank's body with
@@ -362,6 +362,9 @@ def run(args, rank, world, local_rank, ranks):
     # ---- optional legs of an N-rank run: nothing below may cost the headline (HeadlineGuard) ------------------------------------
     if use_dist and world > 1:
         GUARD.arm(out, int(os.environ.get("TETSIM_BENCH_OPTIONAL_S", "240")), "the legs after the headline (peer-to-peer halo check / config 5)")
+        hp = halo_probe_report(body, ranks)   # (the body is between steps: the timed region ended with a sync + barrier)
+        if rank == 0 and out is not None and "multi_gpu" in out:
+            out["multi_gpu"]["halo_exchange_us"] = hp
     if use_dist and world > 1 and args.halo == "rccl" and (args.p2p_check == "on" or (args.p2p_check == "auto" and not args.fake_ranks)):
         try:
             pos_rccl = body.pos

@@ -210,6 +210,21 @@ def multi_gpu_report(body, world, elapsed_local, host_local, steps, ranks):
         rep["loopback"] = True
     return rep
 
+def halo_probe_report(body, ranks):
+    """The transfer term of the substep's halo chain on THIS wire: 100 exchanges of the real messages with the real neighbours (a
+    collective of the ranks; idempotent).  The chain is  wait V + halo-side tiles + boundary particles (~19 us on one GPU)  +  this.
+    Runs under the HeadlineGuard: nothing here may cost the line."""
+    try:
+        from tetsim_amd import halo_probe
+        hp = halo_probe(body, 100)
+        return {"rank0": {k: round(v, 1) for k, v in hp.items()}, "median_min_over_ranks": round(ranks.min_float(hp["median"]), 1),
+                "median_max_over_ranks": round(ranks.max_float(hp["median"]), 1),
+                "what": "grouped ncclSend / ncclRecv of this rank's halo messages to its neighbours, events on the halo stream, 100 repetitions between steps"}
+    except Exception as e:  # noqa: BLE001
+        ranks.min_float(0.0); ranks.max_float(0.0)   # (keep the collectives of the ranks in step)
+        return {"error": repr(e)[:200]}
+
+
 def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
     """The headline run once more on a fresh body whose halo goes peer to peer (include/tetsim.h: tetsim_halo_p2p_connect): the same
     warm-up and timed frames from the same rest state, so the owned positions must equal the RCCL run's BIT FOR BIT -- on real

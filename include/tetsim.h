@@ -384,6 +384,11 @@ int tetsim_comm_selftest(tetsim_handle h);
  * host_us = host time to issue one group, total_us = wall time per group.  Design input for DESIGN.md 7. */
 int tetsim_comm_probe(tetsim_handle h, uint64_t bytes, uint32_t reps, int32_t use_graph, uint32_t per_graph,
                       double *host_us, double *total_us);
+/* What one halo exchange costs this rank with ITS neighbours and message sizes: `reps` grouped send / recv of the current predictions
+ * into the neighbours' ghost ranges (idempotent), each bracketed by events on the halo stream; min / median / max in microseconds.
+ * A collective of all ranks (same reps), between steps.  The transfer term of the substep's halo chain, measured on the real wire
+ * (bench.py --gpus N reports it per rank).  Since ABI 4. */
+int tetsim_halo_probe(tetsim_handle h, uint32_t reps, double *min_us, double *median_us, double *max_us);
 /* Peer-to-peer halo (opt-in; POLAR_JACOBI + TETSIM_FAST blocked partitions).  The per-substep ghost exchange without a transfer
  * kernel: each rank's boundary-particle kernel stores its new predictions straight into the neighbours' ghost ranges (peer memory
  * over xGMI, mapped through HIP IPC; double buffered by substep parity) and a word per neighbour says "arrived"; the halo-side

@@ -134,6 +134,9 @@ def test_multi_rank_code_path_with_thread_ranks(extra):
     plane = (cells + 1) ** 2
     assert mg["halo_rank0"] == {"neighbours": 1, "send_bytes_per_substep": 16 * plane, "recv_bytes_per_substep": 16 * plane, "max_message_bytes": 16 * plane}
     assert mg["halo_max_message_bytes_over_ranks"] == 16 * plane
+    # ... and the transfer term of the halo chain, measured on the transport the run used (100 exchanges of the real messages)
+    hx = mg["halo_exchange_us"]
+    assert 0 < hx["rank0"]["min"] <= hx["rank0"]["median"] <= hx["rank0"]["max"] and hx["median_min_over_ranks"] <= hx["median_max_over_ranks"]
     if "--config5" in extra:
         c5 = d["config5_strong"]
         assert c5["scaling"] == "strong" and c5["value"] > 0 and c5["finite"] is True and "18^3" in c5["workload"] and "3 z-slabs" in c5["workload"]

@@ -264,6 +264,43 @@ int refresh_final_rccl(tetsim_body* h) {
 }  // namespace tetsim
 
 extern "C" {
+// What one halo exchange costs THIS rank with ITS neighbours and ITS message sizes -- the transfer term of the substep's halo chain
+// (wait V + halo-side tiles + boundary particles + transfer) -- measured, not assumed: `reps` times the grouped send /
+// recv of the current predictions into the neighbours' ghost ranges (idempotent: the ghosts already hold these values), each bracketed
+// by events on the halo stream.  A collective: every rank calls it with the same `reps`, between steps.  bench.py --gpus N reports it
+// per rank so that the first run on real xGMI says which term of the chain the wire is.
+int tetsim_halo_probe(tetsim_handle h, uint32_t reps, double* min_us, double* median_us, double* max_us) {
+    if (!h || !min_us || !median_us || !max_us || reps == 0 || reps > 4096) return fail(h, TETSIM_EINVAL, "bad argument");
+    if (!h->comm || !h->comm_stream) return fail(h, TETSIM_ESTATE, "no RCCL communicator on this body (tetsim_comm_init)");
+    if (h->deep) return fail(h, TETSIM_ESTATE, "bodies with a two-layer ghost region exchange their ghosts through the peer-to-peer halo only");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    struct Events : std::vector<hipEvent_t> { using std::vector<hipEvent_t>::vector; ~Events() { for (hipEvent_t e : *this) if (e) (void)hipEventDestroy(e); } } ev(2ull * reps, nullptr);
+    for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+    for (uint32_t i = 0; i < reps; i++) {
+        HIPCHK(h, hipEventRecord(ev[2 * i], h->comm_stream));
+        for (auto& nb : h->neigh)
+            if (!nb.contiguous && nb.send_count) util_launch_gather4(h->comm_stream, h->pj.pos_pred, nb.send_idx, nb.send_buf, nb.send_count);
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return rccl_fail(h, r, "ncclGroupStart");
+        for (auto& nb : h->neigh) {
+            const int peer = h->loopback ? h->comm_rank : nb.rank;
+            if (nb.send_count && (r = g_rccl.Send(nb.contiguous ? h->pj.pos_pred + nb.send_first : nb.send_buf, 4ull * nb.send_count, ncclFloat, peer, h->comm, h->comm_stream)) != ncclSuccess)
+                return rccl_fail(h, r, "ncclSend");
+            if (nb.recv_count && (r = g_rccl.Recv(ghost_buffer(h, static_cast<uint32_t>(h->p2p_round)) + (nb.recv_start - h->pj.nv_owned), 4ull * nb.recv_count, ncclFloat, peer, h->comm, h->comm_stream)) != ncclSuccess)
+                return rccl_fail(h, r, "ncclRecv");
+        }
+        if ((r = g_rccl.GroupEnd()) != ncclSuccess) return rccl_fail(h, r, "ncclGroupEnd");
+        HIPCHK(h, hipEventRecord(ev[2 * i + 1], h->comm_stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    std::vector<double> us(reps);
+    for (uint32_t i = 0; i < reps; i++) { float ms = 0.0f; HIPCHK(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); us[i] = 1e3 * ms; }
+    std::sort(us.begin(), us.end());
+    *min_us = us.front(); *median_us = us[reps / 2]; *max_us = us.back();
+    return 0;
+}
 int tetsim_halo_refresh_final(tetsim_handle h) {
     if (!h) return TETSIM_EINVAL;
     if (!h->partitioned || h->neigh.empty()) { h->final_ghosts_fresh = true; return 0; }

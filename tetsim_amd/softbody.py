@@ -394,6 +394,14 @@ class SoftBodyHIP:
         return ms.value
 
 
+def halo_probe(body, reps=100):
+    """{min, median, max} microseconds of one halo exchange of this rank with its real neighbours and message sizes (a collective of
+    all ranks, between steps; include/tetsim.h: tetsim_halo_probe)."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    capi.check(capi.lib().tetsim_halo_probe(body._h, int(reps), C.byref(a), C.byref(b), C.byref(c)), body._h)
+    return {"min": a.value, "median": b.value, "max": c.value}
+
+
 def comm_unique_id():
     """128-byte RCCL unique id (rank 0 creates it; the host distributes it to every rank)."""
     buf = (C.c_char * 128)()
