@@ -264,7 +264,7 @@ def run(args, rank, world, local_rank, ranks):
         units = win["tets_per_tet_launch"]
         kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
         if body.info.fused_particle_pass in (1, 2):   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
-            kname, tet_bytes = "pjb_tet_fused_kernel", b_alg
+            kname, tet_bytes = "pjb_tet_kernel_x<TetFused>", b_alg
         traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
         alg = tet_bytes * units
 

@@ -254,7 +254,8 @@ int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
  * The blob is only meaningful for a body created from the same mesh with the same options by the same library build family (it
  * starts with a header that tetsim_load_state validates: magic, ABI, solver, precision, flags, counts, and a digest of the mesh --
  * vertices, tets, density, batch layout -- so that a blob of ANOTHER mesh with the same counts is rejected too).  A body restored
- * from a blob continues the original trajectory bit for bit.  Both calls synchronise (both streams).
+ * from a blob continues the original trajectory bit for bit.  Both calls synchronise (both streams; for the partitions of an
+ * in-process group the streams of every member: a neighbour's transfer lands in this body's ghost range).
  * PARTITIONED bodies (since ABI 4): every partition saves and loads ITS OWN blob -- its owned particles, its ghosts (the predictions
  * its neighbours sent for the next substep are state too) and its local tets incl. ghost tets; the digest also covers the cut
  * (part_count, part_index, the owner map as this partition sees it), so a blob of another decomposition is rejected.  All ranks save
@@ -525,10 +526,11 @@ int tetsim_abi_version(void);
  * its tiling (what profiles/pmc_traffic.json is keyed by); ablation != 0: the development build (-DTETSIM_ABLATION) whose
  * tet kernel obeys TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL -- never the product; debug_env: bit i set = the i-th of
  * {TETSIM_DEBUG_LOOPBACK_HALO, TETSIM_DEBUG_LOOPBACK_COPY, TETSIM_DEBUG_ONE_STREAM, TETSIM_DEBUG_GROUP_SYNC,
- * TETSIM_DEBUG_HOSTPROF, TETSIM_DEBUG_TRACE, TETSIM_HALO_SYNC, TETSIM_HALO_GRAPH, TETSIM_DEBUG_LOOPBACK_DELAY_US, TETSIM_NH_QUADS,
- * TETSIM_FUSED_PARTICLE_PASS, TETSIM_FRAME_KERNEL, TETSIM_FRAME_LOCAL, TETSIM_NH_FOLD, TETSIM_HALO_ALIGNED_TILES, TETSIM_HALO_FOLD_WAIT, TETSIM_QUAD,
- * TETSIM_QUAD_POLL_DELAY, TETSIM_NH_FRAME} is set in the
- * environment.  bench.py records all of it in its JSON line. */
+ * TETSIM_DEBUG_HOSTPROF, TETSIM_DEBUG_TRACE*, TETSIM_HALO_SYNC, TETSIM_HALO_GRAPH, TETSIM_DEBUG_LOOPBACK_DELAY_US, TETSIM_NH_QUADS*,
+ * TETSIM_FUSED_PARTICLE_PASS, TETSIM_FRAME_KERNEL, TETSIM_FRAME_LOCAL*, TETSIM_NH_FOLD*, TETSIM_HALO_ALIGNED_TILES*, TETSIM_HALO_FOLD_WAIT, TETSIM_QUAD,
+ * TETSIM_QUAD_POLL_DELAY*, TETSIM_NH_FRAME*} is set in the environment and READ by this build -- the names marked * are A/B switches
+ * of choices settled by measurement, which only the development build looks at (the product library reads the 12 others and
+ * TETSIM_RCCL_LIB, TETSIM_HALO_TIMEOUT_MS, TETSIM_DEBUG_STREAM_PROBE: INTEGRATION.md 4).  bench.py records all of it in its JSON line. */
 typedef struct TetSimLibraryInfo {
     int32_t abi;
     int32_t ablation;

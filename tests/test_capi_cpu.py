@@ -46,17 +46,23 @@ def test_library_info_names_the_environment_knobs_it_sees():
     assert json.loads(subprocess.run([sys.executable, "-c", code], cwd=root, env=clean, capture_output=True, text=True, check=True).stdout) == []
     for name in capi.DEBUG_ENV_NAMES:
         out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(clean, **{name: "1"}), capture_output=True, text=True, check=True).stdout
-        assert json.loads(out) == [name], (name, out)
+        # (the product library neither reads nor reports the A/B switches of settled choices: development build only)
+        assert json.loads(out) == ([] if name in capi.LAB_ENV_NAMES else [name]), (name, out)
     blob = open(capi.LIB_PATH, "rb").read()
-    for name in capi.DEBUG_ENV_NAMES:
-        assert name.encode() in blob, name
+    for name in capi.DEBUG_ENV_NAMES:   # the product binary does not even contain the names it does not read
+        assert (name.encode() in blob) == (name not in capi.LAB_ENV_NAMES), name
 
 
 def test_product_kernel_has_no_ablation_knobs():
-    """TETSIM_DEBUG_ITERS & co. exist only in the -DTETSIM_ABLATION build: the product binary does not even contain the names."""
+    """TETSIM_DEBUG_ITERS & co. exist only in the -DTETSIM_ABLATION build: the product binary does not even contain the names, and the
+    product's kernel sources have no `#ifdef TETSIM_ABLATION` and no getenv left (the laboratory lives in pj_lab.h / pj_blocked_lab.inc)."""
     blob = open(capi.LIB_PATH, "rb").read()
-    for name in (b"TETSIM_DEBUG_ITERS", b"TETSIM_DEBUG_SKIP_REST_STORE", b"TETSIM_DEBUG_NO_PEEL"):
+    for name in (b"TETSIM_DEBUG_ITERS", b"TETSIM_DEBUG_SKIP_REST_STORE", b"TETSIM_DEBUG_NO_PEEL", b"TETSIM_DEBUG_STAGGER", b"TETSIM_DEBUG_ITER_HIST"):
         assert name not in blob, name
+    src = os.path.join(os.path.dirname(capi.LIB_PATH), "csrc")
+    for f in ("pj_blocked.hip", "pj_math.inc"):
+        text = open(os.path.join(src, f)).read()
+        assert "#ifdef TETSIM_ABLATION" not in text and "defined(TETSIM_ABLATION" not in text and "getenv" not in text, f
 
 
 def test_no_cpu_fallback():

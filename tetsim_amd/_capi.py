@@ -61,6 +61,10 @@ DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "
                    "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES", "TETSIM_HALO_FOLD_WAIT", "TETSIM_QUAD", "TETSIM_QUAD_POLL_DELAY", "TETSIM_NH_FRAME"]
 
 
+# A/B switches of settled choices: read (and reported) by the development build only (csrc/body.h: lab_env, build_info.cpp)
+LAB_ENV_NAMES = ["TETSIM_DEBUG_TRACE", "TETSIM_NH_QUADS", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES", "TETSIM_QUAD_POLL_DELAY", "TETSIM_NH_FRAME"]
+
+
 class TetSimCommInfo(C.Structure):
     _fields_ = [("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("neighbours", C.c_uint32), ("send_bytes_per_substep", C.c_uint64),
                 ("recv_bytes_per_substep", C.c_uint64), ("max_message_bytes", C.c_uint64), ("loopback", C.c_int32), ("p2p", C.c_int32)]

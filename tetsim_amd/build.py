@@ -59,10 +59,10 @@ UNITS = {
     "skin_kernels.hip": ["-ffp-contract=off"],
     "build_info.cpp": ["-x", "hip"],
 }
-HEADERS = ["body.h", "dev_common.h", "dev_store.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
+HEADERS = ["body.h", "dev_common.h", "dev_store.h", "host_prep.h", "mesh_file.h", "pj_kernels.inc", "pj_math.inc", "pj_lab.h", "pj_blocked_lab.inc", "nh_kernels.inc", os.path.join("..", "..", "include", "tetsim.h")]
 # what determines the polar tet kernel (pjb_tet_kernel), its tiling and therefore its HBM traffic: profiles/pmc_traffic.json
 # is keyed by the hash of these (+ their flags), so a stale counter figure is never attached to a different kernel
-KERNEL_FILES = ["pj_blocked.hip", "pj_math.inc", "dev_common.h", "dev_store.h", "host_prep.cpp", "host_prep.h"]
+KERNEL_FILES = ["pj_blocked.hip", "pj_math.inc", "pj_lab.h", "dev_common.h", "dev_store.h", "host_prep.cpp", "host_prep.h"]
 
 
 def _sha(files, extra):

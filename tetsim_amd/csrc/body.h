@@ -92,6 +92,17 @@ struct Rccl {
         return loaded;
     }
 };
+// A/B switches of choices that measurement has settled (HISTORY.md) are read by the DEVELOPMENT build only (-DTETSIM_ABLATION); the
+// product library does not look at them: TETSIM_QUAD_POLL_DELAY, TETSIM_NH_QUADS, TETSIM_NH_FOLD, TETSIM_NH_FRAME, TETSIM_FRAME_LOCAL,
+// TETSIM_HALO_ALIGNED_TILES.  What the product reads is what INTEGRATION.md 4 lists.
+inline const char* lab_env(const char* name) {
+#ifdef TETSIM_ABLATION
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 extern Rccl g_rccl;
 // Bumped whenever this library creates a stream in the process (every handle's main stream, every halo stream): HIP does not pin a
 // stream to a hardware queue, so a queue-independence probe (probe_queue_independence) is only as good as the set of streams it

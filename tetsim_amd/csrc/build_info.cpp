@@ -19,11 +19,19 @@ extern "C" int tetsim_library_info(TetSimLibraryInfo* out) {
 #ifdef TETSIM_ABLATION
     out->ablation = 1;
 #endif
-    static const char* const kEnv[] = {"TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "TETSIM_DEBUG_ONE_STREAM", "TETSIM_DEBUG_GROUP_SYNC",
-                                       "TETSIM_DEBUG_HOSTPROF", "TETSIM_DEBUG_TRACE", "TETSIM_HALO_SYNC", "TETSIM_HALO_GRAPH", "TETSIM_DEBUG_LOOPBACK_DELAY_US", "TETSIM_NH_QUADS", "TETSIM_FUSED_PARTICLE_PASS",
-                   "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES", "TETSIM_HALO_FOLD_WAIT", "TETSIM_QUAD", "TETSIM_QUAD_POLL_DELAY", "TETSIM_NH_FRAME"};
-    for (unsigned i = 0; i < sizeof(kEnv) / sizeof(kEnv[0]); i++)
-        if (std::getenv(kEnv[i])) out->debug_env |= 1u << i;
+    // bit i = the i-th name is set in the environment AND this build reads it.  The positions are part of the ABI (tetsim_amd/_capi.py,
+    // the N-API addon); names marked lab are A/B switches of settled choices that only the development build looks at (body.h: lab_env).
+    static const struct { const char* name; bool lab; } kEnv[] = {
+        {"TETSIM_DEBUG_LOOPBACK_HALO", false}, {"TETSIM_DEBUG_LOOPBACK_COPY", false}, {"TETSIM_DEBUG_ONE_STREAM", false}, {"TETSIM_DEBUG_GROUP_SYNC", false},
+        {"TETSIM_DEBUG_HOSTPROF", false}, {"TETSIM_DEBUG_TRACE", true}, {"TETSIM_HALO_SYNC", false}, {"TETSIM_HALO_GRAPH", false}, {"TETSIM_DEBUG_LOOPBACK_DELAY_US", false},
+        {"TETSIM_NH_QUADS", true}, {"TETSIM_FUSED_PARTICLE_PASS", false}, {"TETSIM_FRAME_KERNEL", false}, {"TETSIM_FRAME_LOCAL", true}, {"TETSIM_NH_FOLD", true},
+        {"TETSIM_HALO_ALIGNED_TILES", true}, {"TETSIM_HALO_FOLD_WAIT", false}, {"TETSIM_QUAD", false}, {"TETSIM_QUAD_POLL_DELAY", true}, {"TETSIM_NH_FRAME", true}};
+    for (unsigned i = 0; i < sizeof(kEnv) / sizeof(kEnv[0]); i++) {
+#ifndef TETSIM_ABLATION
+        if (kEnv[i].lab) continue;
+#endif
+        if (std::getenv(kEnv[i].name)) out->debug_env |= 1u << i;
+    }
     std::strncpy(out->source_sha, TETSIM_SOURCE_SHA, sizeof(out->source_sha) - 1);
     std::strncpy(out->kernel_sha, TETSIM_KERNEL_SHA, sizeof(out->kernel_sha) - 1);
     return TETSIM_OK;

@@ -68,7 +68,7 @@ struct PJBlk {
     float4* pos_pred = nullptr;
     float4* pos_final = nullptr;
     float4* vel = nullptr;
-    // Fused particle pass (pjb_tet_fused_kernel): the staging of substep s+1 performs the particle update of substep s for the
+    // Fused particle pass (pjb_tet_kernel_x<.., TetFused>): the staging of substep s+1 performs the particle update of substep s for the
     // tile's own particles instead of reading predictions a separate kernel wrote.  Inputs of that update are the PREVIOUS tet
     // pass's partial sums and end-of-substep positions, which other tiles of the same launch still read while this launch writes
     // the new ones: both are double buffered (the launcher fills these four per launch; the particle kernel uses fin_in / fin_out
@@ -81,7 +81,7 @@ struct PJBlk {
     uint32_t ns_pad = 0;
     const DevParams* params = nullptr;
     // peer-to-peer halo (tetsim_p2p.hip, tetsim_halo.hip): the neighbours store their boundary predictions straight into this rank's ghost range,
-    // double buffered by substep parity -- pos_pred's own tail on even substeps, ghost_alt on odd ones (pjb_tet_kernel_alt)
+    // double buffered by substep parity -- pos_pred's own tail on even substeps, ghost_alt on odd ones (pjb_tet_kernel_x<.., TetAlt>)
     const float4* ghost_alt = nullptr;       // [nv_local - nv_owned]
     // two-layer ghost regions: ghosts [nv_owned, nv_owned + n_ghost1) come from ghost_alt, the second layer from ghost2
     const float4* ghost2 = nullptr;

@@ -40,16 +40,19 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dev_common.h"
 #include "dev_store.h"
 #include "host_prep.h"
+#include "pj_lab.h"
 
 namespace tetsim {
 namespace {
 
 #include "pj_math.inc"
+#include "pj_blocked_lab.inc"   // empty unless -DTETSIM_ABLATION: the iteration histogram, the run-time mode word
 
 // Streamed outputs (carried rest shape, quaternion, partial sums, particle state) are written WRITE-THROUGH
 // (sc0 sc1, dev_store.h): a plain store leaves the line dirty in the XCD's 4 MiB L2, and a kernel that streams ~70 MB of
@@ -92,62 +95,18 @@ __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 pr
     return o;
 }
 
-#ifdef TETSIM_ABLATION
-// Development (TETSIM_DEBUG_ITER_HIST; tools/rotation_iterations.py): what a tet's nine |omega|^2 say about exit thresholds.  For each of
-// the thresholds {1e-9 (the reference's), 1e-7, 3e-7, 1e-6} the number of iterations this tet (level 0) and its whole wave (level 1:
-// the loop is wave-uniform) would execute if the correction iterations 2..9 ended at that threshold -- iteration 1 always uses 1e-9 --
-// and the distribution of |omega| per iteration in half decades.  hist: [2][4][10] counts by iterations executed (1..9), then
-// [9][22] half-decade bins (bin 0: < 1e-10 incl. "done", bin 21: >= 1).
-__device__ __forceinline__ void pjb_log_iterations(unsigned long long* hist, const float* w2log) {
-    const float thr2[4] = {1.0e-18f, 1.0e-14f, 9.0e-14f, 1.0e-12f};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int n = 9;
-#pragma unroll
-        for (int j = 8; j >= 0; j--) {   // the first iteration whose omega fails the test ends the loop (computed, not applied)
-            const float lim = j == 0 ? 1.0e-18f : thr2[k];
-            if (w2log[j] < lim) n = j + 1;   // (-1 = not executed: done)
-        }
-        atomicAdd(&hist[(0 * 4 + k) * 10 + n], 1ull);
-        int wn = n;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wn = max(wn, __shfl_xor(wn, o));   // (lanes without a tet are not here: the tail wave of a tile under-reports by its idle lanes only)
-        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__builtin_amdgcn_ballot_w64(true))) - 1)) atomicAdd(&hist[(1 * 4 + k) * 10 + wn], 1ull);
-    }
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const float w = w2log[j] > 0.0f ? sqrtf(w2log[j]) : 0.0f;
-        int bin = w > 0.0f ? static_cast<int>(floorf(2.0f * log10f(w))) + 21 : 0;   // 1e-10 -> 1, 1 -> 21
-        bin = min(max(bin, 0), 21);
-        atomicAdd(&hist[80 + j * 22 + bin], 1ull);
-    }
-}
-#endif
 constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile; host_prep.cpp cuts the tiles with the same constant
 
 // LDS per workgroup is 18 KB (4 + 12 + 2) so that 8 workgroups fit a CU's 160 KB: with 22.5 KB only 7
 // fit and the 3900 tiles of the 1 M-tet lattice need 2.18 "rounds" of the chip instead of 1.9.
-// Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration) change the physics and
-// exist only in the separate development build (-DTETSIM_ABLATION -> libtetsim_hip_ablation.so, tools/ab_iters.py): there the
-// kernel takes a run-time `dbg` word (bits 0-3: iterations, bit 4: skip the write-back, bit 6: no peel).  The product kernel
-// has no such argument: 9 iterations, peeled, every store -- compile-time constants.
-#ifdef TETSIM_ABLATION
-#define TETSIM_DBG_PARAM , uint32_t dbg
-#define TETSIM_DBG_ARG , dbg
-#define TETSIM_DBG_ITERS static_cast<int>(dbg & 15u)
-#define TETSIM_DBG_PEEL (!(dbg & 64u))
-#define TETSIM_DBG_STORE_REST (!(dbg & 16u))
-#else
-#define TETSIM_DBG_PARAM
-#define TETSIM_DBG_ARG
-#define TETSIM_DBG_ITERS 9
-#define TETSIM_DBG_PEEL true
-#define TETSIM_DBG_STORE_REST true
-#endif
+// Timing ablations (fewer rotation iterations, no rest-shape write-back, unpeeled first iteration), per-tile phase stamps and the
+// rotation-iteration histogram change the physics or the timing and exist only in the separate development build
+// (-DTETSIM_ABLATION -> libtetsim_hip_ablation.so): pj_lab.h defines every TETSIM_LAB_* / TETSIM_DBG_* name used below as nothing
+// (or as the product's compile-time constant: 9 iterations, peeled, every store) unless that build is being made.
 // kLean: the constant-rest-shape formulation (TETSIM_FLAG_CONSTANT_REST_SHAPE), a compile-time choice: as a run-time flag it
 // cost the default path 12 register moves per tet at the join of the two variants.
 // kAlt: ghost particles (id >= nv_owned) are staged from d.ghost_alt instead of pos_pred's tail (peer-to-peer halo, odd substeps)
-// kHaloWait: the halo-side tiles of a peer-to-peer body do their queue's hand-overs themselves (pjb_tet_kernel_hwait): the first wave of
+// kHaloWait: the halo-side tiles of a peer-to-peer body do their queue's hand-overs themselves (pjb_tet_kernel_x<.., TetHwait>): the first wave of
 // every tile looks at V and at the neighbours' "arrived" words -- after the record loads are out, before the positions are asked for --
 // and every position comes from the memory side: the kernel may have started before the data it waits for was written.
 struct PJHaloWait { const PJPeerSync* w; const uint32_t* vflag; uint32_t* error; uint32_t timeout_ms; const float4* ghosts; };
@@ -164,21 +123,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
-#ifdef TETSIM_ABLATION  // per-tile phase timestamps (TETSIM_DEBUG_TRACE): development build only
-#define TETSIM_STAMP(i) do { if (d.trace && tid == 0) d.trace[8ull * b + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (d.trace && tid == 0) d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-#else
-#define TETSIM_STAMP(i) do { } while (0)
-#endif
-    TETSIM_STAMP(0);
-#ifdef TETSIM_ABLATION
-    // TETSIM_DEBUG_STAGGER=<s_sleep units of 64 cycles>: workgroups of the first round delay their loads by (slot index) x that
-    // much, slot index guessed from the dispatch order in two ways (bit 16 of the mode word selects which)
-    if (const uint32_t st = (dbg >> 8) & 0xffu; st != 0u && blockIdx.x < 2048u) {
-        const uint32_t k = (dbg & 0x10000u) ? (blockIdx.x >> 3) & 7u : (blockIdx.x >> 8) & 7u;
-        for (uint32_t i = 0; i < k * st; i++) __builtin_amdgcn_s_sleep(1);
-    }
-#endif
+    TETSIM_LAB_TILE_BEGIN();
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
 
@@ -293,15 +238,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         // world-space goal is goal + cc.  Same bytes as the reference's world-space shape, 21 instructions fewer per tet
         // (no rest centroid, no subtraction), and without the add-then-subtract of a position-sized number every substep.
         f3 cc;
-#ifdef TETSIM_ABLATION
-        float w2log[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) w2log[i] = -1.0f;   // -1: iteration not executed (the wave had left the loop: every tet done)
-        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.rot_exit_w2, d.iter_hist ? w2log : nullptr);
-        if (d.iter_hist) pjb_log_iterations(d.iter_hist, w2log);
-#else
-        pj_solve_tet(cur, rest, q_old, q_new, goal, TETSIM_DBG_ITERS, TETSIM_DBG_PEEL, kLean, !kLean, &cc, d.rot_exit_w2);
-#endif
+        TETSIM_LAB_SOLVE_TET(cur, rest, q_old, q_new, goal, cc);   // pj_solve_tet(..., 9 iterations, peeled, kLean, centred, &cc, d.rot_exit_w2)
         TETSIM_STAMP(3);  // solved
         // LDS staging first, global results after it: nothing below may have to wait for the write-through stores
         const f3 vcc = cc * V;
@@ -354,7 +291,6 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
-#undef TETSIM_STAMP
 }
 
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
@@ -365,61 +301,54 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
     pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
-// ... raising a hand-over word as they START (partitioned bodies): a kernel starts only when everything in front
-// of it in its in-order queue is complete, so "the previous kernel of this queue is done" costs one store of one thread here
-// instead of a signal kernel of its own (~2.7 us of queue time each, and the two-queue substep had two of them)
-// ... and, in front of the raise, putting back a word whose waiters were the waves of the kernel in front of this one in its queue (the
-// interior particle kernel that waits for G itself, pjb_vertex_kernel_await: all of its waves are through when this kernel starts)
+// The variants partitioned and mid-sized bodies need are ONE kernel template over what happens around the tile's solve:
+//   TetRaise  raises a hand-over word as it STARTS (partitioned bodies): a kernel starts only when everything in front
+//             of it in its in-order queue is complete, so "the previous kernel of this queue is done" costs one store of one thread here
+//             instead of a signal kernel of its own (~2.7 us of queue time each, and the two-queue substep had two of them) -- and, in
+//             front of the raise, puts back a word whose waiters were the waves of the kernel in front of this one in its queue (the
+//             interior particle kernel that waits for G itself, pjb_vertex_kernel_await: all of its waves are through when this starts);
+//   TetAlt    reads the ghosts from the second buffer (peer-to-peer halo; halo-side tiles of odd substeps);
+//   TetHwait  does the halo queue's hand-overs itself (peer-to-peer halo, one rank per process): as the kernel STARTS its first thread
+//             tells the neighbours "my boundary predictions of the previous substep are in your ghost range" (the kernel in front of
+//             it in this queue is this rank's boundary-particle kernel), every tile waits for V and the neighbours' words (kHaloWait),
+//             and nobody consumes them: the boundary-particle kernel behind this one puts them back as it starts
+//             (pjb_vertex_kernel_peer).  The one-wave wait kernel this replaces was a launch boundary on the chain that decides how
+//             much wire latency a rank can hide;
+//   TetFused  the previous substep's particle update fused into the staging (unpartitioned bodies of < 2,048 tiles, tetsim_step_n).
+// The plain kernel of the headline keeps its own two names above (profiles and counters are keyed by them).
 __device__ __forceinline__ void clear_then_raise(uint32_t* clear, uint32_t* sig) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (clear) __hip_atomic_store(clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sig) __hip_atomic_store(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                              uint32_t tiles_per_xcd, uint32_t* sig, uint32_t* clear TETSIM_DBG_PARAM) {
-    clear_then_raise(clear, sig);
-    pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+struct TetRaise { uint32_t* sig; uint32_t* clear; };
+struct TetAlt { uint32_t unused; };
+struct TetHwait { PJPeerSync w; const uint32_t* vflag; uint32_t* error; uint32_t timeout_ms; const float4* ghosts; };
+struct TetFused { uint32_t unused; };
+template <bool kLean, class Extra>
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_x(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd, Extra x TETSIM_DBG_PARAM) {
+    if constexpr (std::is_same_v<Extra, TetRaise>) {
+        clear_then_raise(x.clear, x.sig);
+        pjb_tet_body<kLean, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    } else if constexpr (std::is_same_v<Extra, TetAlt>) {
+        pjb_tet_body<kLean, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    } else if constexpr (std::is_same_v<Extra, TetHwait>) {
+        if (blockIdx.x == 0 && threadIdx.x < x.w.n_raise) __hip_atomic_store(x.w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const PJHaloWait hw = {&x.w, x.vflag, x.error, x.timeout_ms, x.ghosts};
+        pjb_tet_body<kLean, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
+    } else {
+        pjb_tet_body<kLean, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    }
 }
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_raise(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                                            uint32_t tiles_per_xcd, uint32_t* sig, uint32_t* clear TETSIM_DBG_PARAM) {
-    clear_then_raise(clear, sig);
-    pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-// ... reading the ghosts from the second buffer (peer-to-peer halo; halo-side tiles of odd substeps)
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                            uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_alt(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                                          uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<true, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-// ... doing the halo queue's hand-overs themselves (peer-to-peer halo, one rank per process): as the kernel STARTS its first thread tells
-// the neighbours "my boundary predictions of the previous substep are in your ghost range" (the kernel in front of it in this queue is
-// this rank's boundary-particle kernel), every tile waits for V and the neighbours' words here (kHaloWait), and nobody consumes them:
-// the boundary-particle kernel behind this one puts them back as it starts (pjb_vertex_kernel_peer).  The one-wave wait kernel this
-// replaces was a launch boundary on the chain that decides how much wire latency a rank can hide.
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_hwait(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd,
-                                                              PJPeerSync w, const uint32_t* vflag, uint32_t* error, uint32_t timeout_ms, const float4* ghosts TETSIM_DBG_PARAM) {
-    if (blockIdx.x == 0 && threadIdx.x < w.n_raise) __hip_atomic_store(w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const PJHaloWait hw = {&w, vflag, error, timeout_ms, ghosts};
-    pjb_tet_body<false, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
-}
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest_hwait(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd,
-                                                                            PJPeerSync w, const uint32_t* vflag, uint32_t* error, uint32_t timeout_ms, const float4* ghosts TETSIM_DBG_PARAM) {
-    if (blockIdx.x == 0 && threadIdx.x < w.n_raise) __hip_atomic_store(w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const PJHaloWait hw = {&w, vflag, error, timeout_ms, ghosts};
-    pjb_tet_body<true, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
-}
-// ... with the previous substep's particle update fused into the staging (unpartitioned bodies, tetsim_step_n)
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                               uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
-}
-__global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
-                                                                             uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<true, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+// one launcher for all of them: the kernel by (constant rest shape?, variant), its own begin / end events on request
+template <class Extra>
+void launch_tet_x(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, const Extra& x, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (tile_count == 0) return;
+    const uint32_t per_xcd = (tile_count + 7u) / 8u;
+    auto* kernel = d.lean ? pjb_tet_kernel_x<true, Extra> : pjb_tet_kernel_x<false, Extra>;
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, x TETSIM_DBG_LAUNCH);
+    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, x TETSIM_DBG_LAUNCH);
 }
 
 // ---- one persistent launch per tetsim_step_n call (small bodies) -------------------------------------------
@@ -444,11 +373,7 @@ __global__ __launch_bounds__(kTile, 2) void pjb_tet_fused_kernel_constant_rest(P
 // verified the dispatcher's block -> XCD rule with pjb_probe_xcd), so the exchange only has to be coherent in that XCD's L2: plain
 // stores (the L1 writes through) and agent-scope loads (miss the L1, served by the L2) -- dev_store.h.  !kLocal: write-through
 // stores and cache-bypassing loads, coherent at the memory side (any placement).
-#ifdef TETSIM_ABLATION
-constexpr int kFrameIters = 9;                  // (the ablation knobs belong to the per-substep kernel)
-#else
-constexpr int kFrameIters = TETSIM_DBG_ITERS;   // the product's compile-time constant (tools/mutation_check.sh mutates it for both kernels)
-#endif
+constexpr int kFrameIters = TETSIM_LAB_FRAME_ITERS;   // the product's compile-time constant, 9 (tools/mutation_check.sh mutates it for both kernels)
 template <bool kLean, bool kLocal>
 __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
                                                uint32_t* const err, const uint32_t timeout_ms) {
@@ -462,14 +387,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
     if (bt < 0) return;   // (a block that only pads the grid so that the others land on the intended XCDs)
     const uint32_t b = static_cast<uint32_t>(bt);
     const uint32_t tid = threadIdx.x;
-#ifdef TETSIM_ABLATION   // development build: thread 0 adds up the cycles of each phase over the call (TETSIM_DEBUG_TRACE, tools/frame_trace.py)
-    unsigned long long fr_acc[5] = {0, 0, 0, 0, 0}, fr_last = 0, fr_polls = 0;
-#define FRAME_STAMP(i) do { if (d.trace && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) fr_acc[(i) - 1] += now_ - fr_last; fr_last = now_; } } while (0)
-#define FRAME_POLL() do { if (tid == 0) fr_polls++; } while (0)
-#else
-#define FRAME_STAMP(i) do { } while (0)
-#define FRAME_POLL() do { } while (0)
-#endif
+    TETSIM_LAB_FRAME_BEGIN();
     const uint32_t t0 = d.blk_tet_off[b], ntb = d.blk_tet_off[b + 1] - t0;
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
     const bool has_slot = tid < nu, has_tet = tid < ntb;
@@ -618,9 +536,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
     }
     // the particle update that ends the call, and the state back to memory: one writer per particle, every lane its own tet
     const VertexOut o = gather_update(n - 1u);
-#ifdef TETSIM_ABLATION
-    if (d.trace && tid == 0) { for (int i = 0; i < 5; i++) d.trace[8ull * b + i] = fr_acc[i]; d.trace[8ull * b + 5] = fr_polls; d.trace[8ull * b + 6] = n; d.trace[8ull * b + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // XCC_ID
-#endif
+    TETSIM_LAB_FRAME_END();
     if (owner) {
         store_wt(d.pos_final, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
         store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
@@ -635,8 +551,6 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
         }
     }
 }
-#undef FRAME_STAMP
-#undef FRAME_POLL
 #define TETSIM_FRAME_KERNEL(name, lean, local)                                                                                         \
     __global__ __launch_bounds__(kTile, 2) void name(PJBlk d, uint32_t n, const int32_t* block_tile, float4* pbuf0, float4* pbuf1, uint32_t* err, \
                                                      uint32_t timeout_ms) {                                                            \
@@ -820,46 +734,16 @@ __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
 
 }  // namespace
 
-#ifdef TETSIM_ABLATION
-static uint32_t tet_mode() {
-    static int dbg = -1;
-    if (dbg < 0) {  // timing ablations (see the kernel comment); unset => 9 iterations, peeled, all stores
-        const char* it = getenv("TETSIM_DEBUG_ITERS");
-        const char* sk = getenv("TETSIM_DEBUG_SKIP_REST_STORE");
-        const char* np = getenv("TETSIM_DEBUG_NO_PEEL");
-        const char* sg = getenv("TETSIM_DEBUG_STAGGER");
-        const char* sm = getenv("TETSIM_DEBUG_STAGGER_MAP");
-        dbg = (it ? (atoi(it) & 15) : 9) | ((sk && sk[0] == '1') ? 16 : 0) | ((np && np[0] == '1') ? 64 : 0) | (sg ? ((atoi(sg) & 255) << 8) : 0) |
-              ((sm && sm[0] == '1') ? 0x10000 : 0);
-        fprintf(stderr, "[tetsim] WARNING: ABLATION build of libtetsim_hip (mode 0x%x): timing experiments only, the results are NOT the solver's\n", dbg);
-    }
-    return static_cast<uint32_t>(dbg);
-}
-#define TETSIM_DBG_LAUNCH , tet_mode()
-#else
-#define TETSIM_DBG_LAUNCH
-#endif
 void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, hipEvent_t e0, hipEvent_t e1, uint32_t* raise_word,
                     uint32_t* clear_word) {
     if (tile_count == 0) return;   // (callers with a word to raise or clear check this themselves)
+    if (raise_word || clear_word) return launch_tet_x(s, d, tile_first, tile_count, TetRaise{raise_word, clear_word}, e0, e1);
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    if (raise_word || clear_word) {
-        auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_raise : pjb_tet_kernel_raise;
-        if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, raise_word, clear_word TETSIM_DBG_LAUNCH);
-        else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, raise_word, clear_word TETSIM_DBG_LAUNCH);
-        return;
-    }
     auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
-void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
-    if (d.nb == 0) return;
-    const uint32_t per_xcd = (d.nb + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_fused_kernel_constant_rest : pjb_tet_fused_kernel;
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
-    else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, 0u, d.nb, per_xcd TETSIM_DBG_LAUNCH);
-}
+void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) { launch_tet_x(s, d, 0u, d.nb, TetFused{0u}, e0, e1); }
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
                       uint32_t* err, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0 || n == 0 || blocks == 0) return;
@@ -886,15 +770,15 @@ uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
 // How many waiting workgroups the in-kernel hand-overs may put on the current device (tetsim_halo.hip: folded waits).  A wave that looks
 // at a word keeps its slot while it waits, and the kernel that raises the word needs slots too: the waiting kernels may hold HALF of
 // what the device keeps resident of pjb_vertex_kernel_await (one-wave workgroups) and a QUARTER of what it keeps of
-// pjb_tet_kernel_hwait -- measured limits, not constants: a compute partition with fewer CUs (or a kernel that grew) shrinks them.
+// the TetHwait tet kernel -- measured limits, not constants: a compute partition with fewer CUs (or a kernel that grew) shrinks them.
 void pjb_wait_capacity(bool lean, uint32_t* vertex_waves, uint32_t* hwait_blocks) {
     *vertex_waves = 0; *hwait_blocks = 0;
     int per_cu_v = 0, per_cu_t = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, pjb_vertex_kernel_await, 64, 0) != hipSuccess) per_cu_v = 0;
-    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_constant_rest_hwait, static_cast<int>(kTile), 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_hwait, static_cast<int>(kTile), 0);
+    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_x<true, TetHwait>, static_cast<int>(kTile), 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_x<false, TetHwait>, static_cast<int>(kTile), 0);
     if (e != hipSuccess) per_cu_t = 0;
     const uint32_t cus = static_cast<uint32_t>(std::max(prop.multiProcessorCount, 0));
     *vertex_waves = static_cast<uint32_t>(std::max(per_cu_v, 0)) * cus / 2u;
@@ -921,17 +805,9 @@ void pjb_launch_vertex_peer(hipStream_t s, const PJBlk& d, uint32_t first, uint3
     hipLaunchKernelGGL(pjb_vertex_kernel_peer, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count, peer, raise_word, clr);
 }
 void pjb_launch_tet_hwait(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, const PJSync& yv, const PJPeerSync& w, const float4* ghosts) {
-    if (tile_count == 0) return;
-    const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_hwait : pjb_tet_kernel_hwait;
-    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, w, yv.flag, yv.error, yv.timeout_ms, ghosts TETSIM_DBG_LAUNCH);
+    launch_tet_x(s, d, tile_first, tile_count, TetHwait{w, yv.flag, yv.error, yv.timeout_ms, ghosts});
 }
-void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count) {
-    if (tile_count == 0) return;
-    const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_kernel_constant_rest_alt : pjb_tet_kernel_alt;
-    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
-}
+void pjb_launch_tet_alt(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count) { launch_tet_x(s, d, tile_first, tile_count, TetAlt{0u}); }
 void pjb_launch_wait(hipStream_t s, const PJSync& y) { hipLaunchKernelGGL(pjb_wait_kernel, dim3(1), dim3(64), 0, s, y.flag, y.error, y.timeout_ms); }
 void pjb_launch_signal(hipStream_t s, const PJSync& y, uint32_t* clear_word) { hipLaunchKernelGGL(pjb_signal_kernel, dim3(1), dim3(64), 0, s, y.flag, clear_word); }
 void pjb_launch_vertex_await(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, const PJSync& y, hipEvent_t e0, hipEvent_t e1) {

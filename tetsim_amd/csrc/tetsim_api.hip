@@ -74,7 +74,7 @@ void fill_params(const tetsim_body* h, double dt, const TetSimParams& p, DevPara
         } else o->grab_local = to_device(h->grab_global);
     }
     o->epoch = h->frame_epoch;
-    static const int32_t poll_delay = [] { const char* e = getenv("TETSIM_QUAD_POLL_DELAY"); return e ? atoi(e) : kQuadPollDelay; }();
+    static const int32_t poll_delay = [] { const char* e = lab_env("TETSIM_QUAD_POLL_DELAY"); return e ? atoi(e) : kQuadPollDelay; }();
     o->poll_delay = poll_delay;
     o->d_dt = dt;
     o->d_gravity = p.gravity;
@@ -575,16 +575,16 @@ void tetsim_destroy(tetsim_handle h) {
     (void)hipSetDevice(h->opt.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->blk.trace && getenv("TETSIM_DEBUG_TRACE")) {
+    if (h->blk.trace && lab_env("TETSIM_DEBUG_TRACE")) {
         std::vector<unsigned long long> tr(8ull * h->blk.nb);
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* f = fopen(getenv("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
+            if (FILE* f = fopen(lab_env("TETSIM_DEBUG_TRACE"), "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), f); fclose(f); }
     }
 #ifdef TETSIM_ABLATION
-    if (h->blk.iter_hist && getenv("TETSIM_DEBUG_ITER_HIST")) {   // one text line per body, appended: "<tets> <particles> <278 counters>"
+    if (h->blk.iter_hist && lab_env("TETSIM_DEBUG_ITER_HIST")) {   // one text line per body, appended: "<tets> <particles> <278 counters>"
         std::vector<unsigned long long> hs(278);
         if (hipMemcpy(hs.data(), h->blk.iter_hist, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* f = fopen(getenv("TETSIM_DEBUG_ITER_HIST"), "a")) {
+            if (FILE* f = fopen(lab_env("TETSIM_DEBUG_ITER_HIST"), "a")) {
                 fprintf(f, "%u %u", h->info.num_elems, h->info.num_particles);
                 for (unsigned long long x : hs) fprintf(f, " %llu", x);
                 fprintf(f, "\n");

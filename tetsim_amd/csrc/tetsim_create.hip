@@ -142,7 +142,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         // where every tile that reaches the interface is halo-side (A/B)
         std::vector<uint8_t> tet_class;
         if (h->partitioned) {
-            const char* e = getenv("TETSIM_HALO_ALIGNED_TILES");
+            const char* e = lab_env("TETSIM_HALO_ALIGNED_TILES");
             const bool aligned = !(e && e[0] == '0');
             tet_class.assign(ntl, 0);
             for (uint32_t i = 0; i < ntl; i++) {
@@ -322,7 +322,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const uint32_t slots = per_cu * cus, exclusive_max = slots - slots / 10u;
             if (per_cu != 0u && nbk != 0u && nbk <= (h->partitioned ? slots / 2u : exclusive_max)) {
                 h->frame_exclusive = nbk > slots / 2u;
-                static const bool allow_local = [] { const char* e = getenv("TETSIM_FRAME_LOCAL"); return !(e && e[0] == '0'); }();
+                static const bool allow_local = [] { const char* e = lab_env("TETSIM_FRAME_LOCAL"); return !(e && e[0] == '0'); }();
                 static int xcd_rule[64] = {};   // per device: 0 = not probed, 1 = round-robin over 8 XCDs verified, 2 = no
                 int& rule = xcd_rule[o.device & 63];
                 if (allow_local && rule == 0) rule = pjb_probe_xcd(h->stream, 256) == 8u ? 1 : 2;
@@ -388,12 +388,12 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         k.lc_range = lcr; k.lc_ent = lce; k.vp_ell = vpe; k.vp_cols = B.max_partials; k.nv_pad = B.nv_pad;
         d.quat = k.quat;  // tetsim_read_quats
 #ifdef TETSIM_ABLATION
-        if (getenv("TETSIM_DEBUG_ITER_HIST")) {  // development: rotation-iteration statistics of every tet-kernel launch (pjb_log_iterations)
+        if (lab_env("TETSIM_DEBUG_ITER_HIST")) {  // development: rotation-iteration statistics of every tet-kernel launch (pjb_log_iterations)
             if ((rc = dev_alloc(h, &k.iter_hist, 278))) return rc;
             HIPCHK(h, hipMemset(k.iter_hist, 0, 278 * sizeof(unsigned long long)));
         }
 #endif
-        if (getenv("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
+        if (lab_env("TETSIM_DEBUG_TRACE")) {  // development: per-tile phase timestamps of the LAST tet-kernel launch
             if ((rc = dev_alloc(h, &k.trace, 8ull * B.num_blocks))) return rc;
             HIPCHK(h, hipMemset(k.trace, 0, 8ull * B.num_blocks * sizeof(unsigned long long)));
         }
@@ -560,8 +560,8 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         std::vector<uint8_t> first_mask;
         std::vector<uint32_t> mask_off(nl + 1, 0);
         {
-            const char* e = getenv("TETSIM_NH_FOLD");
-            const char* q = getenv("TETSIM_NH_QUADS");
+            const char* e = lab_env("TETSIM_NH_FOLD");
+            const char* q = lab_env("TETSIM_NH_QUADS");
             // FAST on four lanes per cluster only: a lane folds two particles there; with one lane per cluster (PRECISE) it would fold
             // eight one after the other, in f64 -- as long as the pass it replaces (measured: 132 against 120 us per substep)
             h->nh_fold = h->fast && !(q && q[0] == '0') && !(e && e[0] == '0');
@@ -607,7 +607,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
     // (PRECISE: bodies of up to 12 k tets -- f64 at half rate on ONE CU is throughput-bound beyond that: 157 us per substep at 20 k tets
     // against 117 with one launch per level, 92 against ~115 at 10 k; FAST stays ahead up to the LDS limit: 60 against 87 us at 20 k
     // tets -- tools/nh_size_sweep.py)
-    static const bool allow_nh_frame = [] { const char* e = getenv("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
+    static const bool allow_nh_frame = [] { const char* e = lab_env("TETSIM_NH_FRAME"); return !(e && e[0] == '0'); }();
     if (allow_nh_frame && !clustered && nv > 0 && nt > 0 && nl > 0) {
         std::vector<uint32_t> first_vert = h->batch_first_vert, first_tet = h->batch_first_tet;
         if (first_vert.empty()) { first_vert = {0u, nv}; first_tet = {0u, nt}; }

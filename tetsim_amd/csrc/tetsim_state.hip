@@ -150,6 +150,22 @@ int state_guard(tetsim_body* h) {
     if (h->partitioned && h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "partitioned bodies are POLAR_JACOBI bodies");
     return 0;
 }
+// Everything that may still write into this body's arrays has to be done before they are copied: its own two queues, and -- for the
+// partitions of one process (in-process group: sender-driven copies, peer-to-peer stores through plain pointers) -- the queues of
+// the other members, whose transfers of the last substep land in THIS body's ghost range.
+int quiesce(tetsim_body* h) {
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    for (tetsim_body* g : h->group) {
+        if (!g || g == h) continue;
+        HIPCHK(h, hipSetDevice(g->opt.device));
+        HIPCHK(h, hipStreamSynchronize(g->stream));
+        if (g->comm_stream) HIPCHK(h, hipStreamSynchronize(g->comm_stream));
+    }
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    return 0;
+}
 // peer-to-peer bodies on an odd substep parity read their ghosts from ghost_alt, not from pos_pred's tail
 int ghosts_to_tail(tetsim_body* h) {
     const size_t ng = h->pj.nv_local - h->pj.nv_owned;
@@ -176,9 +192,7 @@ int tetsim_save_state(tetsim_handle h, void* blob, uint64_t bytes) {
     if (int rc = state_guard(h)) return rc;
     const StateHeader hd = state_header(h);
     if (bytes < sizeof(hd) + hd.payload) return fail(h, TETSIM_EINVAL, "state buffer too small (tetsim_state_size)");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (int rc = quiesce(h)) return rc;
     if (int rc = ghosts_to_tail(h)) return rc;   // (the tail is the other parity's buffer: free until the substep after next writes it)
     char* out = static_cast<char*>(blob);
     std::memcpy(out, &hd, sizeof(hd));
@@ -205,9 +219,7 @@ int tetsim_load_state(tetsim_handle h, const void* blob, uint64_t bytes) {
         return fail(h, TETSIM_EINVAL, "state blob belongs to a body with another mesh or other options");
     if (in.mesh_digest != want.mesh_digest) return fail(h, TETSIM_EINVAL, "state blob belongs to another mesh (same counts, different vertices / tets / density / batch layout)");
     if (bytes < sizeof(in) + in.payload) return fail(h, TETSIM_EINVAL, "state blob is truncated");
-    HIPCHK(h, hipSetDevice(h->opt.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    if (int rc = quiesce(h)) return rc;
     const char* src = static_cast<const char*>(blob) + sizeof(in);
     std::vector<StateSection> secs;
     state_sections(h, secs);

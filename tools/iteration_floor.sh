@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Iteration ablation of the PRODUCT tet kernel (run ON the GPU box; the variant libraries are built beforehand, without a GPU:
-#   for n in 0 3 6; do python tools/mutant_lib.py it$n pj_blocked.hip '#define TETSIM_DBG_ITERS 9' "#define TETSIM_DBG_ITERS $n /* ABLATION OF THE PRODUCT KERNEL */"; done )
+#   for n in 0 3 6; do python tools/mutant_lib.py it$n pj_lab.h '#define TETSIM_ROTATION_ITERATIONS 9' "#define TETSIM_ROTATION_ITERATIONS $n /* ABLATION OF THE PRODUCT KERNEL */"; done )
 # Alternating runs of the bench line through each library; prints one line per library: the tet kernel on the floor (per-launch events,
 # median of the runs), inside the graphs there (wall clock minus particle kernel and launch boundaries), and over the timed frames.
 cd "${GRAFT_REPO_ROOT:-.}"

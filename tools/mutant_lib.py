@@ -2,7 +2,7 @@
 """A library built from a MUTATED copy of the sources (no GPU needed):  python tools/mutant_lib.py NAME FILE 'FROM' 'TO' [FILE 'FROM' 'TO' ...]
 -> tetsim_amd/libtetsim_hip_NAME.so (git-ignored; travels to the GPU box with the snapshot; load it through TETSIM_HIP_LIB).
 The product sources are not touched: the copy lives in a temporary directory.  Used for the iteration ablation of the PRODUCT kernel
-(tools/iteration_floor.sh: `#define TETSIM_DBG_ITERS 9` -> 0 / 3 / 6) -- the development build's run-time knob compiles to a slower
+(tools/iteration_floor.sh: pj_lab.h: `#define TETSIM_ROTATION_ITERATIONS 9` -> 0 / 3 / 6) -- the development build's run-time knob compiles to a slower
 kernel and cannot give the product's memory floor."""
 import importlib.util
 import os

@@ -17,7 +17,7 @@ rm -rf "$MUT/tetsim_amd/csrc/obj" "$MUT/tetsim_amd/csrc/obj_ablation"
 case "${MUTATION:-bias}" in
   bias)  FILE=pj_math.inc;    FROM='const float r = __builtin_amdgcn_rsqf(d);'; TO='const float r = __builtin_amdgcn_rsqf(d) * 1.00000024f; /* MUTATION */' ;;
   cos)   FILE=pj_math.inc;    FROM='__builtin_amdgcn_sinf(rev + 0.24987326f)';  TO='__builtin_amdgcn_sinf(rev + 0.25f) /* MUTATION */' ;;
-  iters) FILE=pj_blocked.hip; FROM='#define TETSIM_DBG_ITERS 9';                TO='#define TETSIM_DBG_ITERS 8 /* MUTATION */'
+  iters) FILE=pj_lab.h;       FROM='#define TETSIM_ROTATION_ITERATIONS 9';     TO='#define TETSIM_ROTATION_ITERATIONS 8 /* MUTATION */'
          FILE2=pj_quad.hip;   FROM2='for (int iter = 1; iter < 9; iter++)';      TO2='for (int iter = 1; iter < 8; iter++) /* MUTATION */' ;;
   *) echo "unknown MUTATION"; exit 2 ;;
 esac
