@@ -203,7 +203,8 @@ int tetsim_create_batch(const float *const *verts, const uint32_t *nv, const int
 int tetsim_get_batch_layout(tetsim_handle h, uint32_t *first_particle, uint32_t *first_elem);
 void tetsim_destroy(tetsim_handle h);
 
-/* Text of the last error on this handle (h == NULL: last error of a failed create on this thread). */
+/* Text of the last error on this handle.  h == NULL: the last error, on this thread, of a failed create or of an entry point that takes
+ * SEVERAL handles (tetsim_group_step_n, tetsim_group_refresh_final, tetsim_halo_exchange_local: "partition <i>: <text>"). */
 const char *tetsim_last_error(tetsim_handle h);
 int tetsim_get_info(tetsim_handle h, TetSimInfo *info);
 

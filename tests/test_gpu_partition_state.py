@@ -143,3 +143,42 @@ def test_the_partitions_skins_add_up_to_the_whole_visual_mesh(mesh, parts, preci
         next(b for b in bodies if b.info.num_neighbours).visualPositions()
     with pytest.raises(TetSimError, match="unpartitioned"):
         bodies[0].setVisualTriangles(np.array([[0, 1, 2]], np.int32))
+
+
+def test_a_group_outlives_a_member_without_touching_it():
+    """In-process groups hold plain pointers to their members.  A member that is destroyed waits for its siblings' transfers into its
+    ghost ranges and is forgotten by them: a survivor can still save its state; stepping the broken group is refused, not a crash."""
+    cells, parts = 8, 3
+    v, t = make_lattice(cells, y0=0.3)
+    owner = _slab_owner(len(v), cells, parts)
+    a = _group(v, t, parts, owner, "fast")
+    group_step_n(a, 7, DT, PP)
+    a[1].close()                                    # (its neighbours' copies of substep 7 may still be queued: destroy drains them)
+    blob = a[0].saveState()
+    assert len(blob) > 0 and np.isfinite(a[2].pos).all()
+    fresh = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=parts, part_index=1, vert_owner=owner)
+    with pytest.raises(TetSimError, match="destroyed or replaced"):
+        group_step_n([a[0], fresh, a[2]], 1, DT, PP)
+    # a group built anew takes the survivor's checkpoint
+    b = _group(v, t, parts, owner, "fast")
+    b[0].loadState(blob)
+    group_step_n(b, 1, DT, PP)
+    assert np.isfinite(_gather(b, len(v))).all()
+
+
+def test_a_partition_that_keeps_no_row_of_the_visual_mesh():
+    cells, parts = 8, 4
+    v, t = make_lattice(cells, y0=0.3)
+    owner = _slab_owner(len(v), cells, parts)
+    bodies = _group(v, t, parts, owner, "fast")
+    first_slab = np.flatnonzero((owner[t] == 0).all(axis=1))[:50]       # tets whose four corners lie in slab 0
+    vis = np.concatenate([first_slab[:, None].astype(np.float32), np.full((len(first_slab), 3), 0.25, np.float32)], axis=1)
+    for b in bodies:
+        b.setVisualMesh(vis)
+        with pytest.raises(TetSimError, match="already attached"):
+            b.setVisualMesh(vis)                                        # (also for the partitions that kept nothing)
+    assert [b.numVisVerts for b in bodies] == [len(vis), 0, 0, 0]
+    group_step_n(bodies, 5, DT, PP)
+    group_refresh_final(bodies)
+    assert bodies[3].visualPositions().shape == (0, 3) and len(bodies[3].visualIds) == 0
+    assert _same(bodies[0].visualPositions(), _host_skin(_gather(bodies, len(v)), t, vis))

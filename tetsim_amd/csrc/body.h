@@ -292,6 +292,8 @@ namespace tetsim {
 
 int fail(tetsim_body* h, int code, const std::string& msg);  // records the message on the handle (or for tetsim_last_error(NULL))
 const char* create_error();
+void group_begin(tetsim_body* const* hs, uint32_t count);             // entry points over several handles: clear the members' messages ...
+int group_result(tetsim_body* const* hs, uint32_t count, int rc);     // ... and publish the failing member's for tetsim_last_error(NULL)
 
 template <class Tp>
 inline int dev_alloc(tetsim_body* h, Tp** p, size_t count) {

@@ -19,6 +19,18 @@ int fail(tetsim_body* h, int code, const std::string& msg) {
     return code;
 }
 const char* create_error() { return g_create_error.c_str(); }
+// Entry points over SEVERAL handles: the caller cannot know whose message to ask for, so the failing member's text is also what
+// tetsim_last_error(NULL) returns on this thread.
+int group_result(tetsim_body* const* hs, uint32_t count, int rc) {
+    if (rc == TETSIM_OK || !hs) return rc;
+    for (uint32_t i = 0; i < count; i++)
+        if (hs[i] && !hs[i]->err.empty()) { g_create_error = "partition " + std::to_string(i) + ": " + hs[i]->err; return rc; }
+    g_create_error = "bad argument";
+    return rc;
+}
+void group_begin(tetsim_body* const* hs, uint32_t count) {
+    if (hs) for (uint32_t i = 0; i < count; i++) if (hs[i]) hs[i]->err.clear();
+}
 
 // float(int(uv.x*(R-1)) + int(uv.y*(R-1)*R)) == grabId with uv = (px+.5, py+.5)/R, all in f32.  Rows cannot collide
 // (the y term advances by R-1 per row and the x term is below R-1), columns px and px+1 can.
@@ -575,6 +587,16 @@ void tetsim_destroy(tetsim_handle h) {
     (void)hipSetDevice(h->opt.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    // an in-process group: the other members' queues may still hold transfers into THIS body's ghost ranges; and they forget this body
+    // (tetsim_group_step_n refuses a group with a member gone, tetsim_save_state / _load_state skip it)
+    for (tetsim_body* g : h->group) {
+        if (!g || g == h) continue;
+        (void)hipSetDevice(g->opt.device);
+        if (g->stream) (void)hipStreamSynchronize(g->stream);
+        if (g->comm_stream) (void)hipStreamSynchronize(g->comm_stream);
+        for (tetsim_body*& x : g->group) if (x == h) x = nullptr;
+    }
+    (void)hipSetDevice(h->opt.device);
     if (h->blk.trace && lab_env("TETSIM_DEBUG_TRACE")) {
         std::vector<unsigned long long> tr(8ull * h->blk.nb);
         if (hipMemcpy(tr.data(), h->blk.trace, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost) == hipSuccess)

@@ -308,7 +308,12 @@ int tetsim_halo_refresh_final(tetsim_handle h) {
     if (!h->comm) return fail(h, TETSIM_ESTATE, "no RCCL communicator on this body (in-process groups: tetsim_group_refresh_final)");
     return refresh_final_rccl(h);
 }
+static int tetsim_group_refresh_final_impl(tetsim_handle* hs, uint32_t count);
 int tetsim_group_refresh_final(tetsim_handle* hs, uint32_t count) {
+    group_begin(hs, count);
+    return group_result(hs, count, tetsim_group_refresh_final_impl(hs, count));
+}
+static int tetsim_group_refresh_final_impl(tetsim_handle* hs, uint32_t count) {
     if (!hs || count == 0) return TETSIM_EINVAL;
     for (uint32_t i = 0; i < count; i++)
         if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i) || hs[i]->opt.solver != TETSIM_SOLVER_POLAR_JACOBI)

@@ -483,13 +483,20 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
 
 extern "C" {
 
+static int tetsim_group_step_n_impl(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params);
 int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
+    group_begin(hs, count);
+    return group_result(hs, count, tetsim_group_step_n_impl(hs, count, n, dt, params));
+}
+static int tetsim_group_step_n_impl(tetsim_handle* hs, uint32_t count, uint32_t n, double dt, const TetSimParams* params) {
     if (!hs || count == 0) return TETSIM_EINVAL;
     for (uint32_t i = 0; i < count; i++) {
         tetsim_body* h = hs[i];
         if (!h || h->opt.part_count != static_cast<int32_t>(count) || h->opt.part_index != static_cast<int32_t>(i) || h->comm)
             return fail(h, TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition without an RCCL communicator");
         if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "POLAR_JACOBI only");
+        if (!h->group.empty() && (h->group.size() != count || !std::equal(h->group.begin(), h->group.end(), hs)))
+            return fail(h, TETSIM_ESTATE, "this partition was wired to other handles by its first tetsim_group_step_n call (a member of the group was destroyed or replaced): create the partitions anew");
         if (h->group.empty()) {  // first use: wire the group and give every partition its halo stream (on ITS device)
             h->group.assign(hs, hs + count);
             HIPCHK(h, hipSetDevice(h->opt.device));
@@ -523,7 +530,12 @@ int tetsim_group_step_n(tetsim_handle* hs, uint32_t count, uint32_t n, double dt
     return 0;
 }
 
+static int tetsim_halo_exchange_local_impl(tetsim_handle* hs, uint32_t count);
 int tetsim_halo_exchange_local(tetsim_handle* hs, uint32_t count) {
+    group_begin(hs, count);
+    return group_result(hs, count, tetsim_halo_exchange_local_impl(hs, count));
+}
+static int tetsim_halo_exchange_local_impl(tetsim_handle* hs, uint32_t count) {
     if (!hs || count == 0) return TETSIM_EINVAL;
     for (uint32_t i = 0; i < count; i++) {
         if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i))

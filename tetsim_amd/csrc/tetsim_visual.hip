@@ -8,7 +8,7 @@ extern "C" {
 
 int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvis, const float* rest_normals) {
     if (!h || (nvis && !vis_verts)) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->skin.nvis || !h->vis_global.empty()) return fail(h, TETSIM_ESTATE, "a visual mesh is already attached");
+    if (h->vis_attached) return fail(h, TETSIM_ESTATE, "a visual mesh is already attached");
     HIPCHK(h, hipSetDevice(h->opt.device));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     const uint32_t nt = h->info.num_elems;

@@ -278,9 +278,8 @@ class SoftBodyHIP:
     # -- embedded visual mesh (Softbody.js:259-277 / SoftbodyGPU.js:424-448), skinned on the device ---------------
     def setVisualMesh(self, visVerts, restNormals=None):
         vv = _f32(visVerts).reshape(-1)
-        self.numVisVerts = vv.size // 4
         n0 = None if restNormals is None else _f32(restNormals).reshape(-1)
-        capi.check(self._L.tetsim_set_visual_mesh(self._h, _fp(vv), self.numVisVerts, _fp(n0) if n0 is not None else None), self._h)
+        capi.check(self._L.tetsim_set_visual_mesh(self._h, _fp(vv), vv.size // 4, _fp(n0) if n0 is not None else None), self._h)
         self._has_normals = n0 is not None
         capi.check(self._L.tetsim_get_info(self._h, C.byref(self.info)), self._h)
         self.numVisVerts = self.info.num_vis_verts   # (a partition keeps the rows of the tets it owns: visualIds)
