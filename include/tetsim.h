@@ -411,7 +411,10 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void *blobs, uint32_t count);
 /* All partitions of one decomposition living in ONE process (one or several devices): n substeps with the SAME
  * stream/event choreography as the RCCL path -- interior tiles, wait for the previous halo, boundary tiles, boundary
  * particles, start the halo on a second stream, interior particles -- with asynchronous device copies standing in
- * for ncclSend/ncclRecv.  handles[i] must be partition i.  Asynchronous; reads synchronise. */
+ * for ncclSend/ncclRecv.  handles[i] must be partition i.  Asynchronous; reads synchronise.  The first call wires the members to
+ * each other (plain pointers); tetsim_destroy of a member first drains its siblings' queues (their transfers land in its ghost ranges)
+ * and the siblings forget it: they can still be read, saved and destroyed, a later tetsim_group_step_n with them is TETSIM_ESTATE
+ * (create the partitions anew).  On failure tetsim_last_error(NULL) has the failing member's text. */
 int tetsim_group_step_n(tetsim_handle *handles, uint32_t count, uint32_t n, double dt, const TetSimParams *params);
 /* In-process transport for partitions living on one device (tests; "multi-GPU without a cluster"):
  * after every handle has been stepped ONE substep, copy owned interface positions into the
