@@ -153,6 +153,7 @@ struct tetsim_body {
     bool halo_graph_broken = false;
     bool halo_warm = false;             // RCCL bodies: one eager call has run (connections are set up before any capture)
     bool loopback = false;              // measurement only (TETSIM_DEBUG_LOOPBACK_HALO): every neighbour is this rank itself
+    bool vel_dead = false;              // the substep being enqueued is not the last of its call: its particle kernels leave the velocity array alone (nobody reads it before the call's last substep)
     bool needs_halo_refresh = false;    // in-process group: predictions were redone for a new dt
     bool fork_needed = true;            // first substep of a step call: the boundary stream must see the main stream's history
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr;

@@ -189,7 +189,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         pos_stage = make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f);
         if (has_slot && ((range >> 15) & 1u)) {   // one writer per particle
             store_wt(d.fin_out, vid, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
-            store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+            if (d.vel) store_wt(d.vel, vid, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
         }
     } else if constexpr (kHaloWait) {
         if (tid < 64u) {
@@ -633,7 +633,7 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
     // (the weight: sum of the rest volumes of the particle's live corners -- a constant, added up on the host in the tiles' entry order)
     const VertexOut o = pjb_vertex_update(xyz(acc), d.wsum[v], xyz(d.fin_in[v]), *d.params, v);
     store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, 0.0f));
-    store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));
+    if (d.vel) store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));   // (null between two substeps of one call: nothing reads it there)
     store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
     if constexpr (kPeer) {
         // peer-to-peer halo: the prediction also goes straight into the ghost range of every neighbour that reads this particle

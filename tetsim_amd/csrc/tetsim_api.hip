@@ -180,7 +180,7 @@ void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e) {
         k.partial_prev = pbuf[(s - 1u) & 1u];
         k.fin_in = fbuf[h->fin_in_b ? 1 : 0];
         k.fin_out = fbuf[h->fin_in_b ? 0 : 1];
-        pjb_launch_tet_fused(h->stream, k, e ? e[0] : nullptr, e ? e[1] : nullptr);
+        { PJBlk kf = k; kf.vel = nullptr; pjb_launch_tet_fused(h->stream, kf, e ? e[0] : nullptr, e ? e[1] : nullptr); }   // (its particle update is never a call's last: the velocity stays in registers)
         h->fin_in_b = !h->fin_in_b;
     }
     if (last) {
@@ -291,15 +291,24 @@ int launch_frame_kernel(tetsim_body* h, uint32_t n, uint32_t epoch) {
 int enqueue_substep(tetsim_body* h, bool first, bool last) {
     if (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) {
         if (h->deep && !h->p2p) return fail(h, TETSIM_ESTATE, "a body with a two-layer ghost region steps through the peer-to-peer halo only: call tetsim_halo_p2p_export / _connect first");
+        // Between two substeps of one call nobody reads the velocity array: the particle kernel hands the velocity on to the next
+        // prediction in registers; re-prediction after a dt change, read-back, checkpoints and the next call all sit behind the call's
+        // LAST substep.  Its store -- 16 B per particle and substep -- is left out everywhere but there (blocked kernels: a null pointer).
         if (has_transport(h)) {
+            h->vel_dead = !last;
             int rc = enqueue_phase_a(h);
+            h->vel_dead = false;
             if (!rc) rc = enqueue_phase_b(h);
             if (rc) return rc;
         } else if (h->fused) {
             pj_fused_substep(h, first, last, nullptr);
         } else {
             pj_tet(h);
-            pj_vertex(h, 0, h->pj.nv_owned);
+            if (h->blocked && !h->quad && !last) {
+                PJBlk k = h->blk;
+                k.vel = nullptr;   // (see above)
+                pjb_launch_vertex(h->stream, k, 0, h->pj.nv_owned);
+            } else pj_vertex(h, 0, h->pj.nv_owned);
         }
     } else {
         // clustered schedules fold the particle pass BETWEEN two substeps of a run into the next sweep: the lane of the first cluster
@@ -703,7 +712,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
             }
         }
         if (!own_rank || !h->comm || !use_graph || !h->halo_warm || h->halo_graph_broken || uses_flag_sync(h)) {
-            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
             if (!rc) rc = flush_v(h);
             h->halo_warm = true;
             return rc;
@@ -723,7 +732,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
             h->halo_graph_broken = true;
             (void)hipGetLastError();
             rc = 0;
-            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h);
+            for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
             if (!rc) rc = flush_v(h);
             return rc;
         }

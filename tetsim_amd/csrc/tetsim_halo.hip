@@ -152,6 +152,9 @@ static void interior_particles(tetsim_body* h, const PJSync& yg, hipEvent_t* ev)
 int enqueue_phase_a(tetsim_body* h, hipEvent_t* ev) {  // tet kernels + particles; ev[0..3]: begin/end of the interior tet and the particle kernel
     if (h->deep && !h->p2p) return fail(h, TETSIM_ESTATE, "a body with a two-layer ghost region steps through the peer-to-peer halo only: call tetsim_halo_p2p_export / _connect first");
     if (!h->group.empty()) HIPCHK(h, hipSetDevice(h->opt.device));  // in-process groups may span devices: streams, events and lazy allocations below are per device
+    // (a substep that is not its call's last: every particle kernel below gets a null velocity array -- tetsim_api.hip: enqueue_substep)
+    struct VelGuard { PJBlk& b; float4* keep; ~VelGuard() { b.vel = keep; } } vel_guard{h->blk, h->blk.vel};
+    if (h->vel_dead) h->blk.vel = nullptr;
     if (h->blocked) {
         const uint32_t nbnd = h->blk.nb - h->blk.nb_interior;
         static const bool one_stream = [] { const char* e = getenv("TETSIM_DEBUG_ONE_STREAM"); return e && e[0] == '1'; }();
@@ -457,7 +460,9 @@ int step_n_flag_graphs(tetsim_body* h, uint32_t n) {
         if (e != hipSuccess) { (void)hipStreamEndCapture(h->stream, &gm); if (gm) (void)hipGraphDestroy(gm); undo(); return fail(h, TETSIM_EHIP, std::string("begin capture (halo stream): ") + hipGetErrorString(e)); }
         int rc = 0;
         for (uint32_t i = 0; i < n && !rc; i++) {
+            h->vel_dead = i + 1 != n;
             rc = enqueue_phase_a(h);
+            h->vel_dead = false;
             if (!rc) rc = enqueue_phase_b(h);
         }
         if (!rc) rc = flush_v(h);
@@ -521,7 +526,7 @@ static int tetsim_group_step_n_impl(tetsim_handle* hs, uint32_t count, uint32_t 
     }
     static const bool dbg_sync = getenv("TETSIM_DEBUG_GROUP_SYNC") != nullptr;  // development: serialise every phase
     for (uint32_t s = 0; s < n; s++) {
-        for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_a(hs[i]); if (rc) return rc; }
+        for (uint32_t i = 0; i < count; i++) { hs[i]->vel_dead = s + 1 != n; int rc = enqueue_phase_a(hs[i]); hs[i]->vel_dead = false; if (rc) return rc; }
         if (dbg_sync) (void)hipDeviceSynchronize();
         for (uint32_t i = 0; i < count; i++) { int rc = enqueue_phase_b(hs[i]); if (rc) return rc; }
         if (dbg_sync) (void)hipDeviceSynchronize();
