@@ -341,7 +341,7 @@ void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e);   // one substep of a fused body (tet | fused x (n-1) | particle)
 void pj_repredict(tetsim_body* h);
-void nh_sweep(tetsim_body* h, bool fold = false);   // fold: first touchers do the particle pass between two substeps
+void nh_sweep(tetsim_body* h, bool fold = false, bool last = true);   // fold: first touchers do the particle pass between two substeps; last: the sweep whose volError the call leaves behind
 // first / last: position inside a run of substeps enqueued back to back with one dt
 int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
 int ensure_prediction(tetsim_body* h, double dt);

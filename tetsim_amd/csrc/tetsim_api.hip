@@ -198,9 +198,13 @@ void pj_repredict(tetsim_body* h) {
 // The halo stream carries the transfers AND the boundary tiles that consume them; high priority so that its few
 // workgroups are dispatched ahead of the interior kernel's backlog.
 // NEOHOOKEAN_GS: the Gauss-Seidel sweep over all tets (A3-A5), as dependency levels or as cluster colours
-void nh_sweep(tetsim_body* h, bool fold) {
+// last = the call's last sweep: `volError` (Softbody.js:163, reset by every simulate()) is what THAT sweep leaves behind; an earlier
+// sweep's per-tet values would be overwritten unread -- 8 B per tet-solve of dead stores, left out (a null pointer)
+void nh_sweep(tetsim_body* h, bool fold, bool last) {
+    NHDev nh = h->nh;
+    if (!last) nh.vol_err = nullptr;
     if (!h->cluster_launch.empty()) {
-        for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, h->nh, L, fold) : nh_launch_cluster_precise(h->stream, h->nh, L, fold);
+        for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, nh, L, fold) : nh_launch_cluster_precise(h->stream, nh, L, fold);
         return;
     }
     if (h->nh_frame && h->fast) {
@@ -210,8 +214,8 @@ void nh_sweep(tetsim_body* h, bool fold) {
         for (size_t l = 0; l + 1 < h->level_off.size(); l++)
             for (uint32_t b = 0; b < bodies; b++) {
                 const uint32_t first = h->nh_seg[2u * (l * bodies + b)], count = h->nh_seg[2u * (l * bodies + b) + 1u] - first;
-                if (count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, h->nh, first, count);
-                else nh_launch_level_fast(h->stream, h->nh, first, count);
+                if (count <= kNHQuadLevelFast) nh_launch_level4_fast(h->stream, nh, first, count);
+                else nh_launch_level_fast(h->stream, nh, first, count);
             }
         return;
     }
@@ -222,8 +226,8 @@ void nh_sweep(tetsim_body* h, bool fold) {
     constexpr uint32_t level4_max = 8192u;
     for (size_t l = 0; l + 1 < h->level_off.size(); l++) {
         const uint32_t first = h->level_off[l], count = h->level_off[l + 1] - first;
-        if (count <= level4_max) h->fast ? nh_launch_level4_fast(h->stream, h->nh, first, count) : nh_launch_level4_precise(h->stream, h->nh, first, count);
-        else h->fast ? nh_launch_level_fast(h->stream, h->nh, first, count) : nh_launch_level_precise(h->stream, h->nh, first, count);
+        if (count <= level4_max) h->fast ? nh_launch_level4_fast(h->stream, nh, first, count) : nh_launch_level4_precise(h->stream, nh, first, count);
+        else h->fast ? nh_launch_level_fast(h->stream, nh, first, count) : nh_launch_level_precise(h->stream, nh, first, count);
     }
 }
 
@@ -315,7 +319,7 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
         // to touch a particle finishes the previous substep and predicts the next for it while loading it (nh_kernels.inc:
         // fold_particle) -- one kernel and one launch boundary less per substep, the same operations per particle
         if (first) h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
-        nh_sweep(h, !first && h->nh_fold);
+        nh_sweep(h, !first && h->nh_fold, last);
         if (last) h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
         else if (h->nh_fold) h->fast ? nh_launch_post_predict_list_fast(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched)
                                      : nh_launch_post_predict_list_precise(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched);
