@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TETSIM_ABI_VERSION 4
+#define TETSIM_ABI_VERSION 5
 
 typedef struct tetsim_body *tetsim_handle;
 
@@ -103,7 +103,20 @@ enum {
      * below the rotation that f32 position rounding alone induces in a centimetre-sized tet a metre from the origin (iteration 1 of
      * a rigid free fall reads 1e-6..3e-5, profiles/r04_rotation_iterations.txt).  Iteration 1 always keeps the reference's test.
      * PRECISE ignores this flag: it always is the reference. */
-    TETSIM_FLAG_REF_ROTATION_EXIT = 1u << 6
+    TETSIM_FLAG_REF_ROTATION_EXIT = 1u << 6,
+    /* POLAR_JACOBI + FAST + blocked: the LEAN tet record (since ABI 5).  The reference streams per tet and substep the carried
+     * ("last rotated") rest shape in and out (SoftbodyGPU.js:253-262: 4 corners, 48 B each way) and its quaternion in and out
+     * (:181, 16 B each way): 148 B with the staged positions and the weight.  Two of those items are redundant in FAST arithmetic:
+     * (a) the quaternion is PURE OUTPUT of a substep -- the rotation applied to the shape is this substep's `rel` alone -- and the
+     * carried shape IS the accumulated rotation applied to the rest shape, so the quaternion is recovered from the shape when it
+     * is asked for (tetsim_read_quats, the visual mesh, tetsim_save_state) instead of being multiplied up every substep;
+     * (b) the shape is kept relative to its own centroid, so its fourth corner is minus the sum of the other three.
+     * 92 B per tet instead of 148.  Rounding differs from the default FAST path at tolerance level (the fourth corner is rebuilt,
+     * not carried; the read-out quaternion is R = C S0^-1 -> q, equal to the multiplied-up one to ~1e-6, and equal in SIGN as long as
+     * a tet turns by less than pi between two read-outs); a zero-volume tet reads back the quaternion it was created with.  Small
+     * bodies take the 256-tet-tile kernels (TetSimInfo.fused_particle_pass 2, not 3).  Excludes _CONSTANT_REST_SHAPE and _DEEP_GHOSTS.
+     * Off by default: the benchmark's headline measures the reference's formulation, `value_lean` this one (bench.py). */
+    TETSIM_FLAG_LEAN_STATE = 1u << 7
 };
 
 /* physicsParams (main.js:22-36) -- the keys the hot path reads each substep. */
@@ -262,7 +275,14 @@ int tetsim_write_state(tetsim_handle h, const float *pos, const float *vel);
  * (part_count, part_index, the owner map as this partition sees it), so a blob of another decomposition is rejected.  All ranks save
  * at the same substep count (after tetsim_sync) and restore together: a multi-GPU run that lost a rank rebuilds its partitions with
  * the same owner map, loads the last set of blobs, re-attaches the transport and continues bit for bit.  Transport state is not in
- * the blob (semaphore words are at rest after a sync; the peer-to-peer halo's substep parity stays the restored body's own).  Not
+ * the blob (semaphore words are at rest after a sync; the peer-to-peer halo's substep parity stays the restored body's own).
+ * ONE RANK PER PROCESS with the peer-to-peer halo (since ABI 5): a neighbour stores into this rank's ghost range from ITS queues, which
+ * this rank cannot drain.  tetsim_save_state therefore waits (bounded: TETSIM_HALO_TIMEOUT_MS, TETSIM_ECOMM) until every neighbour's
+ * predictions of the last substep have arrived, and never writes into a receive buffer -- a rank may save while its neighbours are
+ * already stepping on; no barrier is needed around a save beyond "every rank saves after the same number of substeps".
+ * tetsim_load_state overwrites both ghost buffers: the CALLER brackets the ranks' loads with barriers -- no rank loads before every
+ * rank has synchronised (tetsim_sync), no rank steps before every rank has loaded (tests/test_gpu_p2p_halo.py shows the sequence).
+ * TETSIM_FLAG_LEAN_STATE bodies: the blob holds three carried corners per tet and the quaternions as recovered at the save.  Not
  * supported: bodies with a two-layer ghost region (TETSIM_FLAG_DEEP_GHOSTS). */
 int tetsim_state_size(tetsim_handle h, uint64_t *bytes_out);
 int tetsim_save_state(tetsim_handle h, void *blob, uint64_t bytes);
@@ -295,8 +315,10 @@ int tetsim_get_visual_ids(tetsim_handle h, int32_t *out);
  * normals_out [3*num_vis_verts] (may be NULL): Rotate(rest_normal, quat[tetNr]) as SoftbodyGPU.js:440 -- POLAR_JACOBI only.
  * A PARTITION returns its own rows (tetsim_get_visual_ids order); scattered by row number, the partitions' outputs equal the
  * unpartitioned body's bit for bit (PRECISE).  Corners it does not own need their owner's END-OF-SUBSTEP position, which the
- * per-substep halo does not carry (it carries predictions): RCCL bodies fetch them here -- every rank calls this together, once per
- * frame --, in-process groups call tetsim_group_refresh_final first. */
+ * per-substep halo does not carry (it carries predictions): every rank calls tetsim_halo_refresh_final (RCCL; in-process groups:
+ * tetsim_group_refresh_final) after the frame's last substep, THEN reads.  The read itself never communicates (since ABI 5; before,
+ * RCCL bodies ran the exchange from inside it, and ranks that disagreed on whether it was due hung each other): with stale ghosts
+ * it fails with TETSIM_ESTATE.  A freshly created partition is fresh (its ghost range holds the rest positions). */
 int tetsim_read_visual_mesh(tetsim_handle h, float *positions_out, float *normals_out);
 /* The end-of-substep positions of this partition's ghost particles, from their owners, into the ghost range behind
  * tetsim_read_positions' owned range (what tetsim_read_visual_mesh needs; valid until the next step).  RCCL bodies: a collective of

@@ -48,7 +48,8 @@ def rank_main(r):
                     body.simulate(dts[c], PP)                    # tetsim_step, one substep per call
             else:
                 body.simulateSubsteps(per_call, dts[c], PP)      # tetsim_step_n
-        results[r] = (body.ownedIds, body.pos, body.visualIds, body.visualPositions())   # (visualPositions: a collective of the ranks)
+        body.refreshFinalGhosts()                                # a collective of the ranks, once per frame; the read below never communicates
+        results[r] = (body.ownedIds, body.pos, body.visualIds, body.visualPositions())
         # checkpoint / resume over the RCCL transport: every rank saves its blob, steps on, goes back, steps again -- the same bits
         blob = body.saveState()
         body.simulateSubsteps(5, dts[-1], PP)

@@ -34,7 +34,7 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     lib = d["library"]
-    assert lib["abi"] == 4 and lib["ablation"] is False and lib["debug_env"] == [] and len(lib["kernel_sha"]) == 16
+    assert lib["abi"] == 5 and lib["ablation"] is False and lib["debug_env"] == [] and len(lib["kernel_sha"]) == 16
     assert rf["traffic"] is None          # not the headline lattice: no counter figure is attached to it
     # the dominant kernel is timed over a replay of the timed frames, which must retrace them bit for bit; the window after them beside it
     assert "bit-equal to the timed one: True" in rf["fast_exit"]["window"] and rf["after_timed_region"]["kernel_us"] > 0

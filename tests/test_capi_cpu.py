@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.tetsim_abi_version() == 4
+    assert L.tetsim_abi_version() == 5
 
 
 def test_library_info_matches_the_tree():
     """The loaded library says which sources it was built from; the product build is never the ablation build."""
     from tetsim_amd.build import source_shas
     info = capi.library_info()
-    assert info["abi"] == 4 and info["ablation"] is False
+    assert info["abi"] == 5 and info["ablation"] is False
     assert (info["source_sha"], info["kernel_sha"]) == source_shas(), "libtetsim_hip.so is stale: run python -m tetsim_amd.build"
     assert re.fullmatch(r"[0-9a-f]{16}", info["source_sha"]) and re.fullmatch(r"[0-9a-f]{16}", info["kernel_sha"])
 

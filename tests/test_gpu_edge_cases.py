@@ -165,7 +165,7 @@ def test_pinned_zero_copy_readback_equals_copying_readback(solver, precision):
 
 
 @pytest.mark.parametrize("kw", [dict(precision="precise"), dict(precision="fast"), dict(precision="fast", gather=True),
-                                dict(precision="fast", constant_rest_shape=True)])
+                                dict(precision="fast", constant_rest_shape=True), dict(precision="fast", lean_state=True)])
 def test_polar_save_load_state_continues_bit_for_bit(kw):
     """tetsim_save_state / tetsim_load_state carry the COMPLETE polar state (positions, velocities, quaternions, carried rest
     shape): a fresh body restored from the blob continues the original trajectory bit for bit -- which tetsim_write_state
@@ -245,7 +245,7 @@ def test_neohookean_save_load_state():
     assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32)) and a.volError == b.volError
 
 
-@pytest.mark.parametrize("kw", [dict(precision="precise"), dict(precision="fast")])
+@pytest.mark.parametrize("kw", [dict(precision="precise"), dict(precision="fast"), dict(precision="fast", lean_state=True)])
 def test_pinned_quaternion_view_equals_copying_read(kw):
     """SURVEY.md 8(f)-2, quaternion half: tetsim_read_quats_pinned is a view of a pinned host buffer (same address every
     call) and holds what tetsim_read_quats returns."""
@@ -265,7 +265,7 @@ def test_pinned_quaternion_view_equals_copying_read(kw):
 def test_library_info_on_the_gpu_box():
     from tetsim_amd import library_info
     info = library_info()
-    assert info["abi"] == 4 and info["ablation"] is False and len(info["source_sha"]) == 16
+    assert info["abi"] == 5 and info["ablation"] is False and len(info["source_sha"]) == 16
 
 
 def test_partitioned_bodies_keep_their_rows_of_the_visual_mesh(tmp_path):
@@ -289,6 +289,7 @@ def test_partitioned_bodies_keep_their_rows_of_the_visual_mesh(tmp_path):
 
 @pytest.mark.parametrize("kw", [dict(solver="polar", precision="precise"), dict(solver="polar", precision="fast"),
                                 dict(solver="polar", precision="fast", gather=True), dict(solver="polar", precision="fast", constant_rest_shape=True),
+                                dict(solver="polar", precision="fast", lean_state=True),
                                 dict(solver="neohookean", precision="precise", order="original"), dict(solver="neohookean", precision="precise", order="coloured"),
                                 dict(solver="neohookean", precision="precise", order="clustered"), dict(solver="neohookean", precision="fast", order="clustered")])
 def test_batch_of_bodies_equals_solo_runs_bit_for_bit(kw):

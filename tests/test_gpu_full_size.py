@@ -52,12 +52,12 @@ def oracle_1m_polar(lattice_1m):
     return out
 
 
-@pytest.mark.parametrize("mode,tol1,tol20", [("precise", 2.5e-7, 1e-6), ("fast", 4e-6, 2e-4), ("fast-gather", 4e-6, 5e-5)])
+@pytest.mark.parametrize("mode,tol1,tol20", [("precise", 2.5e-7, 1e-6), ("fast", 4e-6, 2e-4), ("fast-gather", 4e-6, 5e-5), ("fast-lean", 4e-6, 2e-4)])
 def test_lattice_1m_polar_vs_oracle(mode, tol1, tol20, lattice_1m, oracle_1m_polar):
     """BASELINE config 3: free fall from 0.5 m (substeps 1 and 20), through tetsim_step and tetsim_step_n."""
     _, t = lattice_1m
     vv, ref = oracle_1m_polar[0.5]
-    kw = dict(precision="precise") if mode == "precise" else dict(precision="fast", gather=mode == "fast-gather")
+    kw = dict(precision="precise") if mode == "precise" else dict(precision="fast", gather=mode == "fast-gather", lean_state=mode == "fast-lean")
     body = SoftBodyHIP(vv, t, None, dict(PP), solver="polar", **kw)
     body.simulate(DT20, PP)
     within("polar %s 1M lattice vs oracle @1" % mode, np.abs(body.pos - ref[1][0]).max(), tol1)
@@ -70,13 +70,13 @@ def test_lattice_1m_polar_vs_oracle(mode, tol1, tol20, lattice_1m, oracle_1m_pol
     assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-5
 
 
-@pytest.mark.parametrize("mode,tol", [("precise", 1e-6), ("fast", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("precise", 1e-6), ("fast", 1e-4), ("fast-lean", 1e-4)])
 def test_lattice_1m_polar_floor_contact_vs_oracle(mode, tol, lattice_1m, oracle_1m_polar):
     """The same body dropped 0.5 mm onto the floor: 20 substeps with the bottom face in contact (clamp + friction branch of
     the particle pass on 3,136 particles, deformation in the tiles above it)."""
     _, t = lattice_1m
     vv, ref = oracle_1m_polar[0.0005]
-    body = SoftBodyHIP(vv, t, None, dict(PP), solver="polar", precision=mode)
+    body = SoftBodyHIP(vv, t, None, dict(PP), solver="polar", precision=mode.split("-")[0], lean_state=mode == "fast-lean")
     body.simulateSubsteps(20, DT20, PP)
     p = body.pos
     assert p[:, 1].min() == 0.0 and ref[20][0][:, 1].min() == 0.0

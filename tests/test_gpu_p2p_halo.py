@@ -169,6 +169,84 @@ def test_two_processes_share_one_gpu_through_ipc_mappings(tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+_CHECKPOINT_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+from tetsim_amd import SoftBodyHIP, make_lattice, p2p_connect, p2p_export
+rank, world, out, lean = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1], sys.argv[2] == "lean"
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+pp = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0, worldBounds=[-2.5, -1.0, -2.5, 2.5, 10.0, 2.5])
+cells = 16
+v, t = make_lattice(cells, y0=0.02)
+owner = np.minimum((np.arange(len(v)) // (cells + 1) ** 2) * world // (cells + 1), world - 1).astype(np.int32)
+body = SoftBodyHIP(v, t, None, dict(pp), solver="polar", precision="fast", part_count=world, part_index=rank, vert_owner=owner, lean_state=lean)
+blobs = [None] * world
+dist.all_gather_object(blobs, p2p_export(body))
+p2p_connect(body, blobs)
+dist.barrier()
+dt = (1.0 / 60.0) / 20
+for n in (20, 1):
+    body.simulateSubsteps(n, dt, pp)
+body.sync()
+# 21 substeps: an ODD parity (the ghosts live in the second buffer).  No barrier in front of the save: the neighbour may still be inside
+# its last substep -- tetsim_save_state waits for its deliveries itself (and must not touch the live receive buffer of the other parity)
+if rank == 1:
+    import time; time.sleep(0.2)                  # ... and rank 0 is well into its continuation when rank 1 saves
+blob = body.saveState()
+for n in (7, 20):
+    body.simulateSubsteps(n, dt, pp)
+body.sync()
+pos_a, quat_a = body.pos, body.quats
+dist.barrier()                                     # everybody has finished the continuation
+body.loadState(blob)
+dist.barrier()                                     # include/tetsim.h: nobody steps before everybody has loaded
+for n in (7, 20):
+    body.simulateSubsteps(n, dt, pp)
+body.sync()
+assert np.array_equal(body.pos.view(np.uint32), pos_a.view(np.uint32)), "rank %d: the restored continuation differs" % rank
+assert np.array_equal(body.quats.view(np.uint32), quat_a.view(np.uint32))
+np.save(os.path.join(out, "ids%d.npy" % rank), body.ownedIds)
+np.save(os.path.join(out, "pos%d.npy" % rank), body.pos)
+dist.barrier()
+body.close()
+print("RANK_OK", rank, flush=True)
+"""
+
+
+@pytest.mark.parametrize("mode", ["carried", "lean"])
+def test_two_processes_checkpoint_through_ipc_mappings(tmp_path, mode):
+    """Checkpoint / resume of one-rank-per-process peer-to-peer bodies (advisor, round 5): quiesce() drains only a rank's own queues
+    while the NEIGHBOUR stores into its ghost range, so tetsim_save_state waits for the neighbours' "arrived" words itself, copies the
+    odd parity's ghosts straight into the blob (never into the other parity's live receive buffer), and a rank that saves while its
+    neighbour already steps on neither reads stale ghosts nor disturbs the running simulation; loads are bracketed by rank barriers
+    (include/tetsim.h).  The restored continuation equals the original and the in-process decomposition bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rank.py"
+    script.write_text(_CHECKPOINT_SCRIPT)
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", TETSIM_HALO_TIMEOUT_MS="5000", PYTHONPATH=ROOT,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(tmp_path), mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "RANK_OK" in so, (r, so[-300:], se[-1500:])
+    cells = 16
+    v, t = make_lattice(cells, y0=0.02)
+    owner = np.minimum((np.arange(len(v)) // (cells + 1) ** 2) * 2 // (cells + 1), 1).astype(np.int32)
+    ref = _parts(v, t, 2, owner, lean_state=mode == "lean")
+    for n in (20, 1, 7, 20):
+        group_step_n(ref, n, DT, PP)
+    want = _gather(ref, len(v))
+    got = np.empty_like(want)
+    for r in range(2):
+        got[np.load(tmp_path / ("ids%d.npy" % r))] = np.load(tmp_path / ("pos%d.npy" % r))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 # ---- two-layer ghost region: ghosts cross only every other substep (TETSIM_FLAG_DEEP_GHOSTS) -------------------------------------------
 def _deep_parts(v, t, n, owner):
     return [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", part_count=n, part_index=p, vert_owner=owner, deep_ghosts=True) for p in range(n)]

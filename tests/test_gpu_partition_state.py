@@ -37,12 +37,14 @@ def _same(a, b):
     return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
 
 
-@pytest.mark.parametrize("precision,p2p", [("precise", False), ("fast", False), ("fast", True)])
+@pytest.mark.parametrize("precision,p2p", [("precise", False), ("fast", False), ("fast", True), ("fast-lean", False), ("fast-lean", True)])
 def test_a_restored_group_of_eight_slabs_continues_bit_for_bit(precision, p2p):
     cells, parts = 16, 8
+    kw = dict(lean_state=True) if precision == "fast-lean" else {}   # TETSIM_FLAG_LEAN_STATE: the blob holds three corners per tet and the recovered quaternions
+    precision = precision.split("-")[0]
     v, t = make_lattice(cells, y0=0.02)          # reaches the floor within the first call: contact is part of the state
     owner = _slab_owner(len(v), cells, parts)
-    a = _group(v, t, parts, owner, precision)
+    a = _group(v, t, parts, owner, precision, **kw)
     group_step_n(a, 3, DT, PP)
     if p2p:
         group_p2p_connect(a)
@@ -53,7 +55,7 @@ def test_a_restored_group_of_eight_slabs_continues_bit_for_bit(precision, p2p):
     ref_pos, ref_vel = _gather(a, len(v)), _gather(a, len(v), "vel")
     ref_quat = [b.quats.copy() for b in a]
     # a fresh group -- another process after a lost rank would build exactly this --, transport attached, state loaded
-    b = _group(v, t, parts, owner, precision)
+    b = _group(v, t, parts, owner, precision, **kw)
     group_step_n(b, 2, DT, PP)                   # (its own history, and an EVEN parity, before the load: none of it may survive)
     if p2p:
         group_p2p_connect(b)
@@ -71,10 +73,10 @@ def test_a_restored_group_of_eight_slabs_continues_bit_for_bit(precision, p2p):
     # a blob belongs to ITS partition of ITS cut
     with pytest.raises(TetSimError, match="another mesh|other options"):
         b[0].loadState(blobs[1])
-    other_cut = _group(v, t, 4, _slab_owner(len(v), cells, 4), precision)
+    other_cut = _group(v, t, 4, _slab_owner(len(v), cells, 4), precision, **kw)
     with pytest.raises(TetSimError, match="another mesh|other options"):
         other_cut[0].loadState(blobs[0])
-    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision)
+    mono = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision, **kw)
     with pytest.raises(TetSimError, match="another mesh|other options"):
         mono.loadState(blobs[0])
 

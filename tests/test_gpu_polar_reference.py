@@ -42,13 +42,13 @@ def glsl_golden():
     return g, cases
 
 
-@pytest.mark.parametrize("precision,gather", [("precise", False), ("fast", False), ("fast", True)])
+@pytest.mark.parametrize("precision,gather", [("precise", False), ("fast", False), ("fast", True), ("fast", "lean")])
 @pytest.mark.parametrize("name", ["lat4", "dragon", "dragon_grab", "lat4_drag", "hub", "lat12"])
 def test_device_tracks_the_reference_glsl(name, precision, gather, glsl_golden):
     g, cases = glsl_golden
     c, gc = cases[name], g["cases"][name]
     v, t = load_mesh(c["mesh"])
-    kw = dict(gather=True) if gather else {}
+    kw = dict(lean_state=True) if gather == "lean" else dict(gather=True) if gather else {}   # "lean": TETSIM_FLAG_LEAN_STATE (blocked, 92 B/tet)
     # reference-faithful switches: scatter-table quirk, hard-coded bounds, indexFromUV grab texel
     body = SoftBodyHIP(v, t, None, dict(c["params"]), solver="polar", precision=precision, ref_slot_table=True,
                        ref_fixed_bounds=True, ref_grab_texel=True, **kw)
@@ -59,14 +59,14 @@ def test_device_tracks_the_reference_glsl(name, precision, gather, glsl_golden):
         gv = load_f32(f"{name}_gpu_vel_{step}.f32").reshape(-1, 3)
         has_q = step in c.get("quatDumps", c["dumps"])
         tol = TOL[precision][name][step]
-        label = "polar %s%s vs reference GLSL %s @%d" % (precision, " gather" if gather else "", name, step)
+        label = "polar %s%s vs reference GLSL %s @%d" % (precision, " lean" if gather == "lean" else " gather" if gather else "", name, step)
         errs[step] = float(np.abs(body.pos - gp).max())
         within(label, errs[step], tol)
         within(label + " (vel)", np.abs(body.vel - gv).max(), 2.0 * tol / gc["dt"])
         q = body.quats            # local tet order == input order for an unpartitioned PRECISE/gather body
         if has_q:
             gq = load_f32(f"{name}_gpu_quat_{step}.f32").reshape(-1, 4)
-            if not (precision == "precise" or gather):   # the blocked formulation keeps its tets in tile order
+            if not (precision == "precise" or gather is True):   # the blocked formulation keeps its tets in tile order
                 q2 = np.empty_like(q); q2[body.localTets] = q; q = q2
             within(label + " (quat)", np.abs(q - gq).max(), max(50 * tol, 1e-5))
         assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-5

@@ -90,7 +90,7 @@ def test_vertex_normals_on_the_polar_path():
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("precision", ["precise", "fast"])
+@pytest.mark.parametrize("precision", ["precise", "fast", "fast-lean"])
 def test_polar_skinning_and_normals(precision):
     """Vertex-shader formula of SoftbodyGPU.js:429-440 evaluated on the device: positions from the (internally
     renumbered) particles, normals rotated by the quaternion of the vertex's tet (tile-ordered in FAST)."""
@@ -99,7 +99,7 @@ def test_polar_skinning_and_normals(precision):
     rng = np.random.default_rng(7)
     n0 = rng.standard_normal((len(vis), 3)).astype(np.float32)
     n0 /= np.linalg.norm(n0, axis=1, keepdims=True)
-    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision)
+    body = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision=precision.split("-")[0], lean_state=precision == "fast-lean")   # lean: the quaternions are recovered from the carried shape
     body.setVisualMesh(vis, n0)
     orc = OraclePJ(v, t, PP)
     dt = (1.0 / 60.0) / 20

@@ -15,6 +15,7 @@ PRECISE, FAST = 0, 1
 ORDER_ORIGINAL, ORDER_COLOURED, ORDER_CLUSTERED = 0, 1, 2
 FLAG_REF_SLOT_TABLE, FLAG_REF_FIXED_BOUNDS, FLAG_GATHER_FORMULATION, FLAG_CONSTANT_REST_SHAPE, FLAG_REF_GRAB_TEXEL, FLAG_DEEP_GHOSTS = 1, 2, 4, 8, 16, 32
 FLAG_REF_ROTATION_EXIT = 64
+FLAG_LEAN_STATE = 128
 K_TET, K_VERTEX, K_HALO, K_COUNT = 0, 1, 2, 3
 
 

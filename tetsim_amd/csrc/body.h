@@ -189,6 +189,10 @@ struct tetsim_body {
     bool halo_use_flags = true;       // TETSIM_HALO_SYNC (read when the body is created): false = "events", the older event-synchronised halo path
     bool halo_use_graph = true;       // TETSIM_HALO_GRAPH (likewise): false = the halo path stays eager
     bool fused = false;
+    // TETSIM_FLAG_LEAN_STATE (pj_blocked.hip: kModeLeanState): the substep neither reads nor writes pj.quat; it is recovered from the carried
+    // shape and this constant centred rest shape when somebody asks for it (ensure_quats)
+    float4 *rest0_a = nullptr, *rest0_b = nullptr, *rest0_c = nullptr;
+    bool quat_stale = false;          // substeps have been enqueued since pj.quat was last recovered
     // persistent frame kernel (pjb_frame_kernel): tetsim_step_n runs ONE launch per call; fused bodies of few enough tiles
     bool frame = false;
     uint32_t frame_epoch = 1;         // sequence number of the next call's first substep (DevParams::epoch), advanced by 65536 per parameter push
@@ -348,6 +352,7 @@ int ensure_prediction(tetsim_body* h, double dt);
 int read_float4_as_xyz(tetsim_body* h, const float4* src, uint32_t n, float* out);
 // ---- state read-back helpers (tetsim_state.hip)
 const float4* current_positions(tetsim_body* h);   // end-of-substep positions of either solver
+int ensure_quats(tetsim_body* h);                  // lean-state bodies: pj.quat brought up to date on h->stream (behind both queues' work); else nothing
 int ensure_index_map(tetsim_body* h);              // device copy of api2dev (pack / nearest kernels)
 
 // ---- construction (tetsim_create.hip)

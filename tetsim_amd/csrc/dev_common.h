@@ -57,6 +57,7 @@ struct PJBlk {
     float4* rest_a = nullptr;                // [nt] carried rest corners, 12 floats packed in 3 x 16 B:
     float4* rest_b = nullptr;                //      a = r0.xyz r1.x | b = r1.yz r2.xy | c = r2.z r3.xyz
     float4* rest_c = nullptr;
+    float* rest_c1 = nullptr;                // TETSIM_FLAG_LEAN_STATE: r2.z -- the record is r0 r1 r2 (a, b, c1: 36 B), r3 = -(r0 + r1 + r2), rest_c unused
     const float* vol = nullptr;              // [nt] rest volume (the averaging weight)
     float4* quat = nullptr;                  // [nt]
     const uint32_t* lc_range = nullptr;      // per tile slot: first | end << 16 into the tile's entry list
@@ -87,6 +88,7 @@ struct PJBlk {
     const float4* ghost2 = nullptr;
     uint32_t n_ghost1 = 0xffffffffu;
     bool lean = false;                       // TETSIM_FLAG_CONSTANT_REST_SHAPE: rest_a/b/c hold the centred rest shape, read-only
+    bool lean_state = false;                 // TETSIM_FLAG_LEAN_STATE: three carried corners, no quaternion in the substep (pj_blocked.hip: kModeLeanState)
     float rot_exit_w2 = 1.0e-18f;            // squared |omega| that ends a tet's correction iterations 2..9 (pj_math.inc; 1e-18 = the reference's 1e-9)
     uint32_t epoch = 0;                      // persistent frame kernels: first sequence number of this launch; 0 = DevParams::epoch (graph launches: tetsim_step_n)
     unsigned long long* trace = nullptr;     // development: 8 x u64 per tile (phase timestamps), TETSIM_DEBUG_TRACE
@@ -165,6 +167,8 @@ void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                        uint32_t* raise_word = nullptr, uint32_t* clear_word = nullptr);
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d);
+// TETSIM_FLAG_LEAN_STATE: d.quat <- the rotation between the constant centred rest shape (rest0_*) and the carried shape, next to what d.quat held
+void pjb_launch_recover_quats(hipStream_t s, const PJBlk& d, const float4* rest0_a, const float4* rest0_b, const float4* rest0_c);
 // n substeps of an unpartitioned fused-eligible body in ONE persistent launch (pjb_frame_kernel): every tile's workgroup stays
 // resident for the whole call.  block_tile[blocks]: the tile each block works on, -1 = none (the host places the tiles of a body
 // on one XCD that way); local: the exchange of partial sums only has to be coherent inside one XCD's L2 (valid with such a
@@ -180,9 +184,10 @@ void pjq_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* 
 void pjq_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjq_launch_vertex(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 uint32_t pjq_frame_capacity(uint32_t* compute_units);              // workgroups of pjq_frame_kernel one CU keeps resident (0 = query failed)
-uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units);   // workgroups of the frame kernel one CU keeps resident (0 = query failed)
+uint32_t pjb_frame_capacity(int mode, uint32_t* compute_units);    // workgroups of the frame kernel one CU keeps resident (0 = query failed); mode: pjb_mode()
 // waves of the self-waiting particle kernel / workgroups of the self-waiting halo-side tiles that may wait at once on the current device
-void pjb_wait_capacity(bool lean, uint32_t* vertex_waves, uint32_t* hwait_blocks);
+void pjb_wait_capacity(int mode, uint32_t* vertex_waves, uint32_t* hwait_blocks);
+inline int pjb_mode(const PJBlk& d) { return d.lean ? 1 : d.lean_state ? 2 : 0; }   // 0 carried shape + quaternion, 1 constant rest shape, 2 lean state
 uint32_t pjb_probe_xcd(hipStream_t s, uint32_t blocks);            // 8 if block i of a grid runs on XCD i % 8, else 0
 // Cross-queue hand-over of partitioned bodies (pj_blocked.hip): `flag` is a binary semaphore in device memory -- signal stores
 // 1 behind the producer kernel, wait spins until it is non-zero in front of the consumer kernel and clears it.  No per-launch

@@ -23,6 +23,12 @@ __device__ __forceinline__ void store_wt(float4* base, uint32_t index, const flo
     __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, static_cast<int>(index * 16u), 0, 0x11);  // aux: sc0 | sc1
 }
 
+// ... one float (the ninth of a lean-state tet record)
+__device__ __forceinline__ void store_wt1(float* base, uint32_t index, float v) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, static_cast<int>(index * 4u), 0, 0x11);  // aux: sc0 | sc1
+}
+
 // Exchange between workgroups that share ONE XCD (pj_blocked.hip: the frame kernel's tile partial sums when the host has placed a
 // body's tiles on one XCD): the store is a plain one -- the CU's L1 writes through, the line stays in the XCD's L2 --, the load
 // carries agent scope (sc1): it misses the L1 and is served by that L2.  Measured on MI355X (profiles/r03_frame_kernel.txt): bit-equal

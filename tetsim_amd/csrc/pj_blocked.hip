@@ -109,8 +109,23 @@ constexpr uint32_t kTile = kBlockTile;   // tets (= threads) per workgroup tile;
 // kHaloWait: the halo-side tiles of a peer-to-peer body do their queue's hand-overs themselves (pjb_tet_kernel_x<.., TetHwait>): the first wave of
 // every tile looks at V and at the neighbours' "arrived" words -- after the record loads are out, before the positions are asked for --
 // and every position comes from the memory side: the kernel may have started before the data it waits for was written.
+// TETSIM_FLAG_LEAN_STATE: the carried shape is relative to its own centroid, its fourth corner is minus the sum of the other three
+// (one association for every kernel of this unit: the per-substep, fused and persistent kernels agree bit for bit)
+__device__ __forceinline__ f3 lean_fourth_corner(const f3 r[4]) {
+    return F3(-((r[0].x + r[1].x) + r[2].x), -((r[0].y + r[1].y) + r[2].y), -((r[0].z + r[1].z) + r[2].z));
+}
 struct PJHaloWait { const PJPeerSync* w; const uint32_t* vflag; uint32_t* error; uint32_t timeout_ms; const float4* ghosts; };
-template <bool kLean, bool kFused, bool kAlt = false, bool kHaloWait = false>
+// kMode: what a tet's record in HBM is (blk_mode(): a property of the body, a compile-time choice of the kernel)
+//   0  the reference's formulation: the carried shape (48 B in, 48 B out) and the quaternion (16 B in, 16 B out) -- 148 B per tet
+//   1  TETSIM_FLAG_CONSTANT_REST_SHAPE (kLean): the constant rest shape in, the quaternion in and out -- 100 B per tet
+//   2  TETSIM_FLAG_LEAN_STATE: THREE corners of the carried shape in and out (36 B each way: the shape is relative to its own
+//      centroid, so the fourth corner is minus the sum of the other three) and NO quaternion -- in FAST arithmetic the substep's
+//      rotation `rel` is normalize(q) of this substep alone (pj_math.inc), the accumulated quaternion is pure output, and the carried
+//      shape IS the accumulated rotation applied to the rest shape: tetsim_read_quats / the visual mesh / checkpoints recover it
+//      from there when they are asked (skin_kernels.hip: pjb_recover_quat_kernel) -- 92 B per tet
+constexpr int kModeCarried = 0, kModeConstantRest = 1, kModeLeanState = 2;
+inline int blk_mode(const PJBlk& d) { return pjb_mode(d); }
+template <int kMode, bool kFused, bool kAlt = false, bool kHaloWait = false>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
                                              [[maybe_unused]] const PJHaloWait* hw = nullptr) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
@@ -119,6 +134,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     __shared__ float s_gz[4 * kTile];
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
+    constexpr bool kLean = kMode == kModeConstantRest;
     const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
@@ -157,8 +173,10 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
     }
     const uchar4 li = d.tet_lidx[e];
-    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
-    const float4 q_old = d.quat[e];
+    const float4 ra = d.rest_a[e], rb = d.rest_b[e];
+    float4 rc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q_old = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if constexpr (kMode == kModeLeanState) rc.x = d.rest_c1[e];   // (r2.z: the ninth float)
+    else { rc = d.rest_c[e]; q_old = d.quat[e]; }
     const float V = d.vol[e];
     const uint2 ent_row = d.lc_ent[e];
     float4 pos_stage;
@@ -233,6 +251,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         cur[0] = xyz(s_pos[li.x]); cur[1] = xyz(s_pos[li.y]); cur[2] = xyz(s_pos[li.z]); cur[3] = xyz(s_pos[li.w]);
         rest[0] = F3(ra.x, ra.y, ra.z); rest[1] = F3(ra.w, rb.x, rb.y);
         rest[2] = F3(rb.z, rb.w, rc.x); rest[3] = F3(rc.y, rc.z, rc.w);
+        if constexpr (kMode == kModeLeanState) rest[3] = lean_fourth_corner(rest);
         float4 q_new;
         // The carried shape lives in HBM relative to its own centroid (see pj_solve_tet): `goal` comes back centred, the
         // world-space goal is goal + cc.  Same bytes as the reference's world-space shape, 21 instructions fewer per tet
@@ -248,11 +267,12 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             s_gy[k * kTile + tid] = fmaf(goal[k].y, V, vcc.y);
             s_gz[k * kTile + tid] = fmaf(goal[k].z, V, vcc.z);
         }
-        store_wt(d.quat, e, q_new);
+        if constexpr (kMode != kModeLeanState) store_wt(d.quat, e, q_new);
         if (!kLean && TETSIM_DBG_STORE_REST) {  // constant-rest-shape bodies never write the shape back
             store_wt(d.rest_a, e, make_float4(goal[0].x, goal[0].y, goal[0].z, goal[1].x));
             store_wt(d.rest_b, e, make_float4(goal[1].y, goal[1].z, goal[2].x, goal[2].y));
-            store_wt(d.rest_c, e, make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
+            if constexpr (kMode == kModeLeanState) store_wt1(d.rest_c1, e, goal[2].z);
+            else store_wt(d.rest_c, e, make_float4(goal[2].z, goal[3].x, goal[3].y, goal[3].z));
         }
     }
     TETSIM_STAMP(4);  // stores issued
@@ -295,11 +315,15 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
 
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                         uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<false, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    pjb_tet_body<kModeCarried, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_constant_rest(PJBlk d, uint32_t tile_first, uint32_t tile_count,
                                                                       uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
-    pjb_tet_body<true, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+    pjb_tet_body<kModeConstantRest, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+}
+__global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_lean(PJBlk d, uint32_t tile_first, uint32_t tile_count,
+                                                             uint32_t tiles_per_xcd TETSIM_DBG_PARAM) {
+    pjb_tet_body<kModeLeanState, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
 }
 // The variants partitioned and mid-sized bodies need are ONE kernel template over what happens around the tile's solve:
 //   TetRaise  raises a hand-over word as it STARTS (partitioned bodies): a kernel starts only when everything in front
@@ -326,19 +350,19 @@ struct TetRaise { uint32_t* sig; uint32_t* clear; };
 struct TetAlt { uint32_t unused; };
 struct TetHwait { PJPeerSync w; const uint32_t* vflag; uint32_t* error; uint32_t timeout_ms; const float4* ghosts; };
 struct TetFused { uint32_t unused; };
-template <bool kLean, class Extra>
+template <int kMode, class Extra>
 __global__ __launch_bounds__(kTile, 2) void pjb_tet_kernel_x(PJBlk d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd, Extra x TETSIM_DBG_PARAM) {
     if constexpr (std::is_same_v<Extra, TetRaise>) {
         clear_then_raise(x.clear, x.sig);
-        pjb_tet_body<kLean, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+        pjb_tet_body<kMode, false>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
     } else if constexpr (std::is_same_v<Extra, TetAlt>) {
-        pjb_tet_body<kLean, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+        pjb_tet_body<kMode, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
     } else if constexpr (std::is_same_v<Extra, TetHwait>) {
         if (blockIdx.x == 0 && threadIdx.x < x.w.n_raise) __hip_atomic_store(x.w.raise[threadIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const PJHaloWait hw = {&x.w, x.vflag, x.error, x.timeout_ms, x.ghosts};
-        pjb_tet_body<kLean, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
+        pjb_tet_body<kMode, false, false, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG, &hw);
     } else {
-        pjb_tet_body<kLean, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
+        pjb_tet_body<kMode, true>(d, tile_first, tile_count, tiles_per_xcd TETSIM_DBG_ARG);
     }
 }
 // one launcher for all of them: the kernel by (constant rest shape?, variant), its own begin / end events on request
@@ -346,7 +370,8 @@ template <class Extra>
 void launch_tet_x(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t tile_count, const Extra& x, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if (tile_count == 0) return;
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_kernel_x<true, Extra> : pjb_tet_kernel_x<false, Extra>;
+    const int mode = blk_mode(d);
+    auto* kernel = mode == kModeConstantRest ? pjb_tet_kernel_x<kModeConstantRest, Extra> : mode == kModeLeanState ? pjb_tet_kernel_x<kModeLeanState, Extra> : pjb_tet_kernel_x<kModeCarried, Extra>;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd, x TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd, x TETSIM_DBG_LAUNCH);
 }
@@ -374,7 +399,7 @@ void launch_tet_x(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t t
 // stores (the L1 writes through) and agent-scope loads (miss the L1, served by the L2) -- dev_store.h.  !kLocal: write-through
 // stores and cache-bypassing loads, coherent at the memory side (any placement).
 constexpr int kFrameIters = TETSIM_LAB_FRAME_ITERS;   // the product's compile-time constant, 9 (tools/mutation_check.sh mutates it for both kernels)
-template <bool kLean, bool kLocal>
+template <int kMode, bool kLocal>
 __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
                                                uint32_t* const err, const uint32_t timeout_ms) {
     __shared__ float4 s_pos[kTile];
@@ -383,6 +408,7 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
     __shared__ float s_gz[4 * kTile];
     __shared__ uint2 s_ent[kTile];
 
+    constexpr bool kLean = kMode == kModeConstantRest;
     const int32_t bt = block_tile[blockIdx.x];
     if (bt < 0) return;   // (a block that only pads the grid so that the others land on the intended XCDs)
     const uint32_t b = static_cast<uint32_t>(bt);
@@ -403,8 +429,10 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
         for (uint32_t j = 0; j < 9u; j++) src[j] = (has_slot && j < maxsrc) ? col[static_cast<size_t>(j) * d.ns_pad] : 0xffffffffu;
     }
     const uchar4 li = d.tet_lidx[e];
-    const float4 ra = d.rest_a[e], rb = d.rest_b[e], rc = d.rest_c[e];
-    float4 q = d.quat[e];
+    const float4 ra = d.rest_a[e], rb = d.rest_b[e];
+    float4 rc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if constexpr (kMode == kModeLeanState) rc.x = d.rest_c1[e];   // (lean state: three corners, no quaternion -- pjb_tet_body)
+    else { rc = d.rest_c[e]; q = d.quat[e]; }
     const float V = d.vol[e];
     s_ent[tid] = has_tet ? d.lc_ent[e] : make_uint2(0u, 0u);
     f3 rest[4];
@@ -488,10 +516,11 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
             cur[0] = xyz(s_pos[li.x]); cur[1] = xyz(s_pos[li.y]); cur[2] = xyz(s_pos[li.z]); cur[3] = xyz(s_pos[li.w]);
 #pragma unroll
             for (int k = 0; k < 4; k++) r[k] = rest[k];
+            if constexpr (kMode == kModeLeanState) r[3] = lean_fourth_corner(rest);
             float4 q_new;
             f3 cc;
             pj_solve_tet(cur, r, q, q_new, goal, kFrameIters, true, kLean, !kLean, &cc, d.rot_exit_w2);
-            q = q_new;
+            if constexpr (kMode != kModeLeanState) q = q_new;
             if (!kLean) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) rest[k] = goal[k];   // the carried shape stays in registers
@@ -543,23 +572,26 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
         store_wt(d.pos_pred, vid, make_float4(o.pred.x, o.pred.y, o.pred.z, 0.0f));
     }
     if (has_tet) {
-        store_wt(d.quat, e, q);
+        if constexpr (kMode != kModeLeanState) store_wt(d.quat, e, q);
         if (!kLean) {
             store_wt(d.rest_a, e, make_float4(rest[0].x, rest[0].y, rest[0].z, rest[1].x));
             store_wt(d.rest_b, e, make_float4(rest[1].y, rest[1].z, rest[2].x, rest[2].y));
-            store_wt(d.rest_c, e, make_float4(rest[2].z, rest[3].x, rest[3].y, rest[3].z));
+            if constexpr (kMode == kModeLeanState) store_wt1(d.rest_c1, e, rest[2].z);
+            else store_wt(d.rest_c, e, make_float4(rest[2].z, rest[3].x, rest[3].y, rest[3].z));
         }
     }
 }
-#define TETSIM_FRAME_KERNEL(name, lean, local)                                                                                         \
+#define TETSIM_FRAME_KERNEL(name, mode, local)                                                                                         \
     __global__ __launch_bounds__(kTile, 2) void name(PJBlk d, uint32_t n, const int32_t* block_tile, float4* pbuf0, float4* pbuf1, uint32_t* err, \
                                                      uint32_t timeout_ms) {                                                            \
-        pjb_frame_body<lean, local>(d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);                                                  \
+        pjb_frame_body<mode, local>(d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);                                                  \
     }
-TETSIM_FRAME_KERNEL(pjb_frame_kernel, false, false)
-TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest, true, false)
-TETSIM_FRAME_KERNEL(pjb_frame_kernel_local, false, true)
-TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest_local, true, true)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel, kModeCarried, false)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest, kModeConstantRest, false)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_lean, kModeLeanState, false)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_local, kModeCarried, true)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest_local, kModeConstantRest, true)
+TETSIM_FRAME_KERNEL(pjb_frame_kernel_lean_local, kModeLeanState, true)
 #undef TETSIM_FRAME_KERNEL
 // which XCD runs block i of a grid: the dispatcher hands consecutive workgroups to consecutive XCDs (round-robin), which the
 // host verifies with this kernel before it relies on it (hardware register XCC_ID)
@@ -725,6 +757,49 @@ __global__ void pjb_signal_kernel(uint32_t* flag, uint32_t* clear) {
     }
 }
 
+// TETSIM_FLAG_LEAN_STATE: the accumulated quaternion of every tet, recovered from its carried shape when somebody asks for it
+// (tetsim_read_quats, the visual mesh, a checkpoint) instead of being read, multiplied up and written back by every substep.
+// The reference accumulates q <- normalize(rot (x) q) (SoftbodyGPU.js:181) and rotates the carried shape by the same `rot`
+// (:253-262), so in exact arithmetic carried_k = R(q) rest0_k for the centred corners: with S0 = [s0 s1 s2] and C = [c0 c1 c2]
+// (the fourth corner is minus their sum on both sides) R = C S0^-1 -- formed in f64, turned into a quaternion by the
+// largest-diagonal rule, normalised, and given the sign that keeps it next to the quaternion this array held before (q and -q are
+// the same rotation; the reference's product never jumps).  Differs from the multiplied-up quaternion by the rounding the two
+// have gathered on their separate ways (1e-6 after hundreds of substeps, tests/test_gpu_lean_state.py).  A degenerate tet
+// (det S0 = 6V/4 = 0: the reference's zero-volume case) keeps what the array held.
+__global__ __launch_bounds__(256) void pjb_recover_quat_kernel(const float4* __restrict__ r0a, const float4* __restrict__ r0b, const float4* __restrict__ r0c,
+                                                              const float4* __restrict__ ca, const float4* __restrict__ cb, const float* __restrict__ cc1,
+                                                              float4* __restrict__ quat, uint32_t nt) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= nt) return;
+    const float4 a0 = r0a[e], b0 = r0b[e], c0 = r0c[e], a = ca[e], b = cb[e];
+    const float c1 = cc1[e];
+    const float4 qp = quat[e];
+    // columns of S0 and C
+    const double s[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x}};
+    const double c[3][3] = {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c1}};
+    // inverse of S0 (columns s[0], s[1], s[2]) through the cross products of its columns: rows of the inverse are (s1 x s2, s2 x s0, s0 x s1) / det
+    auto cr = [](const double* u, const double* v, double* o) { o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0]; };
+    double inv[3][3];
+    cr(s[1], s[2], inv[0]); cr(s[2], s[0], inv[1]); cr(s[0], s[1], inv[2]);
+    const double det = s[0][0] * inv[0][0] + s[0][1] * inv[0][1] + s[0][2] * inv[0][2];
+    if (!(fabs(det) > 1.0e-300)) return;
+    const double rd = 1.0 / det;
+    double R[3][3];   // R[i][j] = sum_k c[k][i] * inv[k][j] / det
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i][j] = (c[0][i] * inv[0][j] + c[1][i] * inv[1][j] + c[2][i] * inv[2][j]) * rd;
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    double x, y, z, w;
+    if (tr > 0.0) { w = tr + 1.0; x = R[2][1] - R[1][2]; y = R[0][2] - R[2][0]; z = R[1][0] - R[0][1]; }
+    else if (R[0][0] >= R[1][1] && R[0][0] >= R[2][2]) { x = 1.0 + R[0][0] - R[1][1] - R[2][2]; y = R[0][1] + R[1][0]; z = R[0][2] + R[2][0]; w = R[2][1] - R[1][2]; }
+    else if (R[1][1] >= R[2][2]) { y = 1.0 + R[1][1] - R[0][0] - R[2][2]; x = R[0][1] + R[1][0]; z = R[1][2] + R[2][1]; w = R[0][2] - R[2][0]; }
+    else { z = 1.0 + R[2][2] - R[0][0] - R[1][1]; x = R[0][2] + R[2][0]; y = R[1][2] + R[2][1]; w = R[1][0] - R[0][1]; }
+    const double n2 = x * x + y * y + z * z + w * w;
+    if (!(n2 > 0.0) || !(n2 < 1.0e300)) return;   // (NaN / inf shape: a body that has blown up keeps its last quaternion)
+    double k = 1.0 / sqrt(n2);
+    if (x * qp.x + y * qp.y + z * qp.z + w * qp.w < 0.0) k = -k;
+    quat[e] = make_float4(static_cast<float>(x * k), static_cast<float>(y * k), static_cast<float>(z * k), static_cast<float>(w * k));
+}
+
 __global__ __launch_bounds__(256) void pjb_repredict_kernel(PJBlk d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
     if (v >= d.nv_owned) return;
@@ -739,7 +814,8 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     if (tile_count == 0) return;   // (callers with a word to raise or clear check this themselves)
     if (raise_word || clear_word) return launch_tet_x(s, d, tile_first, tile_count, TetRaise{raise_word, clear_word}, e0, e1);
     const uint32_t per_xcd = (tile_count + 7u) / 8u;
-    auto* kernel = d.lean ? pjb_tet_kernel_constant_rest : pjb_tet_kernel;
+    const int mode = blk_mode(d);
+    auto* kernel = mode == kModeConstantRest ? pjb_tet_kernel_constant_rest : mode == kModeLeanState ? pjb_tet_kernel_lean : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
@@ -747,21 +823,23 @@ void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
                       uint32_t* err, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0 || n == 0 || blocks == 0) return;
-    auto* kernel = local ? (d.lean ? pjb_frame_kernel_constant_rest_local : pjb_frame_kernel_local) : (d.lean ? pjb_frame_kernel_constant_rest : pjb_frame_kernel);
+    const int mode = blk_mode(d);
+    auto* kernel = local ? (mode == kModeConstantRest ? pjb_frame_kernel_constant_rest_local : mode == kModeLeanState ? pjb_frame_kernel_lean_local : pjb_frame_kernel_local)
+                         : (mode == kModeConstantRest ? pjb_frame_kernel_constant_rest : mode == kModeLeanState ? pjb_frame_kernel_lean : pjb_frame_kernel);
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
     else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
 }
-uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
+uint32_t pjb_frame_capacity(int mode, uint32_t* compute_units) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     // the smaller answer of the two placements' kernels: which one a body launches is decided after this query (a body too large for the
     // one-XCD placement takes the other), and their register counts need not stay equal
     int per_cu_any = 0;
-    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_constant_rest_local, static_cast<int>(kTile), 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pjb_frame_kernel_local, static_cast<int>(kTile), 0);
-    const hipError_t e2 = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, pjb_frame_kernel_constant_rest, static_cast<int>(kTile), 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, pjb_frame_kernel, static_cast<int>(kTile), 0);
+    auto* k_local = mode == kModeConstantRest ? pjb_frame_kernel_constant_rest_local : mode == kModeLeanState ? pjb_frame_kernel_lean_local : pjb_frame_kernel_local;
+    auto* k_any = mode == kModeConstantRest ? pjb_frame_kernel_constant_rest : mode == kModeLeanState ? pjb_frame_kernel_lean : pjb_frame_kernel;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_local, static_cast<int>(kTile), 0);
+    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_any, k_any, static_cast<int>(kTile), 0);
     if (e != hipSuccess || e2 != hipSuccess || per_cu <= 0 || per_cu_any <= 0) return 0;
     per_cu = std::min(per_cu, per_cu_any);
     if (compute_units) *compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -771,14 +849,14 @@ uint32_t pjb_frame_capacity(bool lean, uint32_t* compute_units) {
 // at a word keeps its slot while it waits, and the kernel that raises the word needs slots too: the waiting kernels may hold HALF of
 // what the device keeps resident of pjb_vertex_kernel_await (one-wave workgroups) and a QUARTER of what it keeps of
 // the TetHwait tet kernel -- measured limits, not constants: a compute partition with fewer CUs (or a kernel that grew) shrinks them.
-void pjb_wait_capacity(bool lean, uint32_t* vertex_waves, uint32_t* hwait_blocks) {
+void pjb_wait_capacity(int mode, uint32_t* vertex_waves, uint32_t* hwait_blocks) {
     *vertex_waves = 0; *hwait_blocks = 0;
     int per_cu_v = 0, per_cu_t = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_v, pjb_vertex_kernel_await, 64, 0) != hipSuccess) per_cu_v = 0;
-    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_x<true, TetHwait>, static_cast<int>(kTile), 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pjb_tet_kernel_x<false, TetHwait>, static_cast<int>(kTile), 0);
+    auto* k_hwait = mode == kModeConstantRest ? pjb_tet_kernel_x<kModeConstantRest, TetHwait> : mode == kModeLeanState ? pjb_tet_kernel_x<kModeLeanState, TetHwait> : pjb_tet_kernel_x<kModeCarried, TetHwait>;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, k_hwait, static_cast<int>(kTile), 0);
     if (e != hipSuccess) per_cu_t = 0;
     const uint32_t cus = static_cast<uint32_t>(std::max(prop.multiProcessorCount, 0));
     *vertex_waves = static_cast<uint32_t>(std::max(per_cu_v, 0)) * cus / 2u;
@@ -824,6 +902,10 @@ void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t c
     }
     if (e0) hipExtLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, e0, e1, 0, d, first, count);
     else hipLaunchKernelGGL(pjb_vertex_kernel, dim3((count + 63u) / 64u), dim3(64), 0, s, d, first, count);
+}
+void pjb_launch_recover_quats(hipStream_t s, const PJBlk& d, const float4* rest0_a, const float4* rest0_b, const float4* rest0_c) {
+    if (d.nt == 0 || !d.lean_state) return;
+    hipLaunchKernelGGL(pjb_recover_quat_kernel, dim3((d.nt + 255u) / 256u), dim3(256), 0, s, rest0_a, rest0_b, rest0_c, d.rest_a, d.rest_b, d.rest_c1, d.quat, d.nt);
 }
 void pjb_launch_repredict(hipStream_t s, const PJBlk& d) {
     if (d.nv_owned == 0) return;

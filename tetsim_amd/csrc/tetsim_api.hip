@@ -25,10 +25,11 @@ int group_result(tetsim_body* const* hs, uint32_t count, int rc) {
     if (rc == TETSIM_OK || !hs) return rc;
     for (uint32_t i = 0; i < count; i++)
         if (hs[i] && !hs[i]->err.empty()) { g_create_error = "partition " + std::to_string(i) + ": " + hs[i]->err; return rc; }
-    g_create_error = "bad argument";
+    if (g_create_error.empty()) g_create_error = "bad argument";   // (a message fail(nullptr, ...) stored since group_begin -- "handles[i] must be ..." for a null member -- stays)
     return rc;
 }
 void group_begin(tetsim_body* const* hs, uint32_t count) {
+    g_create_error.clear();
     if (hs) for (uint32_t i = 0; i < count; i++) if (hs[i]) hs[i]->err.clear();
 }
 
@@ -117,6 +118,7 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
     HIPCHK(h, hipSetDevice(h->opt.device));  // group stepping walks over handles that may live on different devices
     h->final_ghosts_fresh = false;           // (every stepping path comes through here: the ghosts' end-of-substep positions fetched for the visual mesh are stale)
+    h->quat_stale = true;                    // (... and a lean-state body's quaternion array: ensure_quats)
     if (reuse_ok && h->params_known && !h->comm_stream && !h->partitioned) {   // (a halo queue keeps a copy of its own: always refreshed)
         // A host that keeps the reference's loop (main.js:79-84: simulate(dt, physicsParams) per substep) sends the same numbers again
         // and again: the copy and its event were most of what such a call cost (22.5 -> 7.8 us per tetsim_step on the Dragon,
@@ -511,6 +513,10 @@ int create_common(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
     if (o.device < 0 || o.device >= ndev) return fail(nullptr, TETSIM_ENODEVICE, "device ordinal out of range");
     if ((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && o.solver != TETSIM_SOLVER_POLAR_JACOBI)
         return fail(nullptr, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE applies to TETSIM_SOLVER_POLAR_JACOBI only");
+    if ((o.flags & TETSIM_FLAG_LEAN_STATE) && o.solver != TETSIM_SOLVER_POLAR_JACOBI)
+        return fail(nullptr, TETSIM_EINVAL, "TETSIM_FLAG_LEAN_STATE applies to TETSIM_SOLVER_POLAR_JACOBI only");
+    if ((o.flags & TETSIM_FLAG_LEAN_STATE) && (o.flags & (TETSIM_FLAG_CONSTANT_REST_SHAPE | TETSIM_FLAG_DEEP_GHOSTS)))
+        return fail(nullptr, TETSIM_EINVAL, "TETSIM_FLAG_LEAN_STATE excludes TETSIM_FLAG_CONSTANT_REST_SHAPE and TETSIM_FLAG_DEEP_GHOSTS");
 
     tetsim_body* h = new tetsim_body();
     h->opt = o;

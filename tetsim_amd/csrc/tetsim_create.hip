@@ -123,6 +123,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     }
     if ((rc = upload(h, d.pos_pred, pos))) return rc;
     if ((rc = upload(h, d.pos_final, pos))) return rc;
+    h->final_ghosts_fresh = true;   // (pos_final's ghost range holds the rest positions: a fresh partition can skin its visual mesh -- SoftBodyHIP.js does, in its constructor)
     HIPCHK(h, hipMemset(d.vel, 0, std::max<size_t>(nvl, 1) * sizeof(float4)));
 
     // the weight the reference's P4 writes into elems.w: 1.0 / texture(invRestVolume).x, in f32
@@ -135,6 +136,9 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
     h->blocked = h->fast && !(o.flags & TETSIM_FLAG_GATHER_FORMULATION);
     if ((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && !h->blocked)
         return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_CONSTANT_REST_SHAPE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
+    if ((o.flags & TETSIM_FLAG_LEAN_STATE) && !h->blocked)
+        return fail(h, TETSIM_EINVAL, "TETSIM_FLAG_LEAN_STATE needs POLAR_JACOBI + TETSIM_FAST without TETSIM_FLAG_GATHER_FORMULATION");
+    const bool lean_state = (o.flags & TETSIM_FLAG_LEAN_STATE) != 0;
     if (h->blocked) {
         BlockPlan B;
         // partitions: the tets that touch a boundary or a ghost particle get tiles of their own (class 1), and so do the second-layer
@@ -159,7 +163,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         // at most (another body's kernels may hold slots too).  TETSIM_QUAD=0 keeps the 256-tet tiles (development A/B).
         static const bool allow_quad = [] { const char* e = getenv("TETSIM_QUAD"); return !(e && e[0] == '0'); }();
         uint32_t quad_cus = 0, quad_per_cu = 0;
-        bool quad = allow_quad && !h->partitioned && !(o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) && ntl > 0 && nvo == nvl;
+        bool quad = allow_quad && !h->partitioned && !(o.flags & (TETSIM_FLAG_CONSTANT_REST_SHAPE | TETSIM_FLAG_LEAN_STATE)) && ntl > 0 && nvo == nvl;
         if (quad) {
             quad_per_cu = pjq_frame_capacity(&quad_cus);
             quad = quad_per_cu != 0u && (static_cast<uint64_t>(ntl) + kQuadTile - 1u) / kQuadTile <= static_cast<uint64_t>(quad_per_cu) * quad_cus / 2u;
@@ -190,12 +194,13 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             // loses 1.7 us at +20 us, so there it stays off.  TETSIM_HALO_FOLD_WAIT=0 / 1: never / also with RCCL (development A/B).
             const char* fw = getenv("TETSIM_HALO_FOLD_WAIT");
             h->fold_possible = !(fw && fw[0] == '0') && h->partitioned && B.num_interior_blocks > 0 && B.num_interior_blocks < B.num_blocks && nvo > nvb;
-            if (h->fold_possible) pjb_wait_capacity((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0, &h->fold_wave_limit, &h->fold_tile_limit);
+            if (h->fold_possible) pjb_wait_capacity((o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) ? 1 : lean_state ? 2 : 0, &h->fold_wave_limit, &h->fold_tile_limit);
             h->fold_wait = h->fold_possible && fw && fw[0] == '1';
             h->fold_halo = h->fold_wait;   // (RCCL bodies: only when forced; the peer-to-peer connection switches both on)
         }
         k.pos_pred = d.pos_pred; k.pos_final = d.pos_final; k.vel = d.vel; k.params = h->d_params;
         k.lean = (o.flags & TETSIM_FLAG_CONSTANT_REST_SHAPE) != 0;
+        k.lean_state = lean_state;
         k.rot_exit_w2 = d.rot_exit_w2;
         uint32_t *bto, *bvo, *lcr, *vpe;
         int32_t* bv;
@@ -211,7 +216,12 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = dev_alloc(h, &lidx, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.rest_a, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.rest_b, ntl))) return rc;
-        if ((rc = dev_alloc(h, &k.rest_c, ntl))) return rc;
+        if (lean_state) {   // three carried corners (a, b, c1); the constant rest shape stays beside them for the quaternion's recovery
+            if ((rc = dev_alloc(h, &k.rest_c1, ntl))) return rc;
+            if ((rc = dev_alloc(h, &h->rest0_a, ntl))) return rc;
+            if ((rc = dev_alloc(h, &h->rest0_b, ntl))) return rc;
+            if ((rc = dev_alloc(h, &h->rest0_c, ntl))) return rc;
+        } else if ((rc = dev_alloc(h, &k.rest_c, ntl))) return rc;
         if ((rc = dev_alloc(h, &vol, ntl))) return rc;
         if ((rc = dev_alloc(h, &k.quat, ntl))) return rc;
         if ((rc = dev_alloc(h, &lcr, nslots))) return rc;
@@ -309,7 +319,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             // through the memory side.  Either way at most half the resident workgroups the device offers are used: another body's
             // kernels may hold slots too, and a waiting tile keeps its slot.
             uint32_t cus = 0;
-            const uint32_t per_cu = !allow_frame ? 0u : h->quad ? pjq_frame_capacity(&cus) : pjb_frame_capacity(k.lean, &cus);
+            const uint32_t per_cu = !allow_frame ? 0u : h->quad ? pjq_frame_capacity(&cus) : pjb_frame_capacity(pjb_mode(k), &cus);
             const uint32_t nbk = B.num_blocks;
             std::vector<int32_t> block_tile;
             // Up to HALF the device's resident workgroups two such bodies fit side by side whatever the dispatcher does.  A body that
@@ -377,7 +387,14 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         if ((rc = upload(h, lidx, lidxh))) return rc;
         if ((rc = upload(h, k.rest_a, ra))) return rc;
         if ((rc = upload(h, k.rest_b, rb))) return rc;
-        if ((rc = upload(h, k.rest_c, rcv))) return rc;
+        if (lean_state) {
+            std::vector<float> rc1(ntl);
+            for (uint32_t i = 0; i < ntl; i++) rc1[i] = rcv[i].x;
+            if ((rc = upload(h, k.rest_c1, rc1))) return rc;
+            if ((rc = upload(h, h->rest0_a, ra))) return rc;
+            if ((rc = upload(h, h->rest0_b, rb))) return rc;
+            if ((rc = upload(h, h->rest0_c, rcv))) return rc;
+        } else if ((rc = upload(h, k.rest_c, rcv))) return rc;
         if ((rc = upload(h, vol, volh))) return rc;
         if ((rc = upload(h, k.quat, quat))) return rc;
         if ((rc = upload(h, lcr, B.lc_range))) return rc;

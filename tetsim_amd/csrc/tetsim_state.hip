@@ -1,11 +1,25 @@
 // tetsim_state.hip -- C ABI, part 2 (include/tetsim.h): reading the solver's state back (copying and pinned zero-copy reads),
 // checkpoint / resume of the complete state, and the small getters (plans, orders, inverse masses).  See body.h.
+#include <thread>
+
 #include "body.h"
 
 using namespace tetsim;
 
 namespace tetsim {
 const float4* current_positions(tetsim_body* h) { return h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI ? h->pj.pos_final : h->nh.pos; }
+// TETSIM_FLAG_LEAN_STATE: the accumulated quaternions are not part of the substep (pj_blocked.hip); whoever reads pj.quat calls this first.
+// The halo queue's tiles write carried shapes too, so both queues are drained (a read-out path: once per frame at most).
+int ensure_quats(tetsim_body* h) {
+    if (!h->blocked || !h->blk.lean_state || !h->quat_stale) return 0;
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    pjb_launch_recover_quats(h->stream, h->blk, h->rest0_a, h->rest0_b, h->rest0_c);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->quat_stale = false;
+    return 0;
+}
 int ensure_index_map(tetsim_body* h) {  // internal Morton numbering -> API numbering, on the device
     if (h->d_api2dev || h->api2dev.empty()) return 0;
     int rc = dev_alloc(h, &h->d_api2dev, h->api2dev.size());
@@ -55,6 +69,7 @@ int tetsim_read_quats(tetsim_handle h, float* out) {
     if (!h || !out) return fail(h, TETSIM_EINVAL, "null argument");
     if (h->opt.solver != TETSIM_SOLVER_POLAR_JACOBI) return fail(h, TETSIM_ESTATE, "quaternions exist only for POLAR_JACOBI");
     HIPCHK(h, hipSetDevice(h->opt.device));
+    if (int rc = ensure_quats(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     if (h->pj.nt) HIPCHK(h, hipMemcpy(out, h->pj.quat, h->pj.nt * sizeof(float4), hipMemcpyDeviceToHost));
@@ -67,6 +82,7 @@ int tetsim_read_quats_pinned(tetsim_handle h, const float** out) {
     const size_t n = h->pj.nt;
     if (!h->pinned_quat) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pinned_quat), std::max<size_t>(n, 1) * sizeof(float4), hipHostMallocDefault));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));  // ghost tiles write their quaternions on the halo stream
+    if (int rc = ensure_quats(h)) return rc;
     if (n) HIPCHK(h, hipMemcpyAsync(h->pinned_quat, h->pj.quat, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *out = h->pinned_quat;
@@ -112,7 +128,11 @@ void state_sections(tetsim_body* h, std::vector<StateSection>& v) {
         v.push_back({h->pj.pos_pred, nvl * sizeof(float4)});
         v.push_back({h->pj.quat, nt * sizeof(float4)});
         if (h->blocked) {
-            if (!h->blk.lean) {  // constant-rest-shape bodies carry no shape state
+            if (h->blk.lean_state) {  // three corners (the quaternion section above is brought up to date before a save: ensure_quats)
+                v.push_back({h->blk.rest_a, nt * sizeof(float4)});
+                v.push_back({h->blk.rest_b, nt * sizeof(float4)});
+                v.push_back({h->blk.rest_c1, nt * sizeof(float)});
+            } else if (!h->blk.lean) {  // constant-rest-shape bodies carry no shape state
                 v.push_back({h->blk.rest_a, nt * sizeof(float4)});
                 v.push_back({h->blk.rest_b, nt * sizeof(float4)});
                 v.push_back({h->blk.rest_c, nt * sizeof(float4)});
@@ -166,12 +186,34 @@ int quiesce(tetsim_body* h) {
     HIPCHK(h, hipSetDevice(h->opt.device));
     return 0;
 }
-// peer-to-peer bodies on an odd substep parity read their ghosts from ghost_alt, not from pos_pred's tail
-int ghosts_to_tail(tetsim_body* h) {
+// peer-to-peer bodies on an odd substep parity read their ghosts from ghost_alt, not from pos_pred's tail: the blob's pos_pred section
+// gets them straight from there.  (Round 5 copied ghost_alt into pos_pred's tail on the device first -- but that tail is the LIVE
+// receive buffer of the substep after next: a neighbour of another process that has resumed stepping may already have stored there.)
+int patch_blob_ghosts(tetsim_body* h, char* pos_pred_section) {
     const size_t ng = h->pj.nv_local - h->pj.nv_owned;
     if (h->partitioned && h->p2p && h->ghost_alt && ng && (h->p2p_round & 1u))
-        HIPCHK(h, hipMemcpy(h->pj.pos_pred + h->pj.nv_owned, h->ghost_alt, ng * sizeof(float4), hipMemcpyDeviceToDevice));
+        HIPCHK(h, hipMemcpy(pos_pred_section + static_cast<size_t>(h->pj.nv_owned) * sizeof(float4), h->ghost_alt, ng * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
+}
+// One rank per PROCESS with the peer-to-peer halo: this rank's ghosts of the next substep are stored by the NEIGHBOURS' queues, which
+// quiesce() cannot drain.  Every rank raises its neighbours' "arrived" words of the next substep's parity when its call ends (flush_v)
+// or when its next substep starts, and nothing clears them between calls: wait for them (host-side looks, bounded like every wait).
+int await_peer_deliveries(tetsim_body* h) {
+    if (!(h->partitioned && h->p2p && h->group.empty() && h->d_arrived && h->p2p_round > 0 && !h->loopback && !h->deep)) return 0;
+    const uint32_t par = static_cast<uint32_t>(h->p2p_round & 1u);
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t limit_ms = h->timeout_ms ? h->timeout_ms : 30000u;
+    for (;;) {
+        uint32_t words[kMaxPeers] = {};
+        HIPCHK(h, hipMemcpy(words, h->d_arrived + par * kMaxPeers, sizeof words, hipMemcpyDeviceToHost));
+        bool all = true;
+        for (size_t i = 0; i < h->neigh.size() && i < kMaxPeers; i++) if (h->neigh[i].recv_count && words[i] == 0u) all = false;
+        if (all) return 0;
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > limit_ms)
+            return fail(h, TETSIM_ECOMM, "tetsim_save_state: a neighbour's boundary predictions of the last substep did not arrive in time (every rank saves at the same "
+                                         "substep count, after its own tetsim_sync)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 int ghosts_from_tail(tetsim_body* h) {
     const size_t ng = h->pj.nv_local - h->pj.nv_owned;
@@ -192,8 +234,9 @@ int tetsim_save_state(tetsim_handle h, void* blob, uint64_t bytes) {
     if (int rc = state_guard(h)) return rc;
     const StateHeader hd = state_header(h);
     if (bytes < sizeof(hd) + hd.payload) return fail(h, TETSIM_EINVAL, "state buffer too small (tetsim_state_size)");
+    if (int rc = ensure_quats(h)) return rc;
     if (int rc = quiesce(h)) return rc;
-    if (int rc = ghosts_to_tail(h)) return rc;   // (the tail is the other parity's buffer: free until the substep after next writes it)
+    if (int rc = await_peer_deliveries(h)) return rc;
     char* out = static_cast<char*>(blob);
     std::memcpy(out, &hd, sizeof(hd));
     out += sizeof(hd);
@@ -201,6 +244,7 @@ int tetsim_save_state(tetsim_handle h, void* blob, uint64_t bytes) {
     state_sections(h, secs);
     for (const StateSection& sec : secs) {
         if (sec.bytes) HIPCHK(h, hipMemcpy(out, sec.ptr, sec.bytes, hipMemcpyDeviceToHost));
+        if (sec.ptr == h->pj.pos_pred && h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI) { if (int rc = patch_blob_ghosts(h, out)) return rc; }
         out += sec.bytes;
     }
     return 0;
@@ -231,6 +275,7 @@ int tetsim_load_state(tetsim_handle h, const void* blob, uint64_t bytes) {
     h->pred_any_dt = in.pred_any_dt != 0;
     h->dt_pred = in.dt_pred;
     h->final_ghosts_fresh = false;
+    h->quat_stale = false;   // (a lean-state blob holds the quaternions recovered from the very shape it holds)
     return 0;
 }
 

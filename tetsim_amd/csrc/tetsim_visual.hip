@@ -46,9 +46,12 @@ int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvi
                 if (lv < 0) { all_local = false; break; }
                 // owner of a local particle: this partition for the owned range, the neighbour whose receive range holds it otherwise
                 int owner = h->opt.part_index;
+                // (two-layer ghost regions keep the second layer in receive ranges of its own: a tet with such a corner belongs to the
+                // neighbour too -- found in neither range it would pass for this partition's and be kept twice; advisor, round 5)
                 if (static_cast<uint32_t>(lv) >= h->part.n_owned)
                     for (const auto& nb : h->part.neigh)
-                        if (static_cast<uint32_t>(lv) >= nb.recv_start && static_cast<uint32_t>(lv) < nb.recv_start + nb.recv_count) owner = nb.rank;
+                        if ((static_cast<uint32_t>(lv) >= nb.recv_start && static_cast<uint32_t>(lv) < nb.recv_start + nb.recv_count) ||
+                            (static_cast<uint32_t>(lv) >= nb.recv2_start && static_cast<uint32_t>(lv) < nb.recv2_start + nb.recv2_count)) owner = nb.rank;
                 lowest = std::min(lowest, owner);
             }
             if (!all_local || lowest != h->opt.part_index) continue;   // another partition's row
@@ -103,15 +106,15 @@ int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normal
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     if (normals_out && h->skin.nvis && !h->skin.out_nrm) return fail(h, TETSIM_ESTATE, "normals need POLAR_JACOBI and rest normals at tetsim_set_visual_mesh");
     HIPCHK(h, hipSetDevice(h->opt.device));
-    if (h->partitioned && !h->neigh.empty() && !h->final_ghosts_fresh) {
-        // the corners this partition does not own: their end-of-substep positions come from the neighbours (a collective of the ranks
-        // when the transport is RCCL -- every rank reads its visual mesh at the frame's end; groups of one process fetch them for all members at once)
-        if (h->comm) { if (int rc = refresh_final_rccl(h)) return rc; }
-        else return fail(h, TETSIM_ESTATE, "the ghost particles' end-of-substep positions are stale: call tetsim_group_refresh_final (in-process group) or "
-                                          "tetsim_halo_refresh_final (RCCL) after the frame's last substep, before reading the visual mesh of a partition");
-    }
+    if (h->partitioned && !h->neigh.empty() && !h->final_ghosts_fresh)
+        // The corners this partition does not own: their end-of-substep positions come from the neighbours, by an EXPLICIT call every rank
+        // makes.  (Round 5 ran the RCCL exchange from inside this read, gated by a per-rank flag: one rank reading twice per frame, or only
+        // some ranks having refreshed, left the others alone inside a collective -- a hang.  A read never communicates.)
+        return fail(h, TETSIM_ESTATE, "the ghost particles' end-of-substep positions are stale: after the frame's last substep every rank calls tetsim_halo_refresh_final "
+                                      "(RCCL; in-process groups: tetsim_group_refresh_final) before it reads the visual mesh of a partition");
     if (!h->skin.nvis) return 0;   // (a partition that owns no tet with a visual vertex)
     // Softbody.js arithmetic for the solver that mirrors Softbody.js, the vertex-shader arithmetic for the other
+    if (pjs) { if (int rc = ensure_quats(h)) return rc; }   // (lean-state bodies: the quaternions the skinning shader reads, SoftbodyGPU.js:440)
     skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const uint32_t n = h->skin.nvis;
@@ -167,6 +170,7 @@ int tetsim_read_visual_vertex_normals(tetsim_handle h, float* normals_out) {
     if (!h->skin.vt_off) return fail(h, TETSIM_ESTATE, "no visual triangles attached (tetsim_set_visual_triangles)");
     HIPCHK(h, hipSetDevice(h->opt.device));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
+    if (pjs) { if (int rc = ensure_quats(h)) return rc; }
     skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
     skin_launch_vertex_normals(h->stream, h->skin);
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -11,7 +11,7 @@
 //
 // Which reference solver is mirrored is chosen by `physicsParams.tetsim` (optional):
 //     { solver: 'polar' | 'neohookean', precision: 'precise' | 'fast', order: 'original' | 'coloured' | 'clustered', device: 0,
-//       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false,   (include/tetsim.h flags)
+//       refSlotTable: true, refFixedBounds: true, refGrabTexel: false, gather: false, constantRestShape: false, leanState: false,   (include/tetsim.h flags)
 //       partCount: 1, partIndex: 0, vertOwner: Int32Array,    (one Node process per GPU: see commUniqueId / commInit below)
 //       refStartGrab: false }   (true: startGrab searches the edge-mesh copy of the positions, exactly as SoftbodyGPU.js:692-704)
 // default: polar + precise, i.e. SoftBodyGPU's algorithm with reference-order arithmetic.
@@ -21,7 +21,7 @@ const SOLVER = { polar: 0, neohookean: 1 };
 const PRECISION = { precise: 0, fast: 1 };
 const ORDER = { original: 0, coloured: 1, clustered: 2 };
 const FLAG_REF_SLOT_TABLE = 1, FLAG_REF_FIXED_BOUNDS = 2, FLAG_GATHER_FORMULATION = 4, FLAG_CONSTANT_REST_SHAPE = 8, FLAG_REF_GRAB_TEXEL = 16,
-    FLAG_REF_ROTATION_EXIT = 64;
+    FLAG_REF_ROTATION_EXIT = 64, FLAG_LEAN_STATE = 128;
 
 let addon = null;
 function loadTetSim(libPath) {
@@ -51,7 +51,7 @@ class SoftBodyHIP {
             solver: SOLVER[this._solver], precision: PRECISION[opt.precision || 'precise'], order: ORDER[opt.order || 'original'],
             flags: (opt.refSlotTable === false ? 0 : FLAG_REF_SLOT_TABLE) | (opt.refFixedBounds === false ? 0 : FLAG_REF_FIXED_BOUNDS) |
                    (opt.gather ? FLAG_GATHER_FORMULATION : 0) | (opt.constantRestShape ? FLAG_CONSTANT_REST_SHAPE : 0) |
-                   (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0) | (opt.refRotationExit ? FLAG_REF_ROTATION_EXIT : 0),
+                   (opt.refGrabTexel ? FLAG_REF_GRAB_TEXEL : 0) | (opt.refRotationExit ? FLAG_REF_ROTATION_EXIT : 0) | (opt.leanState ? FLAG_LEAN_STATE : 0),
             device: opt.device || 0,
             partCount: opt.partCount || 1, partIndex: opt.partIndex || 0,
             density: this.physicsParams.density === undefined ? 1000.0 : this.physicsParams.density,
@@ -217,8 +217,17 @@ class SoftBodyHIP {
         return out;
     }
     // partitions: which rows of visVerts this rank skins, and its rows written into a full-size [3*numVisVerts] array (the other
-    // ranks' rows are left as they are: a host that gathers the ranks' arrays row by row has the whole mesh).  With an RCCL
-    // transport every rank calls this together (the ghost corners' end-of-substep positions are fetched from their owners).
+    // ranks' rows are left as they are: a host that gathers the ranks' arrays row by row has the whole mesh).  Corners this rank does
+    // not own need their owners' end-of-substep positions: with an RCCL transport EVERY rank calls refreshFinalGhosts() after the
+    // frame's last substep, before endFrame() / readVisualPositions() (a collective; the read itself never communicates, and fails
+    // with "stale" if the refresh was left out).  A freshly built partition is fresh (its ghosts hold the rest pose).
+    refreshFinalGhosts() { this._api.haloRefreshFinal(this._h); }
+    // the partitions of ONE Node process (handles[i] = partition i): step them together / refresh their ghosts together
+    static groupStepN(bodies, n, dt, physicsParams) {
+        loadTetSim().groupStepN(bodies.map(b => b._h), n, dt, physicsParams || bodies[0].physicsParams);
+        for (const b of bodies) b._dirty = true;
+    }
+    static groupRefreshFinal(bodies) { loadTetSim().groupRefreshFinal(bodies.map(b => b._h)); }
     visualIds() { return this._visIds || Int32Array.from({ length: this.numVisVerts }, (_, i) => i); }
     scatterVisualPositions(full) {
         const ids = this._visIds, own = new Float32Array(3 * ids.length);

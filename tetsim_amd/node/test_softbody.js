@@ -283,4 +283,44 @@ if (process.env.TETSIM_TEST_MESH) {   // partitioned bodies from a file that car
     batch.dispose();
     console.log('batch: 2 Dragons + a lattice behind one handle, both Dragons bit-exact vs Softbody.js goldens');
 }
+// 9. partitions WITH display meshes (advisor, round 5): the constructor's first updateVisMesh() must work on a fresh partition (its ghosts
+//    hold the rest pose), a read with stale ghosts says so instead of communicating, the in-process group entry points are reachable
+//    from Node; and the lean tet record (tetsim.leanState) through the same surface
+{
+    class BufferAttribute { constructor(array, itemSize) { this.array = array; this.itemSize = itemSize; this.needsUpdate = false; } }
+    class BufferGeometry { constructor() { this.attributes = {}; } setAttribute(n, a) { this.attributes[n] = a; return this; } setIndex() { return this; }
+                           computeVertexNormals() { if (!this.attributes.normal) this.attributes.normal = new BufferAttribute(new Float32Array(this.attributes.position.array.length), 3); } computeBoundingSphere() {} }
+    class Layers { enable() {} }
+    class Object3D { constructor(g, m) { this.geometry = g; this.material = m; this.layers = new Layers(); this.userData = {}; this.visible = true; } }
+    const THREE = { BufferAttribute, BufferGeometry, LineSegments: Object3D, Mesh: Object3D };
+    const nvv = verts.length / 3, vis = f32('dragon_vis.f32');
+    const owner = new Int32Array(nvv); for (let i = 0; i < nvv; i++) owner[i] = i < nvv / 2 ? 0 : 1;
+    const mk = (r, extra) => new SoftBodyHIP(verts.slice(0), tets, [0, 1], Object.assign({}, pp, { numSubsteps: 20, tetsim: Object.assign({ solver: 'polar', precision: 'fast', partCount: 2, partIndex: r, vertOwner: owner }, extra || {}) }),
+                                             vis, [], null, { THREE });
+    const parts = [mk(0), mk(1)];                                  // (threw TETSIM_ESTATE before: the constructor skins the visual mesh)
+    const p13 = parts[0].physicsParams;
+    const rest = new Float32Array(3 * 29800);
+    for (const b of parts) b.scatterVisualPositions(rest);
+    const mono = new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', precision: 'fast' } }), vis, [], null, {});
+    assert.strictEqual(bitsEqual(rest, mono.readVisualPositions()), -1, 'the partitions\' rest-pose skins add up to the whole visual mesh');
+    SoftBodyHIP.groupStepN(parts, 20, dt20, p13);
+    assert.throws(() => parts[0].readVisualPositions(), /stale/);
+    SoftBodyHIP.groupRefreshFinal(parts);
+    const full = new Float32Array(3 * 29800);
+    for (const b of parts) { b.endFrame(); b.scatterVisualPositions(full); }
+    for (let i = 0; i < full.length; i++) assert.ok(Number.isFinite(full[i]));
+    assert.ok(full.some((x, i) => x !== rest[i]));
+    for (const b of parts) b.dispose();
+    mono.dispose();
+    const lean = new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', precision: 'fast', leanState: true } }), new Float32Array(0), [], null, {});
+    const dflt = new SoftBodyHIP(verts.slice(0), tets, [], Object.assign({}, pp, { tetsim: { solver: 'polar', precision: 'fast' } }), new Float32Array(0), [], null, {});
+    for (const b of [lean, dflt]) { b.simulateSubsteps(20, dt20, p13); b.endFrame(); }
+    let worst = 0;
+    for (let i = 0; i < lean.pos.length; i++) worst = Math.max(worst, Math.abs(lean.pos[i] - dflt.pos[i]));
+    assert.ok(worst < 5e-5, 'lean state vs default FAST after 20 substeps: ' + worst);
+    const ql = lean.readQuats();
+    for (let e = 0; e < ql.length; e += 4) assert.ok(Math.abs(Math.hypot(ql[e], ql[e + 1], ql[e + 2], ql[e + 3]) - 1) < 1e-5);
+    lean.dispose(); dflt.dispose();
+    console.log('partitions with display meshes build and skin (fresh ghosts), stale reads say so, group entry points + leanState reachable from Node');
+}
 console.log('node boundary ok');

@@ -46,6 +46,9 @@ struct Api {
     decltype(&tetsim_set_visual_mesh) set_visual_mesh = nullptr;
     decltype(&tetsim_read_visual_mesh) read_visual_mesh = nullptr;
     decltype(&tetsim_get_visual_ids) get_visual_ids = nullptr;
+    decltype(&tetsim_halo_refresh_final) halo_refresh_final = nullptr;
+    decltype(&tetsim_group_refresh_final) group_refresh_final = nullptr;
+    decltype(&tetsim_group_step_n) group_step_n = nullptr;
     decltype(&tetsim_set_visual_triangles) set_visual_triangles = nullptr;
     decltype(&tetsim_read_visual_vertex_normals) read_visual_vertex_normals = nullptr;
     decltype(&tetsim_set_grab) set_grab = nullptr;
@@ -86,6 +89,7 @@ bool load_lib(const std::string& hint) {
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
     SYM(prep_partition, "tetsim_prep_partition") SYM(prep_partition_quality, "tetsim_prep_partition_quality")
+    SYM(halo_refresh_final, "tetsim_halo_refresh_final") SYM(group_refresh_final, "tetsim_group_refresh_final") SYM(group_step_n, "tetsim_group_step_n")
 #undef SYM
     return true;
 }
@@ -655,6 +659,47 @@ napi_value CommUniqueId(napi_env env, napi_callback_info) {
     napi_create_typedarray(env, napi_uint8_array, 128, ab, 0, &out);
     return out;
 }
+// haloRefreshFinal(handle): every rank together, after the frame's last substep -- the ghost particles' end-of-substep positions from their
+// owners, which readVisualMesh of a partition needs (tetsim_halo_refresh_final; the read itself never communicates)
+napi_value HaloRefreshFinal(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    return h ? check(env, g.halo_refresh_final(h), h) : nullptr;
+}
+// the partitions of ONE process (in-process group: several GPUs -- or one -- driven by a single Node process), handles[i] = partition i
+bool handles_of(napi_env env, napi_value arr, std::vector<tetsim_handle>* hs) {
+    bool is = false;
+    uint32_t n = 0;
+    if (napi_is_array(env, arr, &is) != napi_ok || !is || napi_get_array_length(env, arr, &n) != napi_ok || n == 0) { throw_err(env, "handles must be a non-empty array of tetsim handles"); return false; }
+    hs->resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value e;
+        if (napi_get_element(env, arr, i, &e) != napi_ok) { throw_err(env, "handles must be a non-empty array of tetsim handles"); return false; }
+        if (!((*hs)[i] = handle_of(env, e))) return false;
+    }
+    return true;
+}
+// groupStepN(handles[], n, dt, physicsParams)     (tetsim_group_step_n)
+napi_value GroupStepN(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return nullptr;
+    std::vector<tetsim_handle> hs;
+    if (!handles_of(env, a[0], &hs)) return nullptr;
+    double nd, dt;
+    if (!num_arg(env, a[1], &nd, "n") || !num_arg(env, a[2], &dt, "dt")) return nullptr;
+    if (!(nd >= 0.0) || nd > 4294967295.0 || nd != static_cast<double>(static_cast<uint32_t>(nd))) return throw_err(env, "n must be a non-negative integer");
+    TetSimParams p; params_of(env, a[3], &p);
+    return check(env, g.group_step_n(hs.data(), static_cast<uint32_t>(hs.size()), static_cast<uint32_t>(nd), dt, &p), nullptr);
+}
+// groupRefreshFinal(handles[])                    (tetsim_group_refresh_final)
+napi_value GroupRefreshFinal(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return nullptr;
+    std::vector<tetsim_handle> hs;
+    if (!handles_of(env, a[0], &hs)) return nullptr;
+    return check(env, g.group_refresh_final(hs.data(), static_cast<uint32_t>(hs.size())), nullptr);
+}
 // commInit(handle, Uint8Array(128) id, rank, nranks): RCCL communicator for this partition's ghost halo
 napi_value CommInit(napi_env env, napi_callback_info info) {
     napi_value a[4];
@@ -731,6 +776,9 @@ napi_value Init(napi_env env, napi_value exports) {
         {"setVisualMesh", nullptr, SetVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualMesh", nullptr, ReadVisualMesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"visualIds", nullptr, VisualIds, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"haloRefreshFinal", nullptr, HaloRefreshFinal, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupStepN", nullptr, GroupStepN, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupRefreshFinal", nullptr, GroupRefreshFinal, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualTriangles", nullptr, SetVisualTriangles, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualVertexNormals", nullptr, ReadVisualVertexNormals, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -57,6 +57,7 @@ class SoftBodyHIP:
     def __init__(self, vertices, tetIds, tetEdgeIds=None, physicsParams=None, visVerts=None, visTriIds=None,
                  visMaterial=None, world=None, *, solver="polar", precision="precise", order="original",
                  ref_slot_table=True, ref_fixed_bounds=True, gather=False, constant_rest_shape=False, ref_grab_texel=False, deep_ghosts=False, ref_rotation_exit=False,
+                 lean_state=False,
                  device=0, part_count=1, part_index=0, vert_owner=None, tet_colour=None, mesh_file=None, batch=None):
         L = capi.lib()
         self.physicsParams = physicsParams if physicsParams is not None else {}
@@ -92,7 +93,7 @@ class SoftBodyHIP:
                    | (capi.FLAG_GATHER_FORMULATION if gather else 0)
                    | (capi.FLAG_CONSTANT_REST_SHAPE if constant_rest_shape else 0)
                    | (capi.FLAG_REF_GRAB_TEXEL if ref_grab_texel else 0) | (capi.FLAG_DEEP_GHOSTS if deep_ghosts else 0)
-                   | (capi.FLAG_REF_ROTATION_EXIT if ref_rotation_exit else 0))
+                   | (capi.FLAG_REF_ROTATION_EXIT if ref_rotation_exit else 0) | (capi.FLAG_LEAN_STATE if lean_state else 0))
         o.device = device
         d = self.physicsParams.get("density", 1000.0) if isinstance(self.physicsParams, dict) else getattr(self.physicsParams, "density", 1000.0)
         o.density = float(d)
@@ -292,8 +293,8 @@ class SoftBodyHIP:
         return out
 
     def refreshFinalGhosts(self):
-        """RCCL partitions, every rank together: the ghost particles' end-of-substep positions from their owners (visualPositions does
-        it by itself; in-process groups: group_refresh_final)."""
+        """RCCL partitions, every rank together, after the frame's last substep and before visualPositions(): the ghost particles'
+        end-of-substep positions from their owners (in-process groups: group_refresh_final).  The read itself never communicates."""
         capi.check(self._L.tetsim_halo_refresh_final(self._h), self._h)
 
     def visualPositions(self, with_normals=False):
