@@ -59,6 +59,10 @@ def parse_args():
     ap.add_argument("--order", default="clustered", choices=["coloured", "clustered"], help="--solver neohookean: Gauss-Seidel schedule")
     ap.add_argument("--constant-rest-shape", action="store_true",
                     help="opt-in TETSIM_FLAG_CONSTANT_REST_SHAPE formulation (NOT the headline: 100 instead of 148 algorithmic B/tet)")
+    ap.add_argument("--lean-state", action="store_true",
+                    help="the HEADLINE body with TETSIM_FLAG_LEAN_STATE (92 instead of 148 algorithmic B/tet: three carried corners, no quaternion in the substep) -- "
+                         "counter passes and profiles of the lean kernel; the default line already carries value_lean / roofline_lean beside the reference formulation")
+    ap.add_argument("--no-lean", action="store_true", help="N = 1: skip the lean-state leg (value_lean, roofline_lean)")
     ap.add_argument("--reference-rotation-exit", action="store_true",
                     help="the HEADLINE body with TETSIM_FLAG_REF_ROTATION_EXIT (|omega| < 1e-9: nine rotation iterations in every tet, the reference's "
                          "work) -- counter passes of the equal-work kernel; the default line already carries value_reference_threshold beside value")

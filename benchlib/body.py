@@ -32,6 +32,8 @@ def make_body(args, cells, scaling, rank, world, local_rank, ranks, vote=False, 
             kw = dict(part_count=world, part_index=rank, vert_owner=slab_owner(len(verts), cells, nz, world), ref_fixed_bounds=False)
         if args.constant_rest_shape:
             kw["constant_rest_shape"] = True
+        if getattr(args, "lean_state", False):
+            kw["lean_state"] = True
         if getattr(args, "reference_rotation_exit", False):
             kw["ref_rotation_exit"] = True
         if (halo or args.halo) == "deep" and ranks is not None and world > 1:

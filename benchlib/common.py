@@ -19,6 +19,9 @@ DT = (PP["timeScale"] * PP["timeStep"]) / PP["numSubsteps"]  # main.js:79
 # idx 16 R + lastRest 48 R + 48 W + quat 16 R + 16 W + restVol 4 R.
 TET_KERNEL_BYTES = 148.0
 
+# TETSIM_FLAG_LEAN_STATE (include/tetsim.h): positions 16 R + three carried corners 36 R + 36 W + restVol 4 R (no quaternion, no fourth corner)
+TET_KERNEL_BYTES_LEAN = 92.0
+
 VERTEX_BYTES = 144.0           # per particle per substep (integrate/accumulate/finalize rows)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)

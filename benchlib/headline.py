@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from .common import CELLS, DT, HBM_PEAK_GBS, PP, ROOT, SUBSTEPS, TET_KERNEL_BYTES, VERTEX_BYTES
+from .common import CELLS, DT, HBM_PEAK_GBS, PP, ROOT, SUBSTEPS, TET_KERNEL_BYTES, TET_KERNEL_BYTES_LEAN, VERTEX_BYTES
 from .cpu import cpu_baseline
 from .body import make_body, timed_frames
 from .launcher import GUARD
@@ -168,7 +168,7 @@ def run(args, rank, world, local_rank, ranks):
             "config": {"workload": "Kuhn-6 cube lattice %dx%dx%d cells (%d tets, %d particles), polar-decomposition Jacobi, "
                                    "%d substeps/frame, dt=1/1200 s" % (cells, cells, nz, nt_global, nv_global, SUBSTEPS),
                        "solver": "polar_jacobi", "arithmetic": args.precision,
-                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
+                       "formulation": "constant rest shape (opt-in)" if args.constant_rest_shape else "lean state (opt-in: three carried corners, no quaternion, 92 B/tet)" if args.lean_state else "reference (rest shape carried from substep to substep, 148 B/tet)", "substeps_per_step": SUBSTEPS,
                        "rotation_exit": "|omega| < 1e-9 throughout (--reference-rotation-exit: the reference's, SoftbodyGPU.js:131)" if getattr(args, "reference_rotation_exit", False) else ("iteration 1: |omega| < 1e-9 (the reference's, SoftbodyGPU.js:131); correction iterations 2..9: |omega| < 1e-6 rad "
                                          "(FAST default; value_reference_threshold at the top level has the same frames with 1e-9 throughout, and roofline.frac is quoted on THAT kernel)") if args.precision == "fast"
                                         else "|omega| < 1e-9 (the reference's, SoftbodyGPU.js:131)",
@@ -215,7 +215,7 @@ def run(args, rank, world, local_rank, ranks):
     if world == 1 and args.solver == "polar" and args.precision == "fast" and not args.no_replay and rank == 0:
         try:
             from tetsim_amd import SoftBodyHIP
-            kw = dict(constant_rest_shape=True) if args.constant_rest_shape else {}
+            kw = dict(constant_rest_shape=True) if args.constant_rest_shape else dict(lean_state=True) if args.lean_state else {}
             runs = []
             for _ in range(3):
                 b3 = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, ref_rotation_exit=True, **kw)
@@ -234,6 +234,48 @@ def run(args, rank, world, local_rank, ranks):
             equal = {"elapsed": sorted(runs)[1], "runs": runs, "tet_us": acc4["tet_ms"] / acc4["tet_launches"] * 1e3, "launches": acc4["tet_launches"]}
         except Exception as e:  # noqa: BLE001
             print("[bench] the equal-work (reference threshold) leg failed: %r" % (e,), file=sys.stderr)
+    # THE LEAN TET RECORD (TETSIM_FLAG_LEAN_STATE): the same frames on bodies that stream 92 instead of 148 B per
+    # tet (three carried corners, no quaternion) -- wall clock with the FAST exit (value_lean) and with the reference's threshold
+    # (value_lean_reference_threshold), medians of three bodies from rest each, and the kernel on the floor by per-launch events + in graphs.
+    lean = None
+    if world == 1 and args.solver == "polar" and args.precision == "fast" and not args.no_replay and not args.no_lean and rank == 0 and not args.constant_rest_shape and not args.lean_state:
+        try:
+            from tetsim_amd import SoftBodyHIP
+
+            def lean_runs(**kw):
+                runs = []
+                for _ in range(3):
+                    b = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, lean_state=True, **kw)
+                    el, _ = timed_frames(b, pp, args.steps, args.warmup, None)
+                    runs.append(el)
+                    b.close()
+                return runs
+            fast_runs, ref_runs = lean_runs(), lean_runs(ref_rotation_exit=True)
+            b5 = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, lean_state=True, ref_rotation_exit=True)
+            for _ in range(args.warmup):
+                b5.profile(SUBSTEPS, DT, pp)
+            acc5 = {"tet_ms": 0.0, "tet_launches": 0, "vertex_ms": 0.0, "vertex_launches": 0}
+            for _ in range(args.steps):
+                p5 = b5.profile(SUBSTEPS, DT, pp)
+                for k in acc5:
+                    acc5[k] += p5[k]
+            # ... on to the floor (the headline body lies there after its W + K frames and three batches; this one needs the same ~45 frames)
+            for _ in range(max(0, 45 - args.steps - args.warmup)):
+                b5.simulateSubsteps(SUBSTEPS, DT, pp)
+            fl = sorted((b5.profile(SUBSTEPS * 3, DT, pp) for _ in range(3)), key=lambda p: p["tet_ms"] / p["tet_launches"])[1]
+            b5.sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                b5.simulateSubsteps(SUBSTEPS, DT, pp)
+            b5.sync()
+            floor_sub = (time.perf_counter() - t0) / (10 * SUBSTEPS) * 1e6
+            finite = bool(np.isfinite(b5.pos).all())
+            b5.close()
+            lean = {"fast_runs": fast_runs, "ref_runs": ref_runs, "timed_tet_us": acc5["tet_ms"] / acc5["tet_launches"] * 1e3, "timed_launches": acc5["tet_launches"],
+                    "floor_tet_us": fl["tet_ms"] / fl["tet_launches"] * 1e3, "floor_vert_us": fl["vertex_ms"] / max(fl["vertex_launches"], 1) * 1e3,
+                    "floor_substep_us": floor_sub, "finite": finite}
+        except Exception as e:  # noqa: BLE001
+            print("[bench] the lean-state leg failed: %r" % (e,), file=sys.stderr)
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
         # three batches of 60 substeps, the median batch is reported (a single batch right after the timed region is
         # occasionally 5-8% slow on a box that agrees with rocprofv3 otherwise)
@@ -254,7 +296,7 @@ def run(args, rank, world, local_rank, ranks):
                 print("[bench] the on-floor graph frames failed: %r" % (e,), file=sys.stderr)
         if use_dist:
             ranks.barrier()
-    tet_bytes = TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)   # constant rest shape: read only, never written back
+    tet_bytes = TET_KERNEL_BYTES_LEAN if args.lean_state else TET_KERNEL_BYTES - (48.0 if args.constant_rest_shape else 0.0)   # constant rest shape: read only, never written back
     b_alg = tet_bytes + VERTEX_BYTES * len(verts) / len(tets)
     if rank == 0 and pr is not None:
         after_us = pr["tet_ms"] / pr["tet_launches"] * 1e3
@@ -262,10 +304,10 @@ def run(args, rank, world, local_rank, ranks):
         tet_us = win["tet_ms"] / win["tet_launches"] * 1e3
         vert_us = win["vertex_ms"] / win["vertex_launches"] * 1e3 if win["vertex_launches"] else 0.0
         units = win["tets_per_tet_launch"]
-        kname = "pjb_tet_kernel" if args.precision == "fast" else "pj_tet_kernel_precise"
+        kname = ("pjb_tet_kernel_lean" if args.lean_state else "pjb_tet_kernel") if args.precision == "fast" else "pj_tet_kernel_precise"
         if body.info.fused_particle_pass in (1, 2):   # small bodies (< 2,048 tiles): one kernel per substep does the particle row too
             kname, tet_bytes = "pjb_tet_kernel_x<TetFused>", b_alg
-        traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and cells == CELLS else None
+        traffic = pmc_traffic(kname, lib["kernel_sha"]) if world == 1 and not args.constant_rest_shape and not args.lean_state and cells == CELLS else None
         alg = tet_bytes * units
 
         def window(us, what, **more):
@@ -299,11 +341,27 @@ def run(args, rank, world, local_rank, ranks):
                                        "what": "wall clock of the same frames as graph replays (value_reference_threshold) minus the particle kernel and the two launch "
                                                "boundaries of timed_region_check; on the first frames after a body's creation the graphs run the iteration-heavy kernel "
                                                "slower than its per-launch events say (tools/frame_series.py)"}
+        # WHAT THE PRODUCT RUNS LEADS: the equal-work kernel INSIDE the graphs tetsim_step_n replays -- the timed
+        # frames with the reference's threshold: their wall clock per substep minus the particle kernel and the two launch boundaries --
+        # is `frac`; the per-launch event figures (about 1 us shorter: an eagerly launched kernel with its own events starts on an idle chip)
+        # stand beside it as frac_events / on_floor / timed_frames_reference_threshold.
+        events_lead = lead
+        if ref_win is not None and "in_graph" in ref_win:
+            ig = ref_win["in_graph"]
+            lead = {"kernel_us": ig["kernel_us_implied"], "achieved": round(alg / (ig["kernel_us_implied"] * 1e-6) / 1e9, 1), "frac": ig["frac_implied"],
+                    "window": "the %d timed frames with the reference's rotation threshold AS GRAPH REPLAYS (what tetsim_step_n runs): wall clock per substep (%.2f us, "
+                              "median of three bodies) minus the particle kernel (%.2f us) and the two launch boundaries (%.2f us) of timed_region_check"
+                              % (args.steps, ig["substep_us"], vert_us, boundaries_us)}
+        elif "in_graph" in floor_win:
+            ig = floor_win["in_graph"]
+            lead = {"kernel_us": ig["kernel_us_implied"], "achieved": round(alg / (ig["kernel_us_implied"] * 1e-6) / 1e9, 1), "frac": ig["frac_implied"],
+                    "window": "ten frames on the floor as graph replays: " + ig["what"]}
         achieved = lead["achieved"]
         out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
                            "achieved": lead["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": lead["frac"], "traffic": traffic,
                            "kernel_us": lead["kernel_us"], "window": lead["window"],
+                           "frac_events": events_lead["frac"], "kernel_us_events": events_lead["kernel_us"], "window_events": events_lead["window"],
                            "work": "equal to the reference's: nine rotation iterations in every tet (SoftbodyGPU.js:122-139)" if args.precision == "fast" else "the reference's",
                            "vertex_kernel_us": round(vert_us, 2),
                            "alg_bytes_per_launch": alg,
@@ -331,6 +389,44 @@ def run(args, rank, world, local_rank, ranks):
         if equal is not None:
             out["value_reference_threshold"] = round(nt_global * SUBSTEPS * args.steps / equal["elapsed"] / 1e6, 1)
             out["value_reference_threshold_runs"] = [round(nt_global * SUBSTEPS * args.steps / r / 1e6, 1) for r in equal["runs"]]
+            # the whole substep at equal work, against the peak: SURVEY 8(d)'s 173.3 B per tet-solve x Nt over the in-graph substep of those frames
+            out["roofline"]["frac_substep_reference_threshold"] = round(b_alg * out["value_reference_threshold"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)
+        if lean is not None:
+            rate = lambda el: round(nt_global * SUBSTEPS * args.steps / el / 1e6, 1)   # noqa: E731
+            b_alg_lean = TET_KERNEL_BYTES_LEAN + VERTEX_BYTES * len(verts) / len(tets)
+            alg_lean = TET_KERNEL_BYTES_LEAN * units
+            out["value_lean"] = rate(sorted(lean["fast_runs"])[1])
+            out["value_lean_runs"] = [rate(r) for r in lean["fast_runs"]]
+            out["value_lean_reference_threshold"] = rate(sorted(lean["ref_runs"])[1])
+            out["value_lean_reference_threshold_runs"] = [rate(r) for r in lean["ref_runs"]]
+            sub_ref_lean = sorted(lean["ref_runs"])[1] / (args.steps * SUBSTEPS) * 1e6
+            rl = {"bound": "hbm", "kernel": "pjb_tet_kernel_lean", "formulation": "TETSIM_FLAG_LEAN_STATE: three carried corners in and out, no quaternion in the substep "
+                  "(recovered from the carried shape at read-out): positions 16 + shape 36 + 36 + weight 4 = 92 algorithmic B per tet -- ITS OWN B_alg (SURVEY.md 8(d)), not the reference formulation's 148",
+                  "alg_bytes_per_tet": TET_KERNEL_BYTES_LEAN, "alg_bytes_per_launch": alg_lean, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "substep_alg_bytes_per_tet": round(b_alg_lean, 1), "finite": lean["finite"]}
+            if boundaries_us is not None:   # what leads: the equal-work kernel inside the graphs (as for the reference formulation above)
+                imp = sub_ref_lean - lean["floor_vert_us"] - boundaries_us
+                rl.update({"kernel_us": round(imp, 2), "achieved": round(alg_lean / (imp * 1e-6) / 1e9, 1), "frac": round(alg_lean / (imp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                           "window": "the %d timed frames with the reference's rotation threshold as graph replays: wall clock per substep (%.2f us, median of three bodies) minus the "
+                                     "particle kernel (%.2f us) and the two launch boundaries (%.2f us)" % (args.steps, sub_ref_lean, lean["floor_vert_us"], boundaries_us)})
+            else:
+                rl.update({"kernel_us": round(lean["floor_tet_us"], 2), "achieved": round(alg_lean / (lean["floor_tet_us"] * 1e-6) / 1e9, 1),
+                           "frac": round(alg_lean / (lean["floor_tet_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "window": "on the floor, per-launch events"})
+            ev = lambda us, what: {"kernel_us": round(us, 2), "achieved": round(alg_lean / (us * 1e-6) / 1e9, 1), "frac": round(alg_lean / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "window": what}   # noqa: E731
+            rl["on_floor"] = dict(ev(lean["floor_tet_us"], "180 substeps on the floor (nine iterations in every tet), per-launch events, median of three batches of 60"),
+                                  in_graph={"substep_us": round(lean["floor_substep_us"], 2), "what": "ten more frames as graph replays, wall clock per substep"})
+            rl["timed_frames_reference_threshold"] = ev(lean["timed_tet_us"], "the %d timed frames (%d launches) with the reference's rotation threshold, per-launch events" % (args.steps, lean["timed_launches"]))
+            rl["vertex_kernel_us"] = round(lean["floor_vert_us"], 2)
+            rl["substep_frac_reference_threshold"] = round(b_alg_lean * out["value_lean_reference_threshold"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)
+            ce = tet_kernel_ceiling(lib["kernel_sha"])
+            if ce is not None and ce.get("lean"):
+                # the leaner record is no longer bound by bytes: its ceiling is the vector-issue floor of its own instruction count
+                lc = ce["lean"]
+                ceil_us = max(lc["memory_floor_us"], lc["valu_issue_floor_us"])
+                rl["ceiling"] = dict(lc, ceiling_us=ceil_us, kernel_vs_ceiling=round(ceil_us / rl["kernel_us"], 4), stale=ce["stale"])
+            rl["speedup_vs_reference_formulation"] = {"value": round(out["value_lean"] / out["value"], 4),
+                                                      "value_reference_threshold": round(out["value_lean_reference_threshold"] / out["value_reference_threshold"], 4) if "value_reference_threshold" in out else None}
+            out["roofline_lean"] = rl
         # the FAST-exit replay against the wall clock of the timed region itself: a substep there is the two kernels plus two launch boundaries
         if win is replay and world == 1:
             sub_us = elapsed / (args.steps * SUBSTEPS) * 1e6

@@ -110,17 +110,19 @@ def test_lean_state_quaternion_keeps_its_sign_through_a_full_turn():
     lean.writeState(v, vel)
     ref.writeState(v, vel)
     worst, wmin = 0.0, 1.0
-    for _ in range(75):               # 1,500 substeps = 1.25 s = 0.6 turns
+    for _ in range(150):              # 3,000 substeps = 2.5 s: ~0.9 turns (one Jacobi iteration per substep bleeds some spin: 2.4 rad/s effective)
         lean.simulateSubsteps(20, DT20, pp)
         ref.simulateSubsteps(20, DT20, pp)
         ql, qr = _input_order(lean), _input_order(ref)
         worst = max(worst, float(np.abs(ql - qr).max()))
         wmin = min(wmin, float(qr[:, 3].min()))
     assert wmin < -0.2                 # the body has turned past pi: q.w went negative in the multiplied-up quaternion
-    within("polar fast lean vs carried spinning lattice: quaternion over 1500 substeps", worst, 5e-3)
+    # two FAST trajectories of a free spinning body drift apart in PHASE over 3,000 substeps (observed 0.04 = 0.07 rad of 5.9); a lost
+    # sign would read 2.  The recovery's own accuracy is what the oracle comparisons above and in the GLSL goldens bound.
+    within("polar fast lean vs carried spinning lattice: quaternion over 3000 substeps", worst, 0.2)
     p = lean.pos
     e1 = np.linalg.norm(p[t[:, 0]] - p[t[:, 1]], axis=1)
-    within("polar fast lean spinning lattice: relative edge drift after 1500 substeps", float(np.abs(e1 / e0 - 1.0).max()), 1e-3)
+    within("polar fast lean spinning lattice: relative edge drift after 3000 substeps", float(np.abs(e1 / e0 - 1.0).max()), 1e-3)
 
 
 def test_lean_state_partitions_and_transports():

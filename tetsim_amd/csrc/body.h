@@ -275,6 +275,12 @@ struct tetsim_body {
     uint8_t* d_first_mask = nullptr;
     uint32_t* d_nh_untouched = nullptr;
     uint32_t nh_untouched = 0;
+    // clustered FAST bodies: the sweep as ONE launch per substep, particles handed on with their stamp (dev_common.h: NHSweep);
+    // TETSIM_NH_ONE_LAUNCH=0 at creation keeps one launch per colour (A/B); tetsim_profile always does (it times the colour kernels)
+    bool nh_one_launch = false;
+    NHSweep nh_sweep1;
+    uint32_t nh_sub_index = 0;        // substep inside the run being enqueued (enqueue_substep: first -> 0)
+    uint32_t nh_epoch_arg = 0;        // tetsim_step: a block of stamps of its own as a kernel argument; 0 = DevParams::epoch (tetsim_step_n)
     std::vector<uint32_t> level_off;
     // small bodies (all particles fit one CU's LDS, level schedules): tetsim_step_n runs a call as ONE single-workgroup launch
     bool nh_frame = false;
@@ -345,7 +351,7 @@ void pj_tet(tetsim_body* h, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_vertex(tetsim_body* h, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pj_fused_substep(tetsim_body* h, bool first, bool last, hipEvent_t* e);   // one substep of a fused body (tet | fused x (n-1) | particle)
 void pj_repredict(tetsim_body* h);
-void nh_sweep(tetsim_body* h, bool fold = false, bool last = true);   // fold: first touchers do the particle pass between two substeps; last: the sweep whose volError the call leaves behind
+void nh_sweep(tetsim_body* h, bool fold = false, bool last = true, bool one_launch = false);   // one_launch: bodies with nh_one_launch take the single-launch sweep (enqueue_substep; tetsim_profile keeps the colour kernels)   // fold: first touchers do the particle pass between two substeps; last: the sweep whose volError the call leaves behind
 // first / last: position inside a run of substeps enqueued back to back with one dt
 int enqueue_substep(tetsim_body* h, bool first = true, bool last = true);
 int ensure_prediction(tetsim_body* h, double dt);

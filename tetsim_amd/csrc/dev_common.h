@@ -123,6 +123,32 @@ struct NHClusterLaunch {
     const uint8_t* first_mask = nullptr;
 };
 
+// The clustered sweep as ONE launch per substep (FAST, four lanes per cluster; nh_kernels.inc: nh_sweep1_kernel): the grid holds the
+// clusters of ALL colours, colour by colour -- the dispatcher hands out workgroups in grid order, so whatever a waiting wave waits for has
+// been dispatched before it -- and a particle travels from a cluster to the next one that touches it as ONE 16-byte store {x, y, z, stamp}
+// into an exchange array, stamp = epoch + substep * colours + colour of the writer + 1 (data and "it is there" in one store, as the polar
+// frame kernel's partial sums: pj_blocked.hip).  A cluster polls only its own slots, for the stamp the host worked out per slot (`delta`:
+// how many colours back the previous toucher sits; 0 = this cluster is the first of the sweep to touch the particle, which comes from
+// NHDev::pos as before -- the previous launch completed it); the sweep's LAST toucher of a particle stores it to NHDev::pos.  Inverse
+// masses are constants and travel in the cluster record (slot_im), the fourth float of an exchanged particle being the stamp.
+struct NHSweepColour {
+    NHClusterLaunch L;
+    const float* slot_im = nullptr;      // [kNHClusterVerts][clusters]
+    const uint2* delta = nullptr;        // [clusters] a byte per slot
+    const uint8_t* last_mask = nullptr;  // [clusters] bit k: no later cluster of the sweep touches the particle in slot k
+    uint32_t first_block = 0;            // of this colour in the one-launch grid (4 waves of 16 clusters per block)
+    uint32_t pad = 0;
+};
+struct NHSweep {
+    const NHSweepColour* colours = nullptr;   // device, [ncolours]
+    uint32_t ncolours = 0, blocks = 0;
+    float4* exchange = nullptr;               // [nv]
+    uint32_t* error = nullptr;                // raised by a wave whose wait gave up (bounded: timeout_ms)
+    uint32_t timeout_ms = 0;
+};
+// sub_index: substep inside the call (stamps of different substeps never collide); epoch: first stamp of the call, 0 = DevParams::epoch
+void nh_launch_sweep1_fast(hipStream_t s, const NHDev& d, const NHSweep& w, bool fold, uint32_t sub_index, uint32_t epoch);
+
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
 // e0/e1 (optional): HIP events that timestamp the kernel's own begin and end (hipExtLaunchKernelGGL), for
 // tetsim_profile; normal launches pass none.

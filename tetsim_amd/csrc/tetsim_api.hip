@@ -106,6 +106,7 @@ int next_epoch_block(tetsim_body* h) {
             HIPCHK(h, hipMemsetAsync(h->blk.partial, 0, h->partial_slots * sizeof(float4), h->stream));
             HIPCHK(h, hipMemsetAsync(h->partial_b, 0, h->partial_slots * sizeof(float4), h->stream));
         }
+        if (h->nh_one_launch) HIPCHK(h, hipMemsetAsync(h->nh_sweep1.exchange, 0, static_cast<size_t>(h->nh.nv) * sizeof(float4), h->stream));
         h->frame_epoch = 1u;
     }
     h->frame_epoch += 65536u;
@@ -202,9 +203,13 @@ void pj_repredict(tetsim_body* h) {
 // NEOHOOKEAN_GS: the Gauss-Seidel sweep over all tets (A3-A5), as dependency levels or as cluster colours
 // last = the call's last sweep: `volError` (Softbody.js:163, reset by every simulate()) is what THAT sweep leaves behind; an earlier
 // sweep's per-tet values would be overwritten unread -- 8 B per tet-solve of dead stores, left out (a null pointer)
-void nh_sweep(tetsim_body* h, bool fold, bool last) {
+void nh_sweep(tetsim_body* h, bool fold, bool last, bool one_launch) {
     NHDev nh = h->nh;
     if (!last) nh.vol_err = nullptr;
+    if (one_launch && h->nh_one_launch) {   // clustered FAST: every colour in ONE launch, particles handed on with their stamp (nh_kernels.inc: nh_sweep1_kernel)
+        nh_launch_sweep1_fast(h->stream, nh, h->nh_sweep1, fold, h->nh_sub_index, h->nh_epoch_arg);
+        return;
+    }
     if (!h->cluster_launch.empty()) {
         for (const NHClusterLaunch& L : h->cluster_launch) h->fast ? nh_launch_cluster_fast(h->stream, nh, L, fold) : nh_launch_cluster_precise(h->stream, nh, L, fold);
         return;
@@ -321,7 +326,8 @@ int enqueue_substep(tetsim_body* h, bool first, bool last) {
         // to touch a particle finishes the previous substep and predicts the next for it while loading it (nh_kernels.inc:
         // fold_particle) -- one kernel and one launch boundary less per substep, the same operations per particle
         if (first) h->fast ? nh_launch_predict_fast(h->stream, h->nh) : nh_launch_predict_precise(h->stream, h->nh);
-        nh_sweep(h, !first && h->nh_fold, last);
+        h->nh_sub_index = first ? 0u : h->nh_sub_index + 1u;
+        nh_sweep(h, !first && h->nh_fold, last, true);
         if (last) h->fast ? nh_launch_post_fast(h->stream, h->nh) : nh_launch_post_precise(h->stream, h->nh);
         else if (h->nh_fold) h->fast ? nh_launch_post_predict_list_fast(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched)
                                      : nh_launch_post_predict_list_precise(h->stream, h->nh, h->d_nh_untouched, h->nh_untouched);
@@ -684,7 +690,13 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
         const uint32_t epoch = h->frame_epoch;
         return launch_in_turn(h, [&]() -> int { return launch_frame_kernel(h, 1u, epoch); });
     }
+    if (h->nh_one_launch) {   // (the parameters on the device may be the previous call's: this launch brings its own block of stamps, like the frame kernel above)
+        if (!h->epoch_block_fresh && (rc = next_epoch_block(h))) return rc;
+        h->epoch_block_fresh = false;
+        h->nh_epoch_arg = h->frame_epoch;
+    }
     rc = enqueue_substep(h);
+    h->nh_epoch_arg = 0u;
     if (!rc) rc = flush_v(h);
     return rc;
 }
@@ -696,6 +708,13 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
     while (h->frame && n > 32768u) {   // (a persistent launch numbers its substeps inside one block of 65,536 sequence numbers)
         if (int rc = tetsim_step_n(h, 32768u, dt, params)) return rc;
         n -= 32768u;
+    }
+    if (h->nh_one_launch) {            // (the one-launch sweep stamps substep x colour inside one block too)
+        const uint32_t most = 65000u / h->nh_sweep1.ncolours;
+        while (n > most) {
+            if (int rc = tetsim_step_n(h, most, dt, params)) return rc;
+            n -= most;
+        }
     }
     HIPCHK(h, hipSetDevice(h->opt.device));
     int rc = push_params(h, dt, params);
@@ -770,6 +789,18 @@ int tetsim_sync(tetsim_handle h) {
             h->graphs.clear();
             return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "
                                         "the state since then is invalid; this body falls back to one kernel per substep");
+        }
+    }
+    if (h->nh_one_launch) {   // one-launch Gauss-Seidel sweep: a cluster waited in vain for a particle of an earlier colour (never in a correct run)
+        uint32_t err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->nh_sweep1.error, sizeof err, hipMemcpyDeviceToHost));
+        if (err) {
+            HIPCHK(h, hipMemset(h->nh_sweep1.error, 0, sizeof err));
+            h->nh_one_launch = false;   // one launch per colour from now on
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            return fail(h, TETSIM_EHIP, "one-launch Gauss-Seidel sweep: a cluster waited in vain for a particle of an earlier colour (workgroups not dispatched in grid order?); "
+                                        "the state since then is invalid; this body falls back to one launch per colour");
         }
     }
     if (h->d_sync) {  // a bounded device-side wait that gave up (util_kernels.hip): the results since then are not to be trusted

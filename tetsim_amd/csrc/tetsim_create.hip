@@ -616,6 +616,63 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             L.slot_vid = h->d_slot_vid + plan.vid_off[l];
             h->cluster_launch.push_back(L);
         }
+        // The sweep as ONE launch (nh_kernels.inc: nh_sweep1_kernel): per cluster and slot, how many colours back the previous toucher of
+        // the slot's particle sits (0 = first touch of the sweep: first_mask's bit) and whether this cluster is the last to touch it;
+        // the inverse masses as part of the cluster record; one exchange cell per particle.  The folded particle pass is part of it.
+        const bool allow_one_launch = [] { const char* e = getenv("TETSIM_NH_ONE_LAUNCH"); return !(e && e[0] == '0'); }();   // (read at every creation: tests build both in one process)
+        if (allow_one_launch && h->nh_fold && nl >= 2 && nl <= 255u && nv > 0) {
+            const size_t ncl = mask_off[nl];
+            std::vector<float> slot_im(plan.slot_vid.size(), 0.0f);
+            std::vector<uint2> delta(ncl, make_uint2(0u, 0u));
+            std::vector<uint8_t> last_mask(ncl, 0);
+            std::vector<int32_t> last_colour(nv, -1);
+            std::vector<uint32_t> last_cell(nv, 0);   // (cluster index in mask order, slot) of the latest toucher: index * 8 + slot
+            for (uint32_t l = 0; l < nl; l++) {
+                const uint32_t clusters = mask_off[l + 1] - mask_off[l];
+                for (uint32_t k = 0; k < kClusterVerts; k++)
+                    for (uint32_t i = 0; i < clusters; i++) {
+                        const size_t at = plan.vid_off[l] + static_cast<size_t>(k) * clusters + i;
+                        const int32_t v = plan.slot_vid[at];
+                        if (v < 0) continue;
+                        slot_im[at] = h->h_inv_mass[v];
+                        if (last_colour[v] >= 0) {
+                            const uint32_t back = l - static_cast<uint32_t>(last_colour[v]);
+                            uint2& dl = delta[mask_off[l] + i];
+                            if (k < 4u) dl.x |= back << (8u * k); else dl.y |= back << (8u * (k - 4u));
+                        }
+                        last_colour[v] = static_cast<int32_t>(l);
+                        last_cell[v] = static_cast<uint32_t>((mask_off[l] + i) * 8u + k);
+                    }
+            }
+            for (uint32_t v = 0; v < nv; v++) if (last_colour[v] >= 0) last_mask[last_cell[v] >> 3] |= static_cast<uint8_t>(1u << (last_cell[v] & 7u));
+            float* d_im; uint2* d_delta; uint8_t* d_last; NHSweepColour* d_cols;
+            if ((rc = dev_alloc(h, &d_im, slot_im.size()))) return rc;
+            if ((rc = upload(h, d_im, slot_im))) return rc;
+            if ((rc = dev_alloc(h, &d_delta, delta.size()))) return rc;
+            if ((rc = upload(h, d_delta, delta))) return rc;
+            if ((rc = dev_alloc(h, &d_last, last_mask.size()))) return rc;
+            if ((rc = upload(h, d_last, last_mask))) return rc;
+            std::vector<NHSweepColour> cols(nl);
+            uint32_t blocks = 0;
+            for (uint32_t l = 0; l < nl; l++) {
+                cols[l].L = h->cluster_launch[l];
+                cols[l].slot_im = d_im + plan.vid_off[l];
+                cols[l].delta = d_delta + mask_off[l];
+                cols[l].last_mask = d_last + mask_off[l];
+                cols[l].first_block = blocks;
+                blocks += (h->cluster_launch[l].clusters + 63u) / 64u;
+            }
+            if ((rc = dev_alloc(h, &d_cols, cols.size()))) return rc;
+            if ((rc = upload(h, d_cols, cols))) return rc;
+            NHSweep& w = h->nh_sweep1;
+            w.colours = d_cols; w.ncolours = nl; w.blocks = blocks;
+            if ((rc = dev_alloc(h, &w.exchange, nv))) return rc;
+            HIPCHK(h, hipMemset(w.exchange, 0, static_cast<size_t>(nv) * sizeof(float4)));
+            if ((rc = dev_alloc(h, &w.error, 1))) return rc;
+            HIPCHK(h, hipMemset(w.error, 0, sizeof(uint32_t)));
+            w.timeout_ms = halo_timeout_ms(h);
+            h->nh_one_launch = true;
+        }
     }
     // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle of a body fits one CU's LDS (40 B
     // each) and tetsim_step_n / tetsim_step run a whole call as ONE launch, one workgroup per body (nh_kernels.inc: nh_frame_kernel;
