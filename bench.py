@@ -80,17 +80,20 @@ def parse_args():
     ap.add_argument("--no-replay", action="store_true", help="N = 1: time the dominant kernel in the 180 substeps AFTER the timed region only (rounds 1-3), not over a replay of the timed frames")
     ap.add_argument("--no-beyond-mall", action="store_true", help="N = 1: skip `roofline.beyond_mall` (the 8 M-tet body on this GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the `other_configs` object (BASELINE configs 1, 2, 4)")
-    ap.add_argument("--halo", default="rccl", choices=["rccl", "p2p", "deep"],
-                    help="N > 1: transport of the per-substep ghost exchange of the HEADLINE run -- rccl (default: grouped ncclSend/ncclRecv), p2p "
-                         "(the boundary-particle kernel stores straight into the neighbours' ghost ranges, mapped through HIP IPC) or deep (p2p over a "
-                         "two-layer ghost region: ghosts cross every other substep, TETSIM_FLAG_DEEP_GHOSTS)")
+    ap.add_argument("--halo", default="p2p", choices=["p2p", "rccl", "deep"],
+                    help="N > 1: transport of the per-substep ghost exchange the HEADLINE run starts with -- p2p (default: the boundary-particle kernel stores "
+                         "straight into the neighbours' ghost ranges, mapped through HIP IPC; an RCCL run of the same frames afterwards validates it bit for "
+                         "bit and is reported beside it; a failed vote falls back to RCCL), rccl (RCCL first: grouped ncclSend/ncclRecv, the peer-to-peer "
+                         "halo as a validated second run that may take the headline -- rounds 1-5's order) or deep (p2p over a two-layer ghost region: "
+                         "ghosts cross every other substep, TETSIM_FLAG_DEEP_GHOSTS)")
     ap.add_argument("--p2p-check", default="auto", choices=["auto", "on", "off"],
-                    help="N > 1 with --halo rccl: afterwards repeat the run on a fresh body with the peer-to-peer halo and report its rate and whether its "
-                         "positions equal the RCCL run's bit for bit (`multi_gpu.p2p_halo`); auto = on, except with --fake-ranks")
+                    help="N > 1: the second run over the OTHER transport on a fresh body -- after a peer-to-peer headline the RCCL validator "
+                         "(`multi_gpu.rccl_halo`, `multi_gpu.headline_validated_against_rccl`), with --halo rccl the peer-to-peer run (`multi_gpu.p2p_halo`); "
+                         "auto = on, except with --fake-ranks")
     ap.add_argument("--headline-halo", default="best", choices=["best", "rccl"],
-                    help="N > 1 with --halo rccl and the peer-to-peer check: best (default) = report the faster transport as the headline IF the "
-                         "peer-to-peer run was validated in this run (bit-equal positions, same frames, same protocol), with the RCCL figures beside it "
-                         "in multi_gpu.rccl_halo; rccl = the RCCL run is the headline whatever the check says")
+                    help="--halo rccl only: best (default) = report the faster transport as the headline IF the peer-to-peer run was validated in this run "
+                         "(bit-equal positions, same frames, same protocol), with the RCCL figures beside it in multi_gpu.rccl_halo; rccl = the RCCL run is the "
+                         "headline whatever the check says")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (smoke test)")
     ap.add_argument("--self-spawn", action="store_true",
                     help="launch the rank processes from this process even when --gpus is 1 (what a plain `python bench.py --gpus N`, "

@@ -11,7 +11,7 @@ from .common import CELLS, DT, HBM_PEAK_GBS, PP, ROOT, SUBSTEPS, TET_KERNEL_BYTE
 from .cpu import cpu_baseline
 from .body import make_body, timed_frames
 from .launcher import GUARD
-from .legs import beyond_mall, halo_probe_report, multi_gpu_report, other_configs, p2p_check, promote_p2p, run_neohookean
+from .legs import beyond_mall, demote_p2p, halo_probe_report, multi_gpu_report, other_configs, p2p_check, promote_p2p, run_neohookean, transport_check
 
 
 # How an N-rank headline run may be repeated when a transport fails on the node it meets: each rung rebuilds every rank's body with
@@ -21,15 +21,28 @@ HALO_LADDER = [({}, "flag-synchronised two-queue halo, both chains replayed from
                ({"TETSIM_HALO_GRAPH": "0"}, "the same halo path enqueued eagerly (no graph replay)"),
                ({"TETSIM_HALO_SYNC": "events", "TETSIM_HALO_GRAPH": "0"}, "event-synchronised halo path, eager (round 1's)")]
 
+P2P_RUNG = "peer-to-peer halo (the transport an N-rank run LEADS with): boundary particles stored straight into the neighbours' IPC-mapped ghost ranges, " \
+           "flag-synchronised two-queue path replayed from captured graphs"
+
+
 def headline_with_retries(args, cells, rank, world, local_rank, ranks):
     """The timed region of an N-rank run (timed_frames' protocol: W untimed + K timed frames bracketed by synchronise + barrier), with
-    every local step caught and voted on; on a failure anywhere all ranks close their bodies and climb one rung of HALO_LADDER.
-    Returns (body, verts, tets, pp, nz, wall seconds of this rank, host seconds inside the K calls, [attempt records])."""
+    every local step caught and voted on.  The peer-to-peer halo goes first (--halo p2p, the default: DESIGN.md 7 -- RCCL's grouped
+    send / recv kernel alone is 11-13 us of the halo queue's 30 us cycle); on a failure anywhere all ranks close their bodies and climb
+    down: RCCL with the default settings, then HALO_LADDER's more conservative ones.  Thread-ranks of ONE process (--fake-ranks) cannot
+    step a peer-to-peer halo independently (include/tetsim.h: tetsim_halo_p2p_connect) -- that rung is recorded as skipped.
+    Returns (body, verts, tets, pp, nz, wall seconds of this rank, host seconds inside the K calls, [attempt records], transport used)."""
     attempts = []
     keys = sorted({k for env, _ in HALO_LADDER for k in env} | {"TETSIM_HALO_TIMEOUT_MS"})
     saved = {k: os.environ.get(k) for k in keys}
+    ladder = ([(args.halo, {}, P2P_RUNG + (" over a two-layer ghost region" if args.halo == "deep" else ""))] if args.halo in ("p2p", "deep") else []) + \
+             [("rccl", env, what) for env, what in HALO_LADDER]
+    tried = 0
     try:
-        for rung, (env, what) in enumerate(HALO_LADDER):
+        for halo, env, what in ladder:
+            if halo != "rccl" and args.fake_ranks:
+                attempts.append({"halo": what, "ok": False, "skipped": "thread-ranks of one process cannot step a peer-to-peer halo independently (tetsim_group_step_n would)"})
+                continue
             for k in keys:
                 if k != "TETSIM_HALO_TIMEOUT_MS":
                     os.environ.pop(k, None) if saved[k] is None else os.environ.__setitem__(k, saved[k])
@@ -46,7 +59,7 @@ def headline_with_retries(args, cells, rank, world, local_rank, ranks):
                         state["err"] = "rank %d: %r" % (rank, e)
                 return None
 
-            body, verts, tets, pp, nz, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True)
+            body, verts, tets, pp, nz, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True, halo=halo)
             el = host = 0.0
             if body is None:
                 state["err"] = err
@@ -66,12 +79,13 @@ def headline_with_retries(args, cells, rank, world, local_rank, ranks):
                 fin = local(lambda: bool(np.isfinite(body.pos).all()))
                 if fin is False:
                     state["err"] = "rank %d: non-finite positions after the timed region" % rank
-                if rung == 0 and os.environ.get("TETSIM_BENCH_TEST_FAIL_FIRST_RUNG") == str(rank) and not state["err"]:
+                if tried == 0 and os.environ.get("TETSIM_BENCH_TEST_FAIL_FIRST_RUNG") == str(rank) and not state["err"]:
                     state["err"] = "rank %d: injected failure (test of the retry ladder)" % rank
+            tried += 1
             ok = ranks.min_float(0.0 if state["err"] else 1.0) >= 1.0
             attempts.append({"halo": what, "ok": ok} if ok or not state["err"] else {"halo": what, "ok": False, "error_rank%d" % rank: state["err"][:300]})
             if ok:
-                return body, verts, tets, pp, nz, el, host, attempts
+                return body, verts, tets, pp, nz, el, host, attempts, halo
             if rank == 0:
                 print("[bench] N-rank run failed with: %s -- %s" % (what, state["err"] or "an error on another rank"), file=sys.stderr)
             if body is not None:
@@ -141,8 +155,9 @@ def run(args, rank, world, local_rank, ranks):
         out["library"] = library_info()
         return out, body
     attempts = []
+    used_halo = None
     if use_dist and world > 1:
-        body, verts, tets, pp, nz, elapsed_local, host_local, attempts = headline_with_retries(args, cells, rank, world, local_rank, ranks)
+        body, verts, tets, pp, nz, elapsed_local, host_local, attempts, used_halo = headline_with_retries(args, cells, rank, world, local_rank, ranks)
     else:
         body, verts, tets, pp, nz, _ = make_body(args, cells, args.scaling, rank, world, local_rank, ranks)
         # ---- timed region --------------------------------------------------------------------------------
@@ -180,6 +195,9 @@ def run(args, rank, world, local_rank, ranks):
             out["host_enqueue_us_per_substep"] = round(host_local / (args.steps * SUBSTEPS) * 1e6, 2)
         if mg is not None:
             out["multi_gpu"] = mg
+            if used_halo in ("p2p", "deep"):
+                out["config"]["parallelism"] = "z-slab domain decomposition x%d, peer-to-peer ghost halo per substep%s (RCCL for set-up, the refresh after a dt change and validation)" % (
+                    world, " over a two-layer ghost region" if used_halo == "deep" else "")
     # dominant kernel: its OWN begin/end HIP events (hipExtLaunchKernelGGL) on the handle's stream, inside the real
     # tet -> particle -> tet ... sequence, 60 substeps right after the timed region (same kernels as the graph).  N > 1: every
     # rank takes part (the substeps exchange halos as usual); rank 0 reports ITS interior tet kernel -- the boundary tiles run
@@ -286,7 +304,6 @@ def run(args, rank, world, local_rank, ranks):
         if world == 1 and args.solver == "polar":
             # ... and what a substep costs there INSIDE the graphs (the regime of the timed region: kernels back to back, no per-launch events)
             try:
-                import time
                 t0 = time.perf_counter()
                 for _ in range(10):
                     body.simulateSubsteps(SUBSTEPS, DT, pp)
@@ -385,7 +402,7 @@ def run(args, rank, world, local_rank, ranks):
             if ce is not None:
                 ceil_us = max(ce["memory_floor_us"], ce["valu_issue_floor_us"])
                 out["roofline"]["ceiling"] = dict(ce, ceiling_us=ceil_us, frac_at_ceiling=round(alg / (ceil_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                  kernel_vs_ceiling=round(ceil_us / lead["kernel_us"], 4))
+                                                  kernel_vs_ceiling=round(ceil_us / events_lead["kernel_us"], 4), kernel_vs_ceiling_in_graph=round(ceil_us / lead["kernel_us"], 4))   # (the floors are event-timed: like against like first)
         if equal is not None:
             out["value_reference_threshold"] = round(nt_global * SUBSTEPS * args.steps / equal["elapsed"] / 1e6, 1)
             out["value_reference_threshold_runs"] = [round(nt_global * SUBSTEPS * args.steps / r / 1e6, 1) for r in equal["runs"]]
@@ -461,7 +478,28 @@ def run(args, rank, world, local_rank, ranks):
         hp = halo_probe_report(body, ranks)   # (the body is between steps: the timed region ended with a sync + barrier)
         if rank == 0 and out is not None and "multi_gpu" in out:
             out["multi_gpu"]["halo_exchange_us"] = hp
-    if use_dist and world > 1 and args.halo == "rccl" and (args.p2p_check == "on" or (args.p2p_check == "auto" and not args.fake_ranks)):
+    check = args.p2p_check == "on" or (args.p2p_check == "auto" and not args.fake_ranks)
+    if use_dist and world > 1 and used_halo in ("p2p", "deep") and check:
+        # The headline ran on the peer-to-peer halo.  RCCL is the VALIDATOR: the same frames from the same rest state on a fresh body whose
+        # ghosts travel by grouped ncclSend / ncclRecv must end bit-equal (one-layer ghost regions; the two-layer region has another
+        # rounding path and is compared for finiteness only) -- and its rate stands beside the headline (multi_gpu.rccl_halo).  A run
+        # that is NOT confirmed does not keep the headline: the RCCL figures take it (demote_p2p).
+        try:
+            pos_head = body.pos
+        except Exception:  # noqa: BLE001
+            pos_head = None
+        res = transport_check(args, cells, rank, world, local_rank, ranks, pos_head, nt_global, "rccl")
+        if rank == 0:
+            out["multi_gpu"]["rccl_halo"] = res
+            out["multi_gpu"]["headline_validated_against_rccl"] = bool(isinstance(res, dict) and not res.get("error") and res.get("finite") and (res.get("bit_equal_to_headline_run") or used_halo == "deep"))
+            if demote_p2p(out, res, args.steps, world, exact=used_halo == "p2p"):
+                if pr is None:
+                    out["roofline"] = whole_job_roofline()
+                else:
+                    out["roofline"]["substep_achieved"] = round(b_alg * out["value"] * 1e6 / 1e9, 1)
+                    out["roofline"]["substep_frac"] = round(b_alg * out["value"] * 1e6 / 1e9 / (HBM_PEAK_GBS * world), 4)
+    elif use_dist and world > 1 and used_halo == "rccl" and args.halo == "rccl" and check:
+        # --halo rccl: RCCL first (rounds 1-5's order), the peer-to-peer halo afterwards as a validated second run that may take the headline
         try:
             pos_rccl = body.pos
         except Exception:  # noqa: BLE001
@@ -478,7 +516,7 @@ def run(args, rank, world, local_rank, ranks):
     # ---- BASELINE config 5, literally: the 110^3-cell lattice (7,986,000 tets) cut into N slabs -- strong scaling -----------
     if use_dist and (args.config5 == "on" or (args.config5 == "auto" and world == 8)) and not (args.scaling == "strong" and cells == args.config5_cells):
         # (the headline body stays alive: if this second body cannot be built on some rank, the line above is still reported)
-        body5, v5, t5, pp5, _, err5 = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks, vote=True)
+        body5, v5, t5, pp5, _, err5 = make_body(args, args.config5_cells, "strong", rank, world, local_rank, ranks, vote=True, halo=used_halo)   # (the transport the headline ended up with)
         if body5 is None:
             if rank == 0:
                 out["config5_strong"] = {"error": err5}

@@ -214,23 +214,42 @@ def halo_probe_report(body, ranks):
     """The transfer term of the substep's halo chain on THIS wire: 100 exchanges of the real messages with the real neighbours (a
     collective of the ranks; idempotent).  The chain is  wait V + halo-side tiles + boundary particles (~19 us on one GPU)  +  this.
     Runs under the HeadlineGuard: nothing here may cost the line."""
-    try:
-        from tetsim_amd import halo_probe
-        hp = halo_probe(body, 100)
+    def one(probe, what):
+        # (a local failure is VOTED on before the ranks' reductions: nobody is left alone inside a collective)
+        hp, err = None, None
+        try:
+            hp = probe(body, 100)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:200]
+        if ranks.min_float(0.0 if err else 1.0) < 1.0:
+            return {"error": err or "the probe failed on another rank"}
         return {"rank0": {k: round(v, 1) for k, v in hp.items()}, "median_min_over_ranks": round(ranks.min_float(hp["median"]), 1),
-                "median_max_over_ranks": round(ranks.max_float(hp["median"]), 1),
-                "what": "grouped ncclSend / ncclRecv of this rank's halo messages to its neighbours, events on the halo stream, 100 repetitions between steps"}
-    except Exception as e:  # noqa: BLE001
-        ranks.min_float(0.0); ranks.max_float(0.0)   # (keep the collectives of the ranks in step)
-        return {"error": repr(e)[:200]}
+                "median_max_over_ranks": round(ranks.max_float(hp["median"]), 1), "what": what}
+    from tetsim_amd import comm_info, halo_p2p_probe, halo_probe
+    rep = one(halo_probe, "grouped ncclSend / ncclRecv of this rank's halo messages to its neighbours, events on the halo stream, 100 repetitions between steps")
+    if comm_info(body).get("p2p") and not (body.info.flags & 32):
+        # the run used the peer-to-peer halo: its hand-over on this wire beside RCCL's exchange of the same messages
+        rep = dict(rep, rccl=dict(rep), p2p=one(halo_p2p_probe, "one store into every neighbour's inbox word + one wait on the own ones (tetsim_halo_p2p_probe): the one-way signal "
+                                                                "latency of the peer-to-peer halo on this wire, device clock, 100 repetitions between steps"))
+    return rep
 
 
 def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
-    """The headline run once more on a fresh body whose halo goes peer to peer (include/tetsim.h: tetsim_halo_p2p_connect): the same
-    warm-up and timed frames from the same rest state, so the owned positions must equal the RCCL run's BIT FOR BIT -- on real
-    peers, which the one-GPU tests cannot show -- and the rate says what taking RCCL's send/recv kernel off the substep's chain
-    is worth here.  Every local step is caught and VOTED on (a rank never leaves the others inside a collective), device-side
-    waits are short, one probe substep comes first, and the whole leg sits under the HeadlineGuard's budget."""
+    """--halo rccl: the RCCL headline run once more with the peer-to-peer halo (transport_check); `bit_equal_to_rccl_run` is the name
+    rounds 3-5 used for the comparison."""
+    res = transport_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global, "p2p")
+    if isinstance(res, dict) and "bit_equal_to_headline_run" in res:
+        res["bit_equal_to_rccl_run"] = res["bit_equal_to_headline_run"]
+    return res
+
+
+def transport_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global, halo):
+    """The headline run once more on a fresh body whose halo goes over the OTHER transport (`halo`: "rccl" after a peer-to-peer headline,
+    "p2p" after an RCCL one; include/tetsim.h: tetsim_halo_p2p_connect): the same warm-up and timed frames from the same rest state, so
+    the owned positions must equal the headline run's BIT FOR BIT -- on real peers, which the one-GPU tests cannot show -- and the rate
+    says what RCCL's send/recv kernel on the substep's chain costs here.  Every local step is caught and VOTED on (a rank never leaves
+    the others inside a collective), device-side waits are short, one probe substep comes first, and the whole leg sits under the
+    HeadlineGuard's budget."""
     saved = os.environ.get("TETSIM_HALO_TIMEOUT_MS")
     os.environ["TETSIM_HALO_TIMEOUT_MS"] = "4000"
     state = {"err": None}
@@ -248,7 +267,7 @@ def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
 
     body2 = None
     try:
-        body2, _, _, pp2, _, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True, halo="p2p")
+        body2, _, _, pp2, _, err = make_body(args, cells, args.scaling, rank, world, local_rank, ranks, vote=True, halo=halo)
         if body2 is None:
             return {"error": err}
         local(lambda: (body2.simulate(DT, pp2), body2.sync()))   # a transport that does not work shows here, within seconds
@@ -274,7 +293,7 @@ def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
         el = ranks.max_float(el_local)
         res = {"value": round(nt_global * SUBSTEPS * timed / el / 1e6, 1) if timed > 0 else None, "unit": "M tet-solves/s",
                "ms_per_step": round(el / max(timed, 1) * 1e3, 4), "steps": timed,
-               "bit_equal_to_rccl_run": bool(ranks.min_float(1.0 if same else 0.0) >= 1.0), "finite": bool(ranks.min_float(1.0 if fin else 0.0) >= 1.0),
+               "halo": halo, "bit_equal_to_headline_run": bool(ranks.min_float(1.0 if same else 0.0) >= 1.0), "finite": bool(ranks.min_float(1.0 if fin else 0.0) >= 1.0),
                "ranks_ms_per_step": {"min": round(ranks.min_float(el_local / max(timed, 1) * 1e3), 4), "max": round(ranks.max_float(el_local / max(timed, 1) * 1e3), 4)}}
         if not everyone_ok():
             res["error"] = state["err"] or "a step failed on another rank"
@@ -290,6 +309,24 @@ def p2p_check(args, cells, rank, world, local_rank, ranks, pos_rccl, nt_global):
             os.environ.pop("TETSIM_HALO_TIMEOUT_MS", None)
         else:
             os.environ["TETSIM_HALO_TIMEOUT_MS"] = saved
+
+def demote_p2p(out, res, steps, world, exact=True):
+    """A peer-to-peer headline that its RCCL validator run (`res`, transport_check) does NOT confirm -- positions not bit-equal (exact:
+    one-layer ghost regions), or non-finite -- gives the headline to the RCCL run's figures, measured over the same frames under the same
+    protocol; the unconfirmed figures stay in multi_gpu.p2p_halo_unconfirmed.  A validator that could not run at all (error) leaves the
+    headline where it is, flagged (multi_gpu.headline_validated_against_rccl: false).  Returns whether `out` was changed."""
+    if not isinstance(res, dict) or res.get("error") or not res.get("value") or res.get("steps") != steps:
+        return False
+    if res.get("finite") and (res.get("bit_equal_to_headline_run") or not exact):
+        return False
+    mgr = out["multi_gpu"]
+    mgr["p2p_halo_unconfirmed"] = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "ranks_ms_per_step": mgr.get("ranks_ms_per_step")}
+    out["value"], out["ms_per_step"] = res["value"], res["ms_per_step"]
+    mgr["ranks_ms_per_step"] = res.get("ranks_ms_per_step")
+    mgr["halo"] = "rccl: the peer-to-peer run of the same frames was NOT confirmed by this RCCL run (positions differ or are not finite): the RCCL figures are the headline"
+    out["config"]["parallelism"] = "z-slab domain decomposition x%d, RCCL ghost halo per substep" % world
+    return True
+
 
 def promote_p2p(out, res, steps, world, mode="best"):
     """The headline of an N-rank run is the faster of the two halo transports -- if the peer-to-peer run (`res`, p2p_check) is VALIDATED

@@ -430,6 +430,11 @@ int tetsim_halo_probe(tetsim_handle h, uint32_t reps, double *min_us, double *me
 #define TETSIM_P2P_BLOB_BYTES 512
 int tetsim_halo_p2p_export(tetsim_handle h, void *blob);
 int tetsim_halo_p2p_connect(tetsim_handle h, const void *blobs, uint32_t count);
+/* tetsim_halo_probe's counterpart for the peer-to-peer halo (since ABI 5): `reps` hand-overs with all neighbours at once -- one store
+ * into each neighbour's inbox word, one wait on the own ones, on the halo stream -- timed by the device's wall clock; min / median / max
+ * microseconds per hand-over (one one-way signal latency of this wire; the boundary predictions ride with the same kind of stores).
+ * A collective of all ranks (same reps, the same number of calls), between steps; one-layer ghost regions only. */
+int tetsim_halo_p2p_probe(tetsim_handle h, uint32_t reps, double *min_us, double *median_us, double *max_us);
 /* All partitions of one decomposition living in ONE process (one or several devices): n substeps with the SAME
  * stream/event choreography as the RCCL path -- interior tiles, wait for the previous halo, boundary tiles, boundary
  * particles, start the halo on a second stream, interior particles -- with asynchronous device copies standing in

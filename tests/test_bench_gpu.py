@@ -40,9 +40,17 @@ def test_single_gpu_line():
     assert "bit-equal to the timed one: True" in rf["fast_exit"]["window"] and rf["after_timed_region"]["kernel_us"] > 0
     # ... and the fraction the line LEADS with is the equal-work one: nine rotation iterations per tet (the reference's threshold over the
     # timed frames), the FAST-exit kernel the value ran and the on-floor window beside it, each with its own achieved / frac
-    assert "lies on the floor" in rf["window"] and "nine rotation iterations" in rf["work"] and rf["on_floor"]["frac"] == rf["frac"]
-    assert rf["timed_frames_reference_threshold"]["kernel_us"] >= 0.97 * rf["fast_exit"]["kernel_us"] and d["value_reference_threshold"] > 0
-    assert len(d["value_reference_threshold_runs"]) == 3
+    # (round 6: `frac` itself is that kernel INSIDE the graphs tetsim_step_n replays -- the timed frames' wall clock with the reference's
+    # threshold minus the particle kernel and the launch boundaries --, the per-launch event figure on the floor beside it as frac_events)
+    rt = rf["timed_frames_reference_threshold"]
+    assert "AS GRAPH REPLAYS" in rf["window"] and "nine rotation iterations" in rf["work"] and rf["frac"] == rt["in_graph"]["frac_implied"]
+    assert rf["frac_events"] == rf["on_floor"]["frac"] and "lies on the floor" in rf["window_events"] and rf["kernel_us"] == rt["in_graph"]["kernel_us_implied"]
+    assert rt["kernel_us"] >= 0.97 * rf["fast_exit"]["kernel_us"] and d["value_reference_threshold"] > 0
+    assert len(d["value_reference_threshold_runs"]) == 3 and 0 < rf["frac_substep_reference_threshold"] < 1
+    # the lean tet record beside the reference formulation: its own value, its own B_alg, its own roofline object
+    rl = d["roofline_lean"]
+    assert d["value_lean"] > 0 and d["value_lean_reference_threshold"] > 0 and len(d["value_lean_runs"]) == 3 and rl["alg_bytes_per_tet"] == 92.0
+    assert rl["kernel"] == "pjb_tet_kernel_lean" and rl["finite"] is True and abs(rl["frac"] - rl["achieved"] / 8000.0) < 1e-3 and rl["on_floor"]["kernel_us"] > 0
 
 
 def test_headline_line_carries_every_baseline_config():
@@ -54,15 +62,16 @@ def test_headline_line_carries_every_baseline_config():
     assert "bit-equal to the timed one: True" in rf["fast_exit"]["window"] and "(60 launches)" in rf["fast_exit"]["window"]
     rt = rf["timed_frames_reference_threshold"]
     assert "(60 launches)" in rt["window"] and rt["in_graph"]["substep_us"] > rt["kernel_us"] and rf["on_floor"]["in_graph"]["kernel_us_implied"] > 0
-    # equal work leads (the on-floor window); the reference-threshold kernel is never faster than the FAST-exit one by more than noise, and
-    # the value with the reference's threshold stands at top level next to `value`
-    assert rf["frac"] == rf["on_floor"]["frac"] and rt["frac"] <= rf["fast_exit"]["frac"] * 1.03 and 0 < d["value_reference_threshold"] <= d["value"] * 1.05
+    # equal work leads, as the product runs it (in graphs); the reference-threshold kernel is never faster than the FAST-exit one by more than
+    # noise, and the value with the reference's threshold stands at top level next to `value`; the lean record is faster than either
+    assert rf["frac"] == rt["in_graph"]["frac_implied"] <= rf["frac_events"] * 1.02 and rt["frac"] <= rf["fast_exit"]["frac"] * 1.03 and 0 < d["value_reference_threshold"] <= d["value"] * 1.05
+    assert d["value_lean"] > d["value"] and d["value_lean_reference_threshold"] > d["value_reference_threshold"] and d["roofline_lean"]["kernel_us"] < rf["kernel_us"]
     # the committed rocprofv3 summary of this command and the kernel's ceiling, keyed to the kernel build they were taken on
     meta = json.load(open(os.path.join(ROOT, "profiles", "bench_kernel_stats.json")))
     assert rf["rocprof"]["file"] == "profiles/" + meta["csv"] and rf["rocprof"]["stale"] == (meta["kernel_sha"] != d["library"]["kernel_sha"])
     assert abs(rf["frac_rocprof"] - rf["alg_bytes_per_launch"] / (rf["rocprof"]["kernel_us"] * 1e-6) / 1e9 / 8000.0) < 1e-3
     ce = rf["ceiling"]
-    assert ce["ceiling_us"] == max(ce["memory_floor_us"], ce["valu_issue_floor_us"]) and 0.5 < ce["kernel_vs_ceiling"] <= 1.0
+    assert ce["ceiling_us"] == max(ce["memory_floor_us"], ce["valu_issue_floor_us"]) and 0.5 < ce["kernel_vs_ceiling"] <= 1.0   # (against the event figure: the floors are event-timed)
     chk = d["roofline"]["timed_region_check"]      # the replayed kernels fit the timed region's own wall clock: what is left are two launch boundaries
     assert 0.0 < chk["two_launch_boundaries_us"] < 0.35 * chk["substep_us"] and abs(chk["substep_us"] - d["ms_per_step"] * 1e3 / 20) < 0.01
     oc = d["other_configs"]
@@ -105,8 +114,13 @@ def test_a_failed_n_rank_run_is_repeated_with_more_conservative_halo_settings():
              env={"TETSIM_RCCL_LIB": _mock_rccl(), "TETSIM_BENCH_TEST_FAIL_FIRST_RUNG": "1"})
     assert REQUIRED <= set(d) and d["n_gpus"] == 3 and d["value"] > 0
     att = d["multi_gpu"]["halo_attempts"]
-    assert len(att) == 2 and att[0]["ok"] is False and att[1]["ok"] is True and "eagerly" in att[1]["halo"]
-    assert d["multi_gpu"]["rccl_ranks"] == 3
+    # the order of an N-rank run (round 6): the peer-to-peer halo first -- thread-ranks of one process cannot step it independently: recorded
+    # as skipped --, then RCCL with the default settings (the injected failure), then RCCL enqueued eagerly
+    assert len(att) == 3 and "peer-to-peer" in att[0]["halo"] and "skipped" in att[0] and att[1]["ok"] is False and "injected" in att[1]["error_rank1"] and att[2]["ok"] is True and "eagerly" in att[2]["halo"]
+    assert d["multi_gpu"]["rccl_ranks"] == 3 and d["multi_gpu"]["halo"].startswith("rccl")
+    # --halo rccl: RCCL first, no peer-to-peer rung at all
+    d = _run(["--fake-ranks", "3", "--cells", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--halo", "rccl"], env={"TETSIM_RCCL_LIB": _mock_rccl()})
+    assert "halo_attempts" not in d["multi_gpu"] and "RCCL ghost halo" in d["config"]["parallelism"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--profile-ranks"], ["--scaling", "strong"], ["--config5", "on", "--config5-cells", "18"]])

@@ -94,7 +94,7 @@ SYMBOLS = [
     "tetsim_library_info", "tetsim_read_quats_pinned", "tetsim_state_size", "tetsim_save_state", "tetsim_load_state",
     "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
-    "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh", "tetsim_get_visual_ids", "tetsim_halo_refresh_final", "tetsim_group_refresh_final", "tetsim_halo_probe",
+    "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh", "tetsim_get_visual_ids", "tetsim_halo_refresh_final", "tetsim_group_refresh_final", "tetsim_halo_probe", "tetsim_halo_p2p_probe",
     "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth", "tetsim_measure_stream_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
@@ -161,6 +161,7 @@ def lib():
     L.tetsim_get_visual_ids.argtypes = [H, C.POINTER(C.c_int32)]
     L.tetsim_halo_refresh_final.argtypes = [H]
     L.tetsim_halo_probe.argtypes = [H, u32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tetsim_halo_p2p_probe.argtypes = [H, u32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tetsim_group_refresh_final.argtypes = [C.POINTER(H), u32]
     L.tetsim_set_visual_triangles.argtypes = [H, ip, u32]
     L.tetsim_read_visual_vertex_normals.argtypes = [H, fp]

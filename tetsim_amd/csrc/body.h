@@ -250,6 +250,7 @@ struct tetsim_body {
     float4* own_g2_even[2] = {nullptr, nullptr};
     float4* own_g2_odd[2] = {nullptr, nullptr};
     std::vector<PeerLink> links;          // parallel to `neigh`
+    uint32_t p2p_probe_base = 0;          // tetsim_halo_p2p_probe: the inbox words count on from here (every rank calls it the same number of times)
     uint64_t p2p_round = 0;               // substeps enqueued since the connection; its parity selects the buffers
     bool p2p_raise_pending = false;       // the last boundary-particle kernel's "arrived" has not been raised yet (no kernel behind it)
     bool halo_pending = false;            // a halo was started and nobody has waited for it yet

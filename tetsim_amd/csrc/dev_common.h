@@ -294,7 +294,10 @@ void util_launch_copy(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 // streaming probe (tetsim_measure_stream_bandwidth): kind 0 copy / 1 read only / 2 write only, nt = non-temporal accesses, unroll = 4 or 8
 // independent 16-byte accesses per lane, grid = workgroups (0: one per chunk of 256 x unroll float4s)
 void util_launch_stream(hipStream_t s, int kind, bool nt, uint32_t unroll, uint32_t grid, const float4* src, float4* dst, uint64_t n);
-void util_launch_delay(hipStream_t s, uint32_t us);   // loopback measurements: a stand-in for wire latency
+void util_launch_delay(hipStream_t s, uint32_t us);
+// tetsim_halo_p2p_probe: raise[k] = this rank's inbox word at neighbour k (peer memory), wait[k] = neighbour k's inbox word here
+struct P2PProbe { uint32_t* raise[kMaxPeers] = {}; uint32_t* wait[kMaxPeers] = {}; uint32_t n = 0; };
+void util_launch_p2p_probe(hipStream_t s, const P2PProbe& p, uint32_t base, uint32_t reps, unsigned long long* ticks, uint32_t* error, uint32_t timeout_ms);   // loopback measurements: a stand-in for wire latency
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 
 

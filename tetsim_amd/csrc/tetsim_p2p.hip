@@ -208,6 +208,7 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     h->links = std::move(links);
     h->p2p = true;
     h->p2p_round = 0;
+    h->p2p_probe_base = 0;
     h->p2p_raise_pending = false;
     h->fold_wait = h->fold_possible;   // (between calls: nothing is pending, the captured chains are dropped below)
     {   // ... and the halo queue's wait kernel goes into the halo-side tiles (tetsim_halo.hip: enqueue_phase_a), one-layer ghost regions only
@@ -216,6 +217,46 @@ int tetsim_halo_p2p_connect(tetsim_handle h, const void* blobs, uint32_t count) 
     }
     h->halo_warm = false;     // the first call after the connection runs eagerly (its first substep has no "arrived" to wait for)
     drop_flag_graphs(h);
+    return 0;
+}
+
+// The peer-to-peer halo's transfer term on THIS wire, measured like tetsim_halo_probe measures RCCL's: `reps` hand-overs with all
+// neighbours at once (a store into each neighbour's inbox word, a wait on the own ones -- the words behind the "arrived" words of a
+// one-layer body, unused otherwise), one wave on the halo stream, stamped by the device's 100 MHz clock.  A repetition costs one one-way
+// signal latency; the payload (the boundary predictions, tetsim_comm_info's bytes) rides with the same stores in a real substep.
+// A collective: every rank calls it with the same reps, between steps, the same number of times.
+int tetsim_halo_p2p_probe(tetsim_handle h, uint32_t reps, double* min_us, double* median_us, double* max_us) {
+    if (!h || !min_us || !median_us || !max_us || reps == 0 || reps > 4096) return fail(h, TETSIM_EINVAL, "bad argument");
+    if (!h->p2p || !h->d_arrived || !h->comm_stream) return fail(h, TETSIM_ESTATE, "no peer-to-peer halo on this body (tetsim_halo_p2p_connect)");
+    if (h->deep) return fail(h, TETSIM_ESTATE, "bodies with a two-layer ghost region use all their hand-over words");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    P2PProbe p;
+    for (size_t k = 0; k < h->neigh.size() && k < kMaxPeers; k++) {
+        if (!h->links[k].arrived[0] || !h->neigh[k].recv_count) continue;
+        p.raise[p.n] = h->links[k].arrived[0] + 2u * kMaxPeers;     // (arrived[0] = the neighbour's word array + this rank's slot there)
+        p.wait[p.n] = h->d_arrived + 2u * kMaxPeers + k;
+        p.n++;
+    }
+    *min_us = *median_us = *max_us = 0.0;
+    if (p.n == 0) return 0;
+    unsigned long long* d_ticks = nullptr;
+    uint32_t* d_err = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&d_ticks), reps * sizeof(unsigned long long)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_err), sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_ticks); return fail(h, TETSIM_ENOMEM, "hipMalloc"); }
+    (void)hipMemset(d_err, 0, sizeof(uint32_t));
+    util_launch_p2p_probe(h->comm_stream, p, h->p2p_probe_base, reps, d_ticks, d_err, halo_timeout_ms(h));
+    h->p2p_probe_base += reps;
+    std::vector<unsigned long long> ticks(reps);
+    uint32_t err = 0;
+    const bool ok = hipStreamSynchronize(h->comm_stream) == hipSuccess && hipMemcpy(ticks.data(), d_ticks, reps * sizeof(ticks[0]), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(&err, d_err, sizeof err, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_ticks); (void)hipFree(d_err);
+    if (!ok) return fail(h, TETSIM_EHIP, "tetsim_halo_p2p_probe: the probe kernel failed");
+    if (err) return fail(h, TETSIM_ECOMM, "tetsim_halo_p2p_probe: a neighbour's hand-over did not arrive in time (every rank calls the probe together, with the same reps)");
+    std::sort(ticks.begin(), ticks.end());
+    *min_us = ticks.front() / 100.0; *median_us = ticks[reps / 2] / 100.0; *max_us = ticks.back() / 100.0;
     return 0;
 }
 

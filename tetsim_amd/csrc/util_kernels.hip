@@ -97,8 +97,32 @@ __global__ void delay_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// tetsim_halo_p2p_probe: `reps` hand-overs with every neighbour at once -- lane k stores base + r into neighbour k's inbox word for this
+// rank (peer memory, system scope) and waits for the neighbour's base + r in its own inbox; thread 0 stamps every repetition with the
+// 100 MHz wall clock.  With every rank in the same loop a repetition costs ONE one-way signal latency (both directions travel at once).
+__global__ void p2p_probe_kernel(P2PProbe p, uint32_t base, uint32_t reps, unsigned long long* ticks, uint32_t* error, uint32_t timeout_ms) {
+    const uint32_t k = threadIdx.x;
+    const long long limit = 100000ll * timeout_ms;
+    for (uint32_t r = 1; r <= reps; r++) {
+        const long long t0 = wall_clock64();
+        if (k < p.n) {
+            __hip_atomic_store(p.raise[k], base + r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            while (__hip_atomic_load(p.wait[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (base + r) > 0x7fffffffu) {   // (wrap-safe "<")
+                __builtin_amdgcn_s_sleep(1);
+                if (limit && wall_clock64() - t0 > limit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long long t1 = wall_clock64();
+        if (k == 0) ticks[r - 1u] = static_cast<unsigned long long>(t1 - t0);
+    }
+}
+
 }  // namespace
 
+void util_launch_p2p_probe(hipStream_t s, const P2PProbe& p, uint32_t base, uint32_t reps, unsigned long long* ticks, uint32_t* error, uint32_t timeout_ms) {
+    hipLaunchKernelGGL(p2p_probe_kernel, dim3(1), dim3(64), 0, s, p, base, reps, ticks, error, timeout_ms);
+}
 void util_launch_delay(hipStream_t s, uint32_t us) {
     if (us) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, 100ll * us);
 }

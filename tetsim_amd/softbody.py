@@ -402,6 +402,14 @@ def halo_probe(body, reps=100):
     return {"min": a.value, "median": b.value, "max": c.value}
 
 
+def halo_p2p_probe(body, reps=100):
+    """{min, median, max} microseconds of one hand-over of the peer-to-peer halo with all neighbours at once (a collective of all ranks,
+    between steps; include/tetsim.h: tetsim_halo_p2p_probe)."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    capi.check(capi.lib().tetsim_halo_p2p_probe(body._h, int(reps), C.byref(a), C.byref(b), C.byref(c)), body._h)
+    return {"min": a.value, "median": b.value, "max": c.value}
+
+
 def comm_unique_id():
     """128-byte RCCL unique id (rank 0 creates it; the host distributes it to every rank)."""
     buf = (C.c_char * 128)()
