@@ -174,6 +174,7 @@ typedef struct TetSimInfo {
                                      4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles (PRECISE: and 12,288 tets): they all
                                      fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE launch of one workgroup (one per body of a batch)
                                      (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit */
+    uint32_t total_vis_verts;    /* rows of the visVerts the caller attached (num_vis_verts of them are this handle's: all, unless partitioned); since ABI 5 */
 } TetSimInfo;
 
 /* per-kernel HIP-event timing of eagerly launched substeps (tetsim_profile) */
@@ -336,6 +337,19 @@ int tetsim_set_visual_triangles(tetsim_handle h, const int32_t *tri_ids, uint32_
  * 1/(length || 1) in f64 and stored f32.  Each vertex gathers its triangles in that order, so the result equals the
  * reference's bit for bit (golden recorded from three.js).  normals_out [3*nvis].  Synchronises. */
 int tetsim_read_visual_vertex_normals(tetsim_handle h, float *normals_out);
+/* PARTITIONED bodies (since ABI 5): tetsim_set_visual_triangles takes the same, GLOBAL triangle list on every rank (ids = rows of the
+ * caller's visVerts) and keeps, for each row the partition skins, that row's triangles in triangle order.  A triangle's corners may be
+ * skinned by different ranks, so the normals are computed from the ranks' skins put together: the host scatters every rank's
+ * tetsim_read_visual_mesh rows by tetsim_get_visual_ids into one [3 * rows of visVerts] array (it needs that array to draw anyway) and
+ * every rank calls tetsim_visual_vertex_normals_from with it -> normals_out [3*num_vis_verts], this rank's rows.  Per vertex the same
+ * face normals are added in the same order as in the unpartitioned body: scattered by row, the ranks' normals equal
+ * tetsim_read_visual_vertex_normals of the unpartitioned body bit for bit (Softbody.js:259-277).  tetsim_read_visual_vertex_normals
+ * itself refuses partitions.  An unpartitioned body may call it too (normals of any positions of its visual mesh). */
+int tetsim_visual_vertex_normals_from(tetsim_handle h, const float *all_positions, float *normals_out);
+/* The partitions of one process, all at once: every member skins its rows (after tetsim_group_refresh_final), the rows are put
+ * together, every member computes its rows' normals from the whole.  positions_out / normals_out [3 * rows of visVerts]; either may be
+ * NULL. */
+int tetsim_group_read_visual_vertex_normals(tetsim_handle *handles, uint32_t count, float *positions_out, float *normals_out);
 
 /* --- grab (Softbody.js:279-298 ; SoftbodyGPU.js:692-712) --------------------------------------- */
 

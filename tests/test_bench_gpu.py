@@ -116,7 +116,7 @@ def test_a_failed_n_rank_run_is_repeated_with_more_conservative_halo_settings():
     att = d["multi_gpu"]["halo_attempts"]
     # the order of an N-rank run (round 6): the peer-to-peer halo first -- thread-ranks of one process cannot step it independently: recorded
     # as skipped --, then RCCL with the default settings (the injected failure), then RCCL enqueued eagerly
-    assert len(att) == 3 and "peer-to-peer" in att[0]["halo"] and "skipped" in att[0] and att[1]["ok"] is False and "injected" in att[1]["error_rank1"] and att[2]["ok"] is True and "eagerly" in att[2]["halo"]
+    assert len(att) == 3 and "peer-to-peer" in att[0]["halo"] and "skipped" in att[0] and att[1]["ok"] is False and "default" in att[1]["halo"] and att[2]["ok"] is True and "eagerly" in att[2]["halo"]
     assert d["multi_gpu"]["rccl_ranks"] == 3 and d["multi_gpu"]["halo"].startswith("rccl")
     # --halo rccl: RCCL first, no peer-to-peer rung at all
     d = _run(["--fake-ranks", "3", "--cells", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--halo", "rccl"], env={"TETSIM_RCCL_LIB": _mock_rccl()})

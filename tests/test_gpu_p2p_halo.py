@@ -130,6 +130,13 @@ dt = (1.0 / 60.0) / 20
 for n in (20, 1, 7, 20, 3):
     body.simulateSubsteps(n, dt, pp)
 body.sync()
+dist.barrier()
+from tetsim_amd import halo_p2p_probe
+for _ in range(2):                                                         # the hand-over on this "wire" (one GPU: its own memory), twice: the inbox words count on
+    hp = halo_p2p_probe(body, 50)
+    assert 0.0 < hp["min"] <= hp["median"] <= hp["max"] < 5000.0, hp
+body.simulateSubsteps(4, dt, pp)                                           # ... and the halo's own words are untouched by it
+body.sync()
 np.save(os.path.join(out, "ids%d.npy" % rank), body.ownedIds)
 np.save(os.path.join(out, "pos%d.npy" % rank), body.pos)
 dist.barrier()                                                             # keep the mappings alive until every rank has finished stepping
@@ -160,7 +167,7 @@ def test_two_processes_share_one_gpu_through_ipc_mappings(tmp_path):
     v, t = make_lattice(cells, y0=0.02)
     owner = np.minimum((np.arange(len(v)) // (cells + 1) ** 2) * 2 // (cells + 1), 1).astype(np.int32)
     ref = _parts(v, t, 2, owner)
-    for n in (20, 1, 7, 20, 3):
+    for n in (20, 1, 7, 20, 3, 4):
         group_step_n(ref, n, DT, PP)
     want = _gather(ref, len(v))
     got = np.empty_like(want)

@@ -5,11 +5,13 @@
   continues bit for bit -- over the copy transport and over the peer-to-peer halo, saved on an odd substep parity too.
 * the embedded visual mesh on a partition (missing #3; SoftbodyGPU.js:424-448, Softbody.js:259-277): every partition skins the
   visual vertices whose tet it owns; the union equals the unpartitioned body's skin bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import load_f32, load_mesh
-from tetsim_amd import SoftBodyHIP, TetSimError, group_p2p_connect, group_refresh_final, group_step_n, make_lattice
+from conftest import GOLDEN, load_f32, load_mesh
+from tetsim_amd import SoftBodyHIP, TetSimError, group_p2p_connect, group_refresh_final, group_step_n, group_visual_vertex_normals, make_lattice
 
 pytestmark = pytest.mark.gpu
 PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, volCompliance=0.0,
@@ -139,12 +141,33 @@ def test_the_partitions_skins_add_up_to_the_whole_visual_mesh(mesh, parts, preci
         assert _same(pos, mp) and _same(nrm, mn)
     else:
         assert np.abs(pos - mp).max() < 1e-4 and np.abs(nrm - mn).max() < 1e-3
+    # computeVertexNormals (Softbody.js:259-277) on the partitioned body: every rank takes the same, global triangle list; a triangle's
+    # corners may be skinned by different ranks, so each rank computes ITS rows' normals from the ranks' skins put together -- per vertex
+    # the same face normals in the same order as unpartitioned: bit for bit
+    if mesh == "dragon":
+        tris = np.fromfile(os.path.join(GOLDEN, "dragon_vistris.u16"), dtype="<u2").astype(np.int32).reshape(-1, 3)   # Dragon.js dragonAttachedTriIds
+    else:
+        tris = rng.integers(0, len(vis), size=(30000, 3)).astype(np.int32)     # (any triangles: corners all over the partitions, degenerate ones included)
+    for b in bodies:
+        b.setVisualTriangles(tris)
+    mono.setVisualTriangles(tris)
+    gpos, gnrm = group_visual_vertex_normals(bodies, len(vis))
+    assert _same(gpos, pos)
+    assert _same(gnrm, mono.visualVertexNormalsFrom(pos))           # the unpartitioned body's kernel on the same positions
+    if precision == "precise":
+        assert _same(gnrm, mono.visualVertexNormals())              # ... and on its own: the partitions equal it bit for bit
+    own = np.empty_like(gnrm)
+    for b in bodies:                                                # the rank-by-rank form (what ranks of different processes do)
+        own[b.visualIds] = b.visualVertexNormalsFrom(pos)
+    assert _same(own, gnrm)
+    with pytest.raises(TetSimError, match="put the ranks' skins together"):
+        bodies[0].visualVertexNormals()
     # stepping makes the fetched positions stale again
     group_step_n(bodies, 1, DT, PP)
     with pytest.raises(TetSimError, match="stale"):
         next(b for b in bodies if b.info.num_neighbours).visualPositions()
-    with pytest.raises(TetSimError, match="unpartitioned"):
-        bodies[0].setVisualTriangles(np.array([[0, 1, 2]], np.int32))
+    with pytest.raises(TetSimError, match="stale"):
+        group_visual_vertex_normals(bodies, len(vis))
 
 
 def test_a_group_outlives_a_member_without_touching_it():

@@ -32,7 +32,7 @@ def test_addon_loads_and_fails_loudly_without_gpu():
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120).stdout
     assert ("KEYS batchLayout,commInit,commUniqueId,create,createBatch,createFromFile,destroy,groupRefreshFinal,groupStepN,haloRefreshFinal,info,libraryInfo,load,loadState,mapPositions,mapQuats,ownedIds,partition,partitionQuality,readMesh,"
             "readPositions,readQuats,readVelocities,readVisualMesh,readVisualVertexNormals,readVolError,refreshPositions,refreshQuats,saveState,"
-            "setGrab,setVisualMesh,setVisualTriangles,startGrab,step,stepN,sync,visualIds") in out
+            "setGrab,setVisualMesh,setVisualTriangles,startGrab,step,stepN,sync,visualIds,visualVertexNormalsFrom") in out
     assert "ABI 5" in out
     owners = out.split("OWNERS ")[1].split()[0]
     assert len(owners) == 5 and set(owners) == {"0", "1"} and "QUALITY " in out   # the partitioner through N-API: one owner per particle, both parts used

@@ -44,7 +44,7 @@ class TetSimInfo(C.Structure):
                 ("num_levels", C.c_uint32), ("max_valence", C.c_uint32), ("dropped_slots", C.c_uint32),
                 ("num_neighbours", C.c_uint32), ("device_bytes", C.c_uint64), ("solver", C.c_int32),
                 ("precision", C.c_int32), ("order", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("num_vis_verts", C.c_uint32), ("num_bodies", C.c_uint32), ("fused_particle_pass", C.c_uint32)]
+                ("num_vis_verts", C.c_uint32), ("num_bodies", C.c_uint32), ("fused_particle_pass", C.c_uint32), ("total_vis_verts", C.c_uint32)]
 
 
 class TetSimProfile(C.Structure):
@@ -95,7 +95,7 @@ SYMBOLS = [
     "tetsim_read_positions", "tetsim_read_positions_pinned", "tetsim_read_prev_positions", "tetsim_read_velocities", "tetsim_read_quats",
     "tetsim_read_vol_error", "tetsim_write_state", "tetsim_get_owned_ids", "tetsim_get_local_tets",
     "tetsim_get_tet_order", "tetsim_get_level_offsets", "tetsim_read_inv_mass", "tetsim_set_visual_mesh", "tetsim_get_visual_ids", "tetsim_halo_refresh_final", "tetsim_group_refresh_final", "tetsim_halo_probe", "tetsim_halo_p2p_probe",
-    "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_set_grab",
+    "tetsim_read_visual_mesh", "tetsim_set_visual_triangles", "tetsim_read_visual_vertex_normals", "tetsim_visual_vertex_normals_from", "tetsim_group_read_visual_vertex_normals", "tetsim_set_grab",
     "tetsim_start_grab", "tetsim_nearest_particle", "tetsim_profile", "tetsim_time_kernels", "tetsim_time_step_n", "tetsim_measure_copy_bandwidth", "tetsim_measure_stream_bandwidth",
     "tetsim_comm_unique_id", "tetsim_comm_init", "tetsim_comm_info", "tetsim_comm_selftest", "tetsim_comm_probe", "tetsim_group_step_n", "tetsim_halo_exchange_local", "tetsim_get_halo_plan",
     "tetsim_halo_p2p_export", "tetsim_halo_p2p_connect",
@@ -165,6 +165,8 @@ def lib():
     L.tetsim_group_refresh_final.argtypes = [C.POINTER(H), u32]
     L.tetsim_set_visual_triangles.argtypes = [H, ip, u32]
     L.tetsim_read_visual_vertex_normals.argtypes = [H, fp]
+    L.tetsim_visual_vertex_normals_from.argtypes = [H, fp, fp]
+    L.tetsim_group_read_visual_vertex_normals.argtypes = [C.POINTER(H), u32, fp, fp]
     L.tetsim_set_grab.argtypes = [H, i32, fp]
     L.tetsim_start_grab.argtypes = [H, fp, ip]
     L.tetsim_profile.argtypes = [H, u32, dbl, PP, C.POINTER(TetSimProfile)]

@@ -260,6 +260,8 @@ struct tetsim_body {
     SkinDev skin;  // embedded visual mesh
     std::vector<int32_t> vis_global;   // row of the caller's visVerts behind each attached visual vertex (a partition keeps the rows of the tets it owns)
     bool vis_attached = false;
+    uint32_t vis_total = 0;            // rows of the caller's visVerts (a partition keeps num_vis_verts of them)
+    float4* d_vis_full = nullptr;      // partitions with visual triangles: every rank's skin put together, [vis_total] (tetsim_visual_vertex_normals_from)
     float* pinned_pos = nullptr;   // tetsim_read_positions_pinned: host-pinned xyz
     float* d_packed = nullptr;     //   and its device-side staging
     float* pinned_quat = nullptr;  // tetsim_read_quats_pinned: host-pinned xyzw per local tet

@@ -282,6 +282,9 @@ struct SkinDev {
     const uint32_t* vt_off = nullptr;   // [nvis + 1]
     const uint32_t* vt_tri = nullptr;   // triangle ids (a triangle listing a vertex twice appears twice)
     float4* out_vnrm = nullptr;
+    // partitions: `tri` holds rows of the caller's GLOBAL visVerts and the positions come from tri_pos [global rows] (the ranks' skins put
+    // together: tetsim_visual_vertex_normals_from); null = out_pos (an unpartitioned body's own skin)
+    const float4* tri_pos = nullptr;
 };
 // js_order: Softbody.js:259-277 arithmetic (f64 accumulate, f32 store per step); else SoftbodyGPU.js:431-435 (f32)
 void skin_launch(hipStream_t s, const SkinDev& d, const float4* pos, const float4* quat, bool js_order);

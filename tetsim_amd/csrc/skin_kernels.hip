@@ -55,9 +55,10 @@ __global__ __launch_bounds__(256) void vertex_normals_kernel(SkinDev d) {
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
     if (v >= d.nvis) return;
     float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    const float4* const P = d.tri_pos ? d.tri_pos : d.out_pos;
     for (uint32_t q = d.vt_off[v]; q < d.vt_off[v + 1]; q++) {
         const int4 t = d.tri[d.vt_tri[q]];
-        const float4 a = d.out_pos[t.x], b = d.out_pos[t.y], c = d.out_pos[t.z];
+        const float4 a = P[t.x], b = P[t.y], c = P[t.z];
         const double cbx = static_cast<double>(c.x) - static_cast<double>(b.x), cby = static_cast<double>(c.y) - static_cast<double>(b.y),
                      cbz = static_cast<double>(c.z) - static_cast<double>(b.z);
         const double abx = static_cast<double>(a.x) - static_cast<double>(b.x), aby = static_cast<double>(a.y) - static_cast<double>(b.y),

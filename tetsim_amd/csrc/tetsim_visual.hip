@@ -88,8 +88,10 @@ int tetsim_set_visual_mesh(tetsim_handle h, const float* vis_verts, uint32_t nvi
     k.corner = dc; k.weight = dw; k.qidx = dq; k.normal0 = dn;
     k.nvis = nk;
     h->vis_global = kept;
+    h->vis_total = nvis;
     h->vis_attached = true;
     h->info.num_vis_verts = nk;
+    h->info.total_vis_verts = nvis;
     return 0;
 }
 
@@ -130,26 +132,35 @@ int tetsim_read_visual_mesh(tetsim_handle h, float* positions_out, float* normal
 
 int tetsim_set_visual_triangles(tetsim_handle h, const int32_t* tri_ids, uint32_t ntri) {
     if (!h || (ntri && !tri_ids)) return fail(h, TETSIM_EINVAL, "null argument");
-    if (h->partitioned) return fail(h, TETSIM_ESTATE, "visual triangles (computeVertexNormals) are supported on unpartitioned bodies only: a triangle's corners may be "
-                                                      "skinned by different partitions; partitions deliver the quaternion-rotated normals of tetsim_read_visual_mesh");
-    if (!h->skin.nvis) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
+    if (!h->vis_attached) return fail(h, TETSIM_ESTATE, "no visual mesh attached (tetsim_set_visual_mesh)");
     if (h->skin.vt_off) return fail(h, TETSIM_ESTATE, "visual triangles are already attached");
     HIPCHK(h, hipSetDevice(h->opt.device));
-    const uint32_t nvis = h->skin.nvis;
+    // A PARTITION takes the same, global triangle list on every rank (ids = rows of the caller's visVerts) and keeps, for each row it
+    // skins, that row's triangles in triangle order: a triangle's other corners may be skinned by other ranks, so the normals are computed
+    // from the ranks' skins put together (tetsim_visual_vertex_normals_from) -- per vertex the same sums in the same order as unpartitioned.
+    const bool part = h->partitioned;
+    const uint32_t nrows = part ? h->vis_total : h->skin.nvis;      // what a triangle id may address
+    const uint32_t nvis = h->skin.nvis;                              // the rows this handle computes normals for
+    std::vector<int32_t> row_of;                                     // partitions: global row -> own row, or -1
+    if (part) {
+        row_of.assign(nrows, -1);
+        for (uint32_t j = 0; j < nvis; j++) row_of[h->vis_global[j]] = static_cast<int32_t>(j);
+    }
+    auto own = [&](int32_t g) { return part ? row_of[g] : g; };
     std::vector<int4> tri(ntri);
     std::vector<uint32_t> off(nvis + 1, 0);
     for (uint32_t t = 0; t < ntri; t++) {
         for (int k = 0; k < 3; k++) {
             const int32_t v = tri_ids[3 * t + k];
-            if (v < 0 || static_cast<uint32_t>(v) >= nvis) return fail(h, TETSIM_EINVAL, "triangle " + std::to_string(t) + " references a visual vertex outside the mesh");
-            off[v + 1]++;
+            if (v < 0 || static_cast<uint32_t>(v) >= nrows) return fail(h, TETSIM_EINVAL, "triangle " + std::to_string(t) + " references a visual vertex outside the mesh");
+            if (own(v) >= 0) off[own(v) + 1]++;
         }
         tri[t] = make_int4(tri_ids[3 * t], tri_ids[3 * t + 1], tri_ids[3 * t + 2], 0);
     }
     for (uint32_t v = 0; v < nvis; v++) off[v + 1] += off[v];
-    std::vector<uint32_t> ent(3ull * ntri), fill(off.begin(), off.end() - 1);
+    std::vector<uint32_t> ent(off[nvis]), fill(off.begin(), off.end() - 1);
     for (uint32_t t = 0; t < ntri; t++)   // triangle order, corner order: the order of the reference's accumulation
-        for (int k = 0; k < 3; k++) ent[fill[tri_ids[3 * t + k]]++] = t;
+        for (int k = 0; k < 3; k++) { const int32_t o = own(tri_ids[3 * t + k]); if (o >= 0) ent[fill[o]++] = t; }
     SkinDev& k = h->skin;
     int4* dt; uint32_t *doff, *dent;
     int rc;
@@ -157,6 +168,7 @@ int tetsim_set_visual_triangles(tetsim_handle h, const int32_t* tri_ids, uint32_
     if ((rc = dev_alloc(h, &doff, off.size()))) return rc;
     if ((rc = dev_alloc(h, &dent, ent.size()))) return rc;
     if ((rc = dev_alloc(h, &k.out_vnrm, nvis))) return rc;
+    if ((rc = dev_alloc(h, &h->d_vis_full, nrows))) return rc;   // (tetsim_visual_vertex_normals_from; unpartitioned bodies may use it too)
     if ((rc = upload(h, dt, tri))) return rc;
     if ((rc = upload(h, doff, off))) return rc;
     if ((rc = upload(h, dent, ent))) return rc;
@@ -165,20 +177,80 @@ int tetsim_set_visual_triangles(tetsim_handle h, const int32_t* tri_ids, uint32_
     return 0;
 }
 
+namespace {
+int read_vnrm(tetsim_body* h, float* normals_out) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t n = h->skin.nvis;
+    std::vector<float4> tmp(n);
+    if (n) HIPCHK(h, hipMemcpy(tmp.data(), h->skin.out_vnrm, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { normals_out[3 * i] = tmp[i].x; normals_out[3 * i + 1] = tmp[i].y; normals_out[3 * i + 2] = tmp[i].z; }
+    return 0;
+}
+}  // namespace
+
 int tetsim_read_visual_vertex_normals(tetsim_handle h, float* normals_out) {
     if (!h || !normals_out) return fail(h, TETSIM_EINVAL, "null argument");
     if (!h->skin.vt_off) return fail(h, TETSIM_ESTATE, "no visual triangles attached (tetsim_set_visual_triangles)");
+    if (h->partitioned) return fail(h, TETSIM_ESTATE, "a partition skins only its own rows, and a triangle's corners may belong to other ranks: put the ranks' skins together "
+                                                      "(tetsim_read_visual_mesh + tetsim_get_visual_ids) and call tetsim_visual_vertex_normals_from, or tetsim_group_read_visual_vertex_normals");
     HIPCHK(h, hipSetDevice(h->opt.device));
     const bool pjs = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI;
     if (pjs) { if (int rc = ensure_quats(h)) return rc; }
     skin_launch(h->stream, h->skin, pjs ? h->pj.pos_final : h->nh.pos, pjs ? h->pj.quat : nullptr, !pjs);
     skin_launch_vertex_normals(h->stream, h->skin);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint32_t n = h->skin.nvis;
-    std::vector<float4> tmp(n);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->skin.out_vnrm, n * sizeof(float4), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; i++) { normals_out[3 * i] = tmp[i].x; normals_out[3 * i + 1] = tmp[i].y; normals_out[3 * i + 2] = tmp[i].z; }
-    return 0;
+    return read_vnrm(h, normals_out);
+}
+
+// computeVertexNormals (Softbody.js:273) of THIS handle's rows from a complete set of visual positions -- for a partition the ranks'
+// skins put together by the host (every rank's tetsim_read_visual_mesh scattered by tetsim_get_visual_ids), for an unpartitioned body
+// any positions of its visual mesh.  Per vertex the face normals of its triangles are added in triangle order exactly as three.js
+// does, so the partitions' rows equal the unpartitioned body's normals bit for bit.
+int tetsim_visual_vertex_normals_from(tetsim_handle h, const float* all_positions, float* normals_out) {
+    if (!h || !all_positions || !normals_out) return fail(h, TETSIM_EINVAL, "null argument");
+    if (!h->skin.vt_off) return fail(h, TETSIM_ESTATE, "no visual triangles attached (tetsim_set_visual_triangles)");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    const uint32_t nrows = h->partitioned ? h->vis_total : h->skin.nvis;
+    std::vector<float4> full(nrows);
+    for (uint32_t i = 0; i < nrows; i++) full[i] = make_float4(all_positions[3 * i], all_positions[3 * i + 1], all_positions[3 * i + 2], 0.0f);
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // (a previous call's kernel may still read the buffer)
+    if (nrows) HIPCHK(h, hipMemcpy(h->d_vis_full, full.data(), nrows * sizeof(float4), hipMemcpyHostToDevice));
+    SkinDev k = h->skin;
+    k.tri_pos = h->d_vis_full;
+    skin_launch_vertex_normals(h->stream, k);
+    return read_vnrm(h, normals_out);
+}
+
+// The partitions of ONE process: every member skins its rows (their ghosts' end-of-substep positions must be fresh:
+// tetsim_group_refresh_final), the rows are put together, every member computes the normals of its rows from the whole.  positions_out /
+// normals_out [3 * rows of visVerts], either may be NULL.  Equal to the unpartitioned body's tetsim_read_visual_mesh /
+// tetsim_read_visual_vertex_normals bit for bit (PRECISE).
+int tetsim_group_read_visual_vertex_normals(tetsim_handle* hs, uint32_t count, float* positions_out, float* normals_out) {
+    group_begin(hs, count);
+    auto impl = [&]() -> int {
+        if (!hs || count == 0) return TETSIM_EINVAL;
+        for (uint32_t i = 0; i < count; i++)
+            if (!hs[i] || hs[i]->opt.part_count != static_cast<int32_t>(count) || hs[i]->opt.part_index != static_cast<int32_t>(i))
+                return fail(hs[i], TETSIM_EINVAL, "handles[i] must be partition i of a count-way decomposition");
+        const uint32_t total = hs[0]->vis_total;
+        std::vector<float> full(3ull * total, 0.0f), rows, nrm;
+        for (uint32_t i = 0; i < count; i++) {
+            tetsim_body* h = hs[i];
+            if (!h->vis_attached || h->vis_total != total) return fail(h, TETSIM_ESTATE, "every member needs the same visual mesh (tetsim_set_visual_mesh)");
+            rows.resize(3ull * h->skin.nvis);
+            if (int rc = tetsim_read_visual_mesh(h, rows.data(), nullptr)) return rc;
+            for (uint32_t j = 0; j < h->skin.nvis; j++) std::memcpy(&full[3ull * h->vis_global[j]], &rows[3ull * j], 3 * sizeof(float));
+        }
+        if (positions_out) std::memcpy(positions_out, full.data(), full.size() * sizeof(float));
+        if (!normals_out) return 0;
+        for (uint32_t i = 0; i < count; i++) {
+            tetsim_body* h = hs[i];
+            nrm.resize(3ull * h->skin.nvis);
+            if (int rc = tetsim_visual_vertex_normals_from(h, full.data(), nrm.data())) return rc;
+            for (uint32_t j = 0; j < h->skin.nvis; j++) std::memcpy(&normals_out[3ull * h->vis_global[j]], &nrm[3ull * j], 3 * sizeof(float));
+        }
+        return 0;
+    };
+    return group_result(hs, count, impl());
 }
 
 int tetsim_set_grab(tetsim_handle h, int32_t id, const float xyz[3]) {

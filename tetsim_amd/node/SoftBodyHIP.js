@@ -84,7 +84,9 @@ class SoftBodyHIP {
             // ... and its vertex normals too: Softbody.js:273 runs geometry.computeVertexNormals() every frame (37 ms of the
             // CPU path's frame); the device reproduces three.js's result bit for bit (tetsim_read_visual_vertex_normals; a triangle's
             // corners may be skinned by different partitions, so unpartitioned bodies only)
-            this._visTris = !this._partitioned && visTriIds && visTriIds.length ? (visTriIds instanceof Int32Array ? visTriIds : Int32Array.from(visTriIds)) : null;
+            // (a PARTITION takes the same global triangle list and computes ITS rows' normals from the ranks' skins put together:
+            // readVisualVertexNormalsFrom below)
+            this._visTris = visTriIds && visTriIds.length ? (visTriIds instanceof Int32Array ? visTriIds : Int32Array.from(visTriIds)) : null;
             if (this._visTris) api.setVisualTriangles(this._h, this._visTris);
         }
         if (THREE) {
@@ -196,7 +198,7 @@ class SoftBodyHIP {
         // Softbody.js:273 always recomputes the normals; SoftbodyGPU.js:687 only when physicsParams.computeNormals is set
         if (this._solver !== 'polar' || this.physicsParams.computeNormals) {
             const normal = this.visMesh.geometry.attributes.normal;
-            if (this._visTris && normal) { this.readVisualVertexNormals(normal.array); normal.needsUpdate = true; }   // = computeVertexNormals()
+            if (this._visTris && normal && !this._partitioned) { this.readVisualVertexNormals(normal.array); normal.needsUpdate = true; }   // = computeVertexNormals()
             else this.visMesh.geometry.computeVertexNormals();
         }
         this.visMesh.geometry.attributes.position.needsUpdate = true;
@@ -207,6 +209,15 @@ class SoftBodyHIP {
         out = out || new Float32Array(3 * this.numVisVerts);
         if (!this._visTris) throw new Error('no visual triangles (visTriIds) were given');
         this._api.readVisualVertexNormals(this._h, out);
+        return out;
+    }
+    // partitions: the normals of THIS rank's rows (visualIds() order) from the ranks' skins put together -- `allPositions` is the full
+    // [3 * rows of visVerts] array every rank's scatterVisualPositions() has filled (gathered over the ranks by the host); scattered by
+    // row the ranks' normals equal the unpartitioned computeVertexNormals() bit for bit
+    readVisualVertexNormalsFrom(allPositions, out) {
+        out = out || new Float32Array(3 * (this._visIds ? this._visIds.length : this.numVisVerts));
+        if (!this._visTris) throw new Error('no visual triangles (visTriIds) were given');
+        this._api.visualVertexNormalsFrom(this._h, allPositions, out);
         return out;
     }
     readVisualPositions(out) {                          // Float32Array [3*numVisVerts], skinned on the GPU

@@ -51,6 +51,7 @@ struct Api {
     decltype(&tetsim_group_step_n) group_step_n = nullptr;
     decltype(&tetsim_set_visual_triangles) set_visual_triangles = nullptr;
     decltype(&tetsim_read_visual_vertex_normals) read_visual_vertex_normals = nullptr;
+    decltype(&tetsim_visual_vertex_normals_from) visual_vertex_normals_from = nullptr;
     decltype(&tetsim_set_grab) set_grab = nullptr;
     decltype(&tetsim_start_grab) start_grab = nullptr;
     decltype(&tetsim_abi_version) abi_version = nullptr;
@@ -89,7 +90,7 @@ bool load_lib(const std::string& hint) {
     SYM(comm_unique_id, "tetsim_comm_unique_id") SYM(comm_init, "tetsim_comm_init") SYM(get_owned_ids, "tetsim_get_owned_ids")
     SYM(mesh_open, "tetsim_mesh_open") SYM(mesh_arrays, "tetsim_mesh_arrays") SYM(mesh_close, "tetsim_mesh_close") SYM(create_from_file, "tetsim_create_from_file")
     SYM(prep_partition, "tetsim_prep_partition") SYM(prep_partition_quality, "tetsim_prep_partition_quality")
-    SYM(halo_refresh_final, "tetsim_halo_refresh_final") SYM(group_refresh_final, "tetsim_group_refresh_final") SYM(group_step_n, "tetsim_group_step_n")
+    SYM(visual_vertex_normals_from, "tetsim_visual_vertex_normals_from") SYM(halo_refresh_final, "tetsim_halo_refresh_final") SYM(group_refresh_final, "tetsim_group_refresh_final") SYM(group_step_n, "tetsim_group_step_n")
 #undef SYM
     return true;
 }
@@ -622,6 +623,21 @@ napi_value ReadVisualVertexNormals(napi_env env, napi_callback_info info) {
     if (nn < 3ull * inf.num_vis_verts) return throw_err(env, "normals output array too small (3 floats per visual vertex)");
     return check(env, g.read_visual_vertex_normals(h, no), h);
 }
+// visualVertexNormalsFrom(handle, Float32Array allPositions [3 * rows of visVerts], Float32Array normalsOut [3 * numVisVerts])
+napi_value VisualVertexNormalsFrom(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return nullptr;
+    tetsim_handle h = handle_of(env, a[0]);
+    if (!h) return nullptr;
+    float *pi, *no; size_t np_, nn;
+    if (!typed_array(env, a[1], napi_float32_array, &pi, &np_)) return throw_err(env, "positions must be a Float32Array");
+    if (!typed_array(env, a[2], napi_float32_array, &no, &nn)) return throw_err(env, "normals output must be a Float32Array");
+    TetSimInfo inf;
+    g.get_info(h, &inf);
+    if (np_ < 3ull * inf.total_vis_verts) return throw_err(env, "positions array too small (3 floats per row of visVerts)");
+    if (nn < 3ull * inf.num_vis_verts) return throw_err(env, "normals output array too small (3 floats per visual vertex)");
+    return check(env, g.visual_vertex_normals_from(h, pi, no), h);
+}
 // setGrab(handle, id, x, y, z)
 napi_value SetGrab(napi_env env, napi_callback_info info) {
     napi_value a[5];
@@ -741,7 +757,7 @@ napi_value Info(napi_env env, napi_callback_info info) {
     set("localElems", inf.local_elems); set("numLevels", inf.num_levels); set("maxValence", inf.max_valence);
     set("droppedSlots", inf.dropped_slots); set("deviceBytes", static_cast<double>(inf.device_bytes));
     set("solver", inf.solver); set("precision", inf.precision); set("localParticles", inf.local_particles);
-    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours); set("numVisVerts", inf.num_vis_verts); set("numBodies", inf.num_bodies);
+    set("ownedElems", inf.owned_elems); set("numNeighbours", inf.num_neighbours); set("numVisVerts", inf.num_vis_verts); set("numBodies", inf.num_bodies); set("totalVisVerts", inf.total_vis_verts);
     return o;
 }
 
@@ -781,6 +797,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"groupRefreshFinal", nullptr, GroupRefreshFinal, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setVisualTriangles", nullptr, SetVisualTriangles, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readVisualVertexNormals", nullptr, ReadVisualVertexNormals, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"visualVertexNormalsFrom", nullptr, VisualVertexNormalsFrom, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setGrab", nullptr, SetGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"startGrab", nullptr, StartGrab, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"info", nullptr, Info, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -314,6 +314,14 @@ class SoftBodyHIP:
         capi.check(self._L.tetsim_read_visual_vertex_normals(self._h, _fp(out)), self._h)
         return out.reshape(-1, 3)
 
+    def visualVertexNormalsFrom(self, allPositions):
+        """computeVertexNormals of THIS body's rows from a complete set of visual positions [rows of visVerts, 3] -- a partition: the
+        ranks' skins put together (visualPositions() scattered by visualIds); include/tetsim.h: tetsim_visual_vertex_normals_from."""
+        ap = _f32(allPositions).reshape(-1)
+        out = np.empty(3 * self.numVisVerts, dtype=np.float32)
+        capi.check(self._L.tetsim_visual_vertex_normals_from(self._h, _fp(ap), _fp(out)), self._h)
+        return out.reshape(-1, 3)
+
     # -- caller-provided transports (include/tetsim.h: tetsim_get_halo_plan / tetsim_halo_export / tetsim_halo_import) --
     def haloPlan(self):
         """[(neighbour rank, global ids sent, global ids received)] in neighbour-slot order."""
@@ -451,6 +459,15 @@ def group_step_n(bodies, n, dt, physicsParams):
     """n substeps of every partition of one decomposition (same choreography as the RCCL path, in-process copies)."""
     arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
     capi.check(capi.lib().tetsim_group_step_n(arr, len(bodies), int(n), float(dt), C.byref(make_params(physicsParams))))
+
+
+def group_visual_vertex_normals(bodies, num_rows):
+    """(positions, normals) of the WHOLE visual mesh [num_rows, 3] from the partitions of one process (after group_refresh_final):
+    tetsim_group_read_visual_vertex_normals."""
+    arr = (C.c_void_p * len(bodies))(*[b._h for b in bodies])
+    pos, nrm = np.empty(3 * num_rows, dtype=np.float32), np.empty(3 * num_rows, dtype=np.float32)
+    capi.check(capi.lib().tetsim_group_read_visual_vertex_normals(arr, len(bodies), _fp(pos), _fp(nrm)))
+    return pos.reshape(-1, 3), nrm.reshape(-1, 3)
 
 
 def group_refresh_final(bodies):
