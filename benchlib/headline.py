@@ -357,7 +357,7 @@ def run(args, rank, world, local_rank, ranks):
                 ref_win["in_graph"] = {"substep_us": round(sub_ref, 2), "kernel_us_implied": round(imp, 2), "frac_implied": round(alg / (imp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                        "what": "wall clock of the same frames as graph replays (value_reference_threshold) minus the particle kernel and the two launch "
                                                "boundaries of timed_region_check; on the first frames after a body's creation the graphs run the iteration-heavy kernel "
-                                               "slower than its per-launch events say (tools/frame_series.py)"}
+                                               "slower than its per-launch events say (tools/attic/frame_series.py)"}
         # WHAT THE PRODUCT RUNS LEADS: the equal-work kernel INSIDE the graphs tetsim_step_n replays -- the timed
         # frames with the reference's threshold: their wall clock per substep minus the particle kernel and the two launch boundaries --
         # is `frac`; the per-launch event figures (about 1 us shorter: an eagerly launched kernel with its own events starts on an idle chip)

@@ -274,7 +274,7 @@ def test_two_layer_ghost_region_tracks_the_monolithic_body_and_its_ghost_tets_tr
         n, owner = 3, None
         # (a gentle pull: yanking a Dragon vertex by a third of the body's size folds its tets over, the polar iteration settles on
         # another branch from a rounding's difference, and ANY decomposition -- one ghost layer too -- is millimetres off the
-        # monolithic body at once: tools/deep_diag.py, profiles/r03_loopback.txt section 3)
+        # monolithic body at once: tools/attic/deep_diag.py, profiles/archive/r03_loopback.txt section 3)
         pull = (0.02, 0.04)
     else:
         n = int(case[5:])

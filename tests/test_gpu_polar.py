@@ -142,7 +142,7 @@ def test_spinning_body_keeps_its_size():
     could rescale the shape every substep and compound.  A free, spinning body (no gravity, no walls, 3 rad/s) must therefore
     keep its edge lengths over 1,500 substeps; the PRECISE path, which divides by a correctly rounded sqrt, is the yardstick.
     (Round 1 put a Newton step behind the FAST path's v_rsq_f32 for this reason; the mutation runs of round 2 --
-    profiles/r02g_mutation.txt, first section -- showed that it moved no check by more than 1.5x and it was removed: the
+    profiles/archive/r02g_mutation.txt, first section -- showed that it moved no check by more than 1.5x and it was removed: the
     rotation matrix is formed as 1 - 2(yy + zz), ..., which a length error of q enters only times the small rotation itself.
     This test is what guards that decision.)"""
     v, t = make_lattice(6, y0=1.0)

@@ -7,7 +7,7 @@ rounding and must not fuse multiply-add (-ffp-contract=off); the FAST units are 
 
 --ablation additionally builds libtetsim_hip_ablation.so: the same sources with -DTETSIM_ABLATION, whose polar tet kernel
 takes the timing-ablation knobs (TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL) and the per-tile trace.  Development
-only (tools/ab_iters.py, tools/trace_tet.py); the product library has none of that code.
+only (tools/attic/ab_iters.py, tools/attic/trace_tet.py); the product library has none of that code.
 """
 import hashlib
 import os
@@ -50,7 +50,7 @@ UNITS = {
     "pj_quad.hip": ["-ffp-contract=off"],
     "nh_precise.hip": ["-ffp-contract=off"],
     # kernarg preload: the four-lane cluster kernel's leading scalar arguments (ids, particles, mask, count) arrive in SGPRs with the
-    # wave instead of through a scalar load at the head of every colour's chain: 66.8 -> 65.4 us per substep (profiles/r03_neohookean.txt)
+    # wave instead of through a scalar load at the head of every colour's chain: 66.8 -> 65.4 us per substep (profiles/archive/r03_neohookean.txt)
     # contract=on, not fast: with fast the BACKEND fuses any multiply with any add it finds, whatever `#pragma clang fp contract` says, and
     # picks the pairs by the surrounding code -- kernels that share their arithmetic (a body's fused launch and its stepwise twin) then
     # round differently in one tet out of a few hundred.  on = only a * b + c written as one expression (or fmaf) fuses.

@@ -31,7 +31,7 @@ __device__ __forceinline__ void store_wt1(float* base, uint32_t index, float v) 
 
 // Exchange between workgroups that share ONE XCD (pj_blocked.hip: the frame kernel's tile partial sums when the host has placed a
 // body's tiles on one XCD): the store is a plain one -- the CU's L1 writes through, the line stays in the XCD's L2 --, the load
-// carries agent scope (sc1): it misses the L1 and is served by that L2.  Measured on MI355X (profiles/r03_frame_kernel.txt): bit-equal
+// carries agent scope (sc1): it misses the L1 and is served by that L2.  Measured on MI355X (profiles/archive/r03_frame_kernel.txt): bit-equal
 // results, 6.1 instead of 6.5 us per Dragon substep against the memory-side pair below.  NOT coherent across XCDs (a line dirty in
 // another XCD's L2 is invisible), and a workgroup-scope load (sc0) is served by the stale L1 line for ever; an L1 invalidate
 // (buffer_inv sc1) + plain loads works too but costs 8.1 us.

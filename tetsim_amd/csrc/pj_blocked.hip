@@ -16,13 +16,13 @@
 //   pjb_vertex_kernel  one lane per particle: adds the 1..9 (2.9 on average; irregular meshes: more) partial sums of the tiles that touch
 //        it instead of gathering ~23 goals, then collides / integrates exactly like the gather formulation.
 //
-// Tried and dropped in round 2 (profiles/r02b_kernel_variants.txt): the staged positions as three f32 planes instead of float4
+// Tried and dropped in round 2 (profiles/archive/r02b_kernel_variants.txt): the staged positions as three f32 planes instead of float4
 // (12 ds_read_b32 instead of 4 ds_read_b128 per tet: 29.5 vs 29.0 us), and 128-tet tiles (-DTETSIM_TILE=128: 16 workgroups per
 // CU, tet kernel 28.3-30.5 us against 29.0, but 15% more partial sums: particle pass 6.5 vs 5.8 us, no gain overall).
 // ... and a second attempt at a persistent, software-pipelined kernel (commit 645542b: workgroups resident over several tiles, the next
 // tile's record AND position gather in flight during the solve -- ids two tiles ahead, headers through scalar loads, partial sums
 // leaving one tile late so that the one drain point per tile finds everything landed; correct, 86 registers, 5 waves per SIMD):
-// 33.4-35.0 us against 28.3-29.2 (profiles/r02j_pipelined_kernel_ab.txt).  What eight independent workgroups per CU overlap for
+// 33.4-35.0 us against 28.3-29.2 (profiles/archive/r02j_pipelined_kernel_ab.txt).  What eight independent workgroups per CU overlap for
 // free, one pipelined workgroup pays for in registers, occupancy and rotation moves.
 // Tried and dropped (measured on the 1 M-tet lattice): (a) a persistent variant prefetching tile i+1
 // during tile i's solve, with scalar tile headers, a 3-deep index pipeline, a peeled first trip and counted
@@ -32,7 +32,7 @@
 // packed f32 (every add/mul/fma a v_pk_*_f32, 128-thread workgroups, 114 VGPRs, no spills): the rotation loop got 14 %
 // cheaper (1.37 vs 1.60 us per iteration) but the 0-iteration base 1.2 us dearer, 37.9 vs 35.0 us overall.  On gfx950 a
 // wave64 v_pk_fma_f32 issues in 4.8 cycles against 2.8 for v_fma_f32 (tools/micro/valu_rate.hip,
-// profiles/r01e_valu_issue_rates.txt): packing buys at most 16 % of f32 throughput, not 2x.
+// profiles/archive/r01e_valu_issue_rates.txt): packing buys at most 16 % of f32 throughput, not 2x.
 //
 // Result differs from the gather formulation only by summation order (tile partials) -- tolerance-level, FAST
 // mode only; PRECISE keeps the reference's slot order.
@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t tiles_per_xcd)
 // tetsim_step_n the latter).  acc = sum of V*goal, wsum = sum of V (a constant), prev = end of the previous substep.
 struct VertexOut { f3 p, vel, pred; };
 // (Every multiply-add below is spelled out: with -ffp-contract=fast the compiler decides per call site which products to fuse, and this
-// function is inlined into several kernels whose results must agree bit for bit -- a fourth call site (profiles/r03_tile_finish.txt)
+// function is inlined into several kernels whose results must agree bit for bit -- a fourth call site (profiles/archive/r03_tile_finish.txt)
 // came out an ulp off.  The spelling is the one the particle kernel has always compiled to.)
 __device__ __forceinline__ VertexOut pjb_vertex_update(f3 acc, float wsum, f3 prev, const DevParams& P, uint32_t v) {
     const float rw = __builtin_amdgcn_rcpf(wsum);

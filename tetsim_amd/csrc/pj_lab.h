@@ -4,8 +4,8 @@
 // the product's compile-time constant (nine rotation iterations, the first one peeled, every store).  Only the separate development
 // build (python -m tetsim_amd.build --ablation: -DTETSIM_ABLATION -> libtetsim_hip_ablation.so, never shipped, `library.ablation` in
 // bench.py's line) gives them bodies: a run-time mode word (TETSIM_DEBUG_ITERS / _SKIP_REST_STORE / _NO_PEEL / _STAGGER), per-tile
-// phase stamps (TETSIM_DEBUG_TRACE; tools/trace_tet.py, frame_trace.py) and the rotation-iteration histogram (TETSIM_DEBUG_ITER_HIST;
-// tools/rotation_iterations.py).  Macros only -- the functions they call live in pj_blocked_lab.inc.
+// phase stamps (TETSIM_DEBUG_TRACE; tools/attic/trace_tet.py, frame_trace.py) and the rotation-iteration histogram (TETSIM_DEBUG_ITER_HIST;
+// tools/attic/rotation_iterations.py).  Macros only -- the functions they call live in pj_blocked_lab.inc.
 #pragma once
 
 // the product's rotation-iteration count (tools/mutation_check.sh and tools/iteration_floor.sh mutate THIS line in a copy of the tree)
@@ -57,7 +57,7 @@
                      d.iter_hist ? w2log_ : nullptr);                                                                              \
         if (d.iter_hist) pjb_log_iterations(d.iter_hist, w2log_);                                                                  \
     } while (0)
-// the frame kernel: thread 0 adds up the cycles of each phase over the call (tools/frame_trace.py)
+// the frame kernel: thread 0 adds up the cycles of each phase over the call (tools/attic/frame_trace.py)
 #define TETSIM_LAB_FRAME_BEGIN() unsigned long long fr_acc[5] = {0, 0, 0, 0, 0}, fr_last = 0, fr_polls = 0
 #define FRAME_STAMP(i) do { if (d.trace && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) fr_acc[(i) > 0 ? (i) - 1 : 0] += now_ - fr_last; fr_last = now_; } } while (0)
 #define FRAME_POLL() do { if (tid == 0) fr_polls++; } while (0)

@@ -3,7 +3,7 @@
 // The reference's own workload is the Dragon (3,840 tets; /root/reference/src/main.js:26-27,79-84).  On this chip such a body is
 // not bandwidth but a chain: with one tet per lane and 256-tet tiles (pj_blocked.hip) it is 60 waves, each alone on its SIMD, and a
 // lone wave issues one DEPENDENT vector instruction every ~5.5-7 cycles -- the ~970 instructions of a tet solve were 48% of a
-// substep (profiles/r03_frame_kernel.txt).  The only lever is fewer instructions per lane.  Here:
+// substep (profiles/archive/r03_frame_kernel.txt).  The only lever is fewer instructions per lane.  Here:
 //   * tiles hold <= 64 tets touching <= 64 particles (host_prep.h kQuadTile): a workgroup is 64 QUADS = 4 waves = one wave per SIMD
 //     of a CU, and the Dragon's 62 tiles keep 248 SIMDs busy instead of 60;
 //   * lanes 4i..4i+2 of quad i hold the x / y / z COMPONENT of everything vector-valued of tet i (P3 + P4, SoftbodyGPU.js:80-262)
@@ -187,7 +187,7 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
     __shared__ uint16_t s_ent[4 * kQT];       // the tile's reduction order (word offsets corner * kQT + tet)
 
     const uint32_t tid = threadIdx.x, c = tid & 3u, qd = tid >> 2;
-#ifdef TETSIM_ABLATION   // development build: thread 0 adds up the cycles of each phase over the call (TETSIM_DEBUG_TRACE, tools/frame_trace.py)
+#ifdef TETSIM_ABLATION   // development build: thread 0 adds up the cycles of each phase over the call (TETSIM_DEBUG_TRACE, tools/attic/frame_trace.py)
     uint32_t fr_acc[5] = {0, 0, 0, 0, 0}, fr_last = 0, fr_polls = 0;   // (32-bit: a call is a few hundred thousand cycles, and the kernel has 128 registers)
 #define QSTAMP(i) do { if (kMode == kModeFrame && d.trace && tid == 0) { const uint32_t now_ = static_cast<uint32_t>(__builtin_amdgcn_s_memtime()); if ((i) > 0) fr_acc[(i) > 0 ? (i) - 1 : 0] += now_ - fr_last; fr_last = now_; } } while (0)
 #define QPOLL() do { if (tid == 0) fr_polls++; } while (0)

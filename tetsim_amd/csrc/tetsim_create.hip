@@ -284,7 +284,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
         // the two-kernel substep (development A/B)
         static const bool allow_fused = [] { const char* e = getenv("TETSIM_FUSED_PARTICLE_PASS"); return !(e && e[0] == '0'); }();
         // ... and only where it pays: a body of fewer tiles than the chip has workgroup slots (2,048) is bound by launches and
-        // dependency bubbles, and one kernel per substep instead of two is worth +21% on the Dragon (15 tiles; profiles/r02h_*); the
+        // dependency bubbles, and one kernel per substep instead of two is worth +21% on the Dragon (15 tiles; profiles/archive/r02h_*); the
         // 1 M-tet lattice (3,900 tiles) gains nothing -- the fused kernel costs what the particle kernel and its bubble cost
         // (32.0 us against 25.6 + 5.8), needs 74 registers instead of 49 (6 waves per SIMD instead of 8) and reads lower on the
         // roofline -- and keeps the two-kernel substep.  TETSIM_FUSED_PARTICLE_PASS=1 forces it on (A/B).

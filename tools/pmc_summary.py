@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Average rocprofv3 --pmc counters per kernel from the CSVs tools/pmc_run.sh leaves behind.
-    python tools/pmc_summary.py gpurun_out/pmc_r1 > profiles/r01_pmc.txt"""
+    python tools/pmc_summary.py gpurun_out/pmc_r1 > profiles/archive/r01_pmc.txt"""
 import csv
 import glob
 import os

@@ -7,7 +7,7 @@
    the kernel's barriers and at the rotation loop): VALU (plain / transcendental), SALU, LDS, global loads / stores -- static
    counts, and dynamic counts per wave for nine iterations (the loop body x 8 + the peeled first iteration).
 2. Vector-issue floor: SQ_INSTS_VALU per launch (counters, tools/pmc_run.sh) / 1,024 SIMDs x the issue rates this chip sustains with
-   several waves per SIMD (profiles/r01e_valu_issue_rates.txt: 3.15 cycles per plain, 8.8 per transcendental wave-instruction) at
+   several waves per SIMD (profiles/archive/r01e_valu_issue_rates.txt: 3.15 cycles per plain, 8.8 per transcendental wave-instruction) at
    2.4 GHz; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES beside it.
 3. Memory floor: the PRODUCT kernel rebuilt with 0 / 3 / 6 rotation iterations (tools/iteration_floor.sh; the development build's
    run-time knob compiles to a slower kernel and cannot give the product's floor).
