@@ -164,3 +164,34 @@ def test_lean_state_zero_volume_tet_and_flag_checks():
         args.update(kw)
         with pytest.raises(TetSimError, match="LEAN_STATE"):
             SoftBodyHIP(v, t, None, dict(PP), lean_state=True, **args)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lean_state=True), dict(constant_rest_shape=True)])
+def test_one_launch_substep_equals_two_kernels_bit_for_bit(kw):
+    """Large unpartitioned bodies (>= 2,048 tiles): inside tetsim_step_n a substep is ONE launch -- every tile, then every particle, whose
+    waves look for the substep's sequence number in their tiles' partial sums (pj_blocked.hip: pjb_substep_kernel).  Same arithmetic as
+    the tet kernel + particle kernel pair tetsim_step launches: bit for bit, across calls of odd lengths, floor contact, a grab, a dt
+    change; TETSIM_PJ_ONE_LAUNCH=0 (read at creation) keeps the pair inside the graphs too."""
+    import os
+    v, t = make_lattice(46, y0=0.01)             # 584,016 tets = 2,282 tiles
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
+    os.environ["TETSIM_PJ_ONE_LAUNCH"] = "0"
+    try:
+        b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
+    finally:
+        del os.environ["TETSIM_PJ_ONE_LAUNCH"]
+    c = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
+    assert a.info.fused_particle_pass == 0
+    for k, (n, dt) in enumerate(((20, DT20), (1, DT20), (7, DT20), (3, DT20 * 2), (20, DT20))):
+        if k == 2:
+            for body in (a, b, c):
+                body.setGrab(11, [0.1, 0.5, -0.1])
+        if k == 4:
+            for body in (a, b, c):
+                body.endGrab()
+        a.simulateSubsteps(n, dt, PP)            # graphs of one-launch substeps
+        b.simulateSubsteps(n, dt, PP)            # graphs of kernel pairs
+        for _ in range(n):
+            c.simulate(dt, PP)                   # tetsim_step: eager kernel pairs
+        assert _same(a.pos, b.pos) and _same(a.pos, c.pos) and _same(a.vel, c.vel), (kw, k)
+    assert _same(a.quats, c.quats) and a.pos[:, 1].min() == 0.0

@@ -189,6 +189,11 @@ struct tetsim_body {
     bool halo_use_flags = true;       // TETSIM_HALO_SYNC (read when the body is created): false = "events", the older event-synchronised halo path
     bool halo_use_graph = true;       // TETSIM_HALO_GRAPH (likewise): false = the halo path stays eager
     bool fused = false;
+    // large unpartitioned blocked bodies (two kernels per substep): tetsim_step_n runs a CALL as ONE launch -- per substep the tiles, then the
+    // particles, handed on by stamped partial sums and predictions (pj_blocked.hip: pjb_call_kernel); TETSIM_PJ_ONE_LAUNCH=0 at creation keeps
+    // two kernels per substep (A/B); tetsim_step and tetsim_profile keep the two kernels (same arithmetic, same bits)
+    bool pj_one_launch = false;
+    uint32_t* d_substep_err = nullptr;
     // TETSIM_FLAG_LEAN_STATE (pj_blocked.hip: kModeLeanState): the substep neither reads nor writes pj.quat; it is recovered from the carried
     // shape and this constant centred rest shape when somebody asks for it (ensure_quats)
     float4 *rest0_a = nullptr, *rest0_b = nullptr, *rest0_c = nullptr;

@@ -55,4 +55,9 @@ __device__ __forceinline__ float4 load_coherent(const float4* base, uint32_t ind
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
 
+__device__ __forceinline__ float load_coherent1(const float* base, uint32_t index) {   // ... one float
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(index * 4u), 0, 0x11));   // aux: sc0 | sc1
+}
+
 }  // namespace tetsim

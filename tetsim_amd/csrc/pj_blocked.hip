@@ -125,9 +125,15 @@ struct PJHaloWait { const PJPeerSync* w; const uint32_t* vflag; uint32_t* error;
 //      from there when they are asked (skin_kernels.hip: pjb_recover_quat_kernel) -- 92 B per tet
 constexpr int kModeCarried = 0, kModeConstantRest = 1, kModeLeanState = 2;
 inline int blk_mode(const PJBlk& d) { return pjb_mode(d); }
-template <int kMode, bool kFused, bool kAlt = false, bool kHaloWait = false>
+// stamp: what goes into the (otherwise unused) fourth float of every partial sum -- 0, or the sequence number of the substep when the
+// particle pass runs in the SAME launch and looks for it (pjb_substep_kernel below)
+// kPoll (pjb_call_kernel below): the tile runs in a launch that spans SEVERAL substeps -- its block index inside its substep is poll->block,
+// and the predictions it stages were written by particle waves of the same launch: memory-side loads, looked at until they carry the
+// previous substep's sequence number poll->want (0: the launch's first substep, whose predictions a completed launch left)
+struct PJPoll { uint32_t block, want; uint32_t* error; uint32_t timeout_ms; };
+template <int kMode, bool kFused, bool kAlt = false, bool kHaloWait = false, bool kPoll = false>
 __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first, uint32_t tile_count, uint32_t tiles_per_xcd TETSIM_DBG_PARAM,
-                                             [[maybe_unused]] const PJHaloWait* hw = nullptr) {
+                                             [[maybe_unused]] const PJHaloWait* hw = nullptr, const uint32_t stamp = 0u, [[maybe_unused]] const PJPoll* poll = nullptr) {
     __shared__ float4 s_pos[kTile];        // staged particle positions
     __shared__ float s_gx[4 * kTile];      // V*goal per corner, plane-major [corner][tet], one plane per component
     __shared__ float s_gy[4 * kTile];
@@ -135,7 +141,9 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
     __shared__ uint2 s_ent[kTile];         // the tile's reduction order, 4 x u16 per tet position
 
     constexpr bool kLean = kMode == kModeConstantRest;
-    const uint32_t rel = xcd_tile(blockIdx.x, tiles_per_xcd);
+    uint32_t block_index = blockIdx.x;
+    if constexpr (kPoll) block_index = poll->block;
+    const uint32_t rel = xcd_tile(block_index, tiles_per_xcd);
     if (rel >= tile_count) return;  // whole workgroup leaves together
     const uint32_t b = tile_first + rel;
     const uint32_t tid = threadIdx.x;
@@ -173,10 +181,22 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         if (maxsrc > 8u) src8 = col[8ull * d.ns_pad];
     }
     const uchar4 li = d.tet_lidx[e];
-    const float4 ra = d.rest_a[e], rb = d.rest_b[e];
-    float4 rc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q_old = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    if constexpr (kMode == kModeLeanState) rc.x = d.rest_c1[e];   // (r2.z: the ninth float)
-    else { rc = d.rest_c[e]; q_old = d.quat[e]; }
+    // (kPoll: the record was written by this tile's workgroup of the PREVIOUS substep of the same launch -- no kernel boundary has emptied
+    // this CU's first-level cache of the line it may have read two substeps ago: memory-side loads, like the looks at the predictions)
+    // ... and only AFTER the looks at the predictions have succeeded (sub > 0): a tile stores its partial sums behind the completion of its
+    // record stores (below), the particle lanes store their predictions behind their looks at those sums, so a stamped prediction says the
+    // record is there -- a record requested together with the predictions could be the substep before's.  One more dependent trip per
+    // tile, hidden by the seven other workgroups of the CU; the launch's first substep keeps the two trips.
+    auto rec4 = [](const float4* a, uint32_t i) { if constexpr (kPoll) return load_coherent(a, i); else return a[i]; };
+    float4 ra = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb = ra, rc = ra, q_old = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    auto load_record = [&]() {
+        ra = rec4(d.rest_a, e); rb = rec4(d.rest_b, e);
+        if constexpr (kMode == kModeLeanState) { if constexpr (kPoll) rc.x = load_coherent1(d.rest_c1, e); else rc.x = d.rest_c1[e]; }   // (r2.z: the ninth float)
+        else { rc = rec4(d.rest_c, e); q_old = rec4(d.quat, e); }
+    };
+    bool record_late = false;
+    if constexpr (kPoll) record_late = poll->want != 0u;   // (uniform)
+    if (!record_late) load_record();
     const float V = d.vol[e];
     const uint2 ent_row = d.lc_ent[e];
     float4 pos_stage;
@@ -231,6 +251,22 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         const uint32_t g = vid - d.nv_owned;   // (ghost index; two-layer regions keep the layers in separate buffers)
         const float4* src = vid >= d.nv_owned ? (g < d.n_ghost1 ? d.ghost_alt + g : d.ghost2 + (g - d.n_ghost1)) : d.pos_pred + vid;
         pos_stage = *src;
+    } else if constexpr (kPoll) {
+        pos_stage = load_coherent(d.pos_pred, vid);
+        if (poll->want != 0u) {
+            bool pend = has_slot && __float_as_uint(pos_stage.w) != poll->want;
+            if (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+                const long long t0 = wall_clock64(), limit = 100000ll * poll->timeout_ms;   // 100 MHz ticks; 0 = unbounded
+                do {
+                    __builtin_amdgcn_s_sleep(8);
+                    asm volatile("" ::: "memory");   // (every look is a fresh load)
+                    if (pend) { pos_stage = load_coherent(d.pos_pred, vid); pend = __float_as_uint(pos_stage.w) != poll->want; }
+                    if (limit && pend && wall_clock64() - t0 > limit) { __hip_atomic_store(poll->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); pend = false; }
+                } while (__builtin_amdgcn_ballot_w64(pend) != 0ull);
+            }
+            __syncthreads();   // (every wave's looks have succeeded: every particle of the tile is stamped, i.e. every neighbouring tile's record too)
+            load_record();
+        }
     } else {
         pos_stage = d.pos_pred[vid];
     }
@@ -276,6 +312,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
         }
     }
     TETSIM_STAMP(4);  // stores issued
+    if constexpr (kPoll) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's record stores have LANDED (write-through: at the memory side) before any partial sum of the tile is stored
     __syncthreads();
     TETSIM_STAMP(5);
 
@@ -308,6 +345,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             const uint32_t o = static_cast<uint32_t>(ent[i]) << 2;
             acc.x += plane(s_gx, o); acc.y += plane(s_gy, o); acc.z += plane(s_gz, o);
         }
+        acc.w = __uint_as_float(stamp);
         store_wt(d.partial, v0 + tid, acc);
     }
     TETSIM_STAMP(6);
@@ -692,6 +730,87 @@ __device__ __forceinline__ void pjb_vertex_body(const PJBlk& d, uint32_t first, 
 }
 
 __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first, uint32_t count) { pjb_vertex_body(d, first, count); }
+
+// ---- a CALL as one launch (large unpartitioned bodies: tetsim_step_n) -------------------------------------------------------------------
+// All n substeps of a call in one grid: per substep the tiles' workgroups, then the particles' (four waves of 64 per workgroup), substep
+// after substep.  The dispatcher hands out workgroups in grid order, so whatever a wave waits for has been dispatched before it -- what
+// it cannot know is whether it is DONE.  So data carries its stamp, as the persistent frame kernel's partial sums do (pjb_frame_body):
+//   * every partial sum has the substep's sequence number in its fourth float (one 16-byte store = data + "it is there"); a particle wave
+//     looks at its particle's (up to nine) sums until they carry it;
+//   * every prediction has it too; a tile of the NEXT substep looks at the predictions it stages until they carry it.
+// All looks are memory-side loads (the writer may sit on another XCD, no kernel boundary in between) and bounded.  Nothing is double
+// buffered: a tile's partial sums are read by the particle lanes of its own particles only, and the tile overwrites them after it has
+// staged those particles' next predictions, which their lanes wrote after reading the sums; a prediction is overwritten by its lane after
+// all tiles around the particle delivered their sums, i.e. after they staged it.  No launch boundary inside a call, and the particle
+// pass -- two dependent memory trips and little else -- and the tiles' staging run under the neighbouring passes' compute.  The
+// arithmetic is pjb_tet_body's and pjb_vertex_update's, operation for operation: a call equals the same substeps through the two
+// kernels (tetsim_step, tetsim_profile) bit for bit.
+template <int kMode>
+__global__ __launch_bounds__(kTile, 2) void pjb_call_kernel(PJBlk d, uint32_t n_sub, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t tet_blocks, uint32_t blocks_per_sub,
+                                                           uint32_t* err, uint32_t timeout_ms TETSIM_DBG_PARAM) {
+    const uint32_t sub = blockIdx.x / blocks_per_sub, r = blockIdx.x - sub * blocks_per_sub;   // (blocks_per_sub is a multiple of 8: r and blockIdx.x land on the same XCD)
+    const uint32_t stamp = (d.epoch ? d.epoch : d.params->epoch) + sub + 1u;
+    if (r < tet_blocks) {
+        const PJPoll poll = {r, sub ? stamp - 1u : 0u, err, timeout_ms};
+        pjb_tet_body<kMode, false, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, nullptr, stamp, &poll);
+        return;
+    }
+    const uint32_t v = (r - tet_blocks) * kTile + threadIdx.x;
+    if (v >= d.nv_owned) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t* col = d.vp_ell + v;
+    const long long limit = 100000ll * timeout_ms;   // 100 MHz ticks; 0 = unbounded
+    const float wsum = d.wsum[v];
+    // (the store of this particle's lane one substep before -- another wave of the same launch: past the caches, and looked at again below
+    // until it carries that substep's number: it was stored ~a tile's lifetime ago, the first look finds it)
+    float4 prev = load_coherent(d.fin_in, v);
+    for (uint32_t j0 = 0; j0 < d.vp_cols; j0 += 8u) {   // (pjb_vertex_body's gather, every sum looked at until it is this substep's)
+        uint32_t idx[8];
+        float4 g[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) idx[j] = (j0 + j < d.vp_cols) ? col[static_cast<size_t>(j0 + j) * d.nv_pad] : 0xffffffffu;
+        uint32_t pend = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            const float4 t = load_coherent(d.partial, idx[j] != 0xffffffffu ? idx[j] : 0u);
+            g[j] = idx[j] != 0xffffffffu ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pend |= (idx[j] != 0xffffffffu && __float_as_uint(t.w) != stamp ? 1u : 0u) << j;
+        }
+        if (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+            const long long t0 = wall_clock64();
+            do {
+                __builtin_amdgcn_s_sleep(8);
+                asm volatile("" ::: "memory");   // (every look is a fresh load)
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++)
+                    if ((pend >> j) & 1u) {
+                        const float4 t = load_coherent(d.partial, idx[j]);
+                        if (__float_as_uint(t.w) == stamp) { g[j] = t; pend &= ~(1u << j); }
+                    }
+                if (limit && pend != 0u && wall_clock64() - t0 > limit) {   // never in a correct run; a wedged GPU helps nobody
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    pend = 0u;
+                }
+            } while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) { acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; }
+        if (__all(idx[7] == 0xffffffffu)) break;
+    }
+    if (sub) {
+        const long long t0 = wall_clock64();
+        while (__float_as_uint(prev.w) != stamp - 1u) {
+            __builtin_amdgcn_s_sleep(4);
+            asm volatile("" ::: "memory");
+            prev = load_coherent(d.fin_in, v);
+            if (limit && wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+    const VertexOut o = pjb_vertex_update(xyz(acc), wsum, xyz(prev), *d.params, v);
+    store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, __uint_as_float(stamp)));
+    if (d.vel && sub + 1u == n_sub) store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));   // (the velocity array: behind a call's last substep only)
+    store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, __uint_as_float(stamp)));
+}
 __global__ __launch_bounds__(64) void pjb_vertex_kernel_raise(PJBlk d, uint32_t first, uint32_t count, uint32_t* sig, uint32_t* clear) {
     clear_then_raise(clear, sig);
     pjb_vertex_body(d, first, count);
@@ -818,6 +937,13 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     auto* kernel = mode == kModeConstantRest ? pjb_tet_kernel_constant_rest : mode == kModeLeanState ? pjb_tet_kernel_lean : pjb_tet_kernel;
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
+}
+void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, uint32_t timeout_ms) {
+    if (d.nb == 0 || n == 0) return;
+    const uint32_t per_xcd = (d.nb + 7u) / 8u, tet_blocks = per_xcd * 8u, per_sub = (tet_blocks + (d.nv_owned + kTile - 1u) / kTile + 7u) & ~7u;
+    const int mode = blk_mode(d);
+    auto* kernel = mode == kModeConstantRest ? pjb_call_kernel<kModeConstantRest> : mode == kModeLeanState ? pjb_call_kernel<kModeLeanState> : pjb_call_kernel<kModeCarried>;
+    hipLaunchKernelGGL(kernel, dim3(per_sub * n), dim3(kTile), 0, s, d, n, d.nb, per_xcd, tet_blocks, per_sub, err, timeout_ms TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) { launch_tet_x(s, d, 0u, d.nb, TetFused{0u}, e0, e1); }
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,

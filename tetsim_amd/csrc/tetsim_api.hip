@@ -399,6 +399,12 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
         rc = launch_frame_kernel(h, n, 0u);
+    } else if (h->pj_one_launch) {
+        // large unpartitioned polar bodies: the n substeps' tiles and particles in ONE grid, handed on by stamped data (pj_blocked.hip:
+        // pjb_call_kernel); the sequence numbers start at DevParams::epoch (this call's parameter upload took a fresh block)
+        pjb_launch_call(h->stream, h->blk, n, h->d_substep_err, halo_timeout_ms(h));
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else if (h->nh_frame) {
         // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
         h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, n) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, n);
@@ -709,6 +715,10 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         if (int rc = tetsim_step_n(h, 32768u, dt, params)) return rc;
         n -= 32768u;
     }
+    while (h->pj_one_launch && n > 8192u) {   // (the one-launch call of large polar bodies: n x ~4,600 workgroups in one grid, stamps inside one block)
+        if (int rc = tetsim_step_n(h, 8192u, dt, params)) return rc;
+        n -= 8192u;
+    }
     if (h->nh_one_launch) {            // (the one-launch sweep stamps substep x colour inside one block too)
         const uint32_t most = 65000u / h->nh_sweep1.ncolours;
         while (n > most) {
@@ -789,6 +799,18 @@ int tetsim_sync(tetsim_handle h) {
             h->graphs.clear();
             return fail(h, TETSIM_EHIP, "persistent frame kernel: a tile waited in vain for a neighbour tile's partial sums (workgroups not co-resident?); "
                                         "the state since then is invalid; this body falls back to one kernel per substep");
+        }
+    }
+    if (h->pj_one_launch) {   // one-launch substep: a particle wave waited in vain for a tile's partial sums (never in a correct run)
+        uint32_t err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->d_substep_err, sizeof err, hipMemcpyDeviceToHost));
+        if (err) {
+            HIPCHK(h, hipMemset(h->d_substep_err, 0, sizeof err));
+            h->pj_one_launch = false;   // two kernels per substep from now on
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            return fail(h, TETSIM_EHIP, "one-launch substep: a particle wave waited in vain for a tile's partial sums (workgroups not dispatched in grid order?); "
+                                        "the state since then is invalid; this body falls back to two kernels per substep");
         }
     }
     if (h->nh_one_launch) {   // one-launch Gauss-Seidel sweep: a cluster waited in vain for a particle of an earlier colour (never in a correct run)

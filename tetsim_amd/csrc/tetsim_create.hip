@@ -293,6 +293,14 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
                    (B.num_blocks < 2048u || force_fused);
         k.fin_in = d.pos_final; k.fin_out = d.pos_final;
         h->info.fused_particle_pass = h->fused ? 1u : 0u;
+        {   // bodies that keep two kernels per substep (>= 2,048 tiles): both in ONE launch inside tetsim_step_n (pjb_substep_kernel)
+            const char* e = getenv("TETSIM_PJ_ONE_LAUNCH");   // (read at every creation: tests build both in one process)
+            h->pj_one_launch = !(e && e[0] == '0') && !h->fused && !h->quad && !h->partitioned && nvo == nvl && ntl > 0 && B.num_blocks > 0;
+            if (h->pj_one_launch) {
+                if ((rc = dev_alloc(h, &h->d_substep_err, 1))) return rc;
+                HIPCHK(h, hipMemset(h->d_substep_err, 0, sizeof(uint32_t)));
+            }
+        }
         if (h->fused || h->quad) {
             uint32_t *dsrc, *dmax;
             if ((rc = dev_alloc(h, &dsrc, B.slot_src.size()))) return rc;

@@ -36,11 +36,16 @@ def main():
     v, t = make_lattice(cells)
     nt = len(t)
     print("lattice %d^3 cells, %d tets, %d particles; %d rounds, modes alternate inside a round" % (cells, nt, len(v), rounds))
+    print("(/2k = TETSIM_PJ_ONE_LAUNCH=0: two kernels per substep in the graphs; else tiles + particles in ONE launch per substep)")
     print("%-14s %-6s %9s %9s %9s %9s %9s %9s" % ("mode", "exit", "fall us", "G/s", "floor us", "tet us", "vert us", "tet TB/s"))
     end = {}
     for r in range(rounds):
-        for mode in ("reference", "lean", "constant-rest"):
-            for ref_exit in (False, True):
+        for mode, ref_exit, one in [(m, x, o) for m in ("reference", "lean", "constant-rest") for x in (False, True) for o in (True, False)]:
+            if True:
+                if one:
+                    os.environ.pop("TETSIM_PJ_ONE_LAUNCH", None)
+                else:
+                    os.environ["TETSIM_PJ_ONE_LAUNCH"] = "0"     # two kernels per substep inside tetsim_step_n (rounds 1-5)
                 b = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", ref_rotation_exit=ref_exit, **KW[mode])
                 frames(b, 5)
                 fall = frames(b, 20)
@@ -49,9 +54,9 @@ def main():
                 p = b.profile(SUB * 3, DT, PP)
                 tet_us = p["tet_ms"] / p["tet_launches"] * 1e3
                 vert_us = p["vertex_ms"] / max(p["vertex_launches"], 1) * 1e3
-                print("%-14s %-6s %9.2f %9.2f %9.2f %9.2f %9.2f %9.3f" % (mode, "1e-9" if ref_exit else "1e-6", fall, nt / fall / 1e3, floor, tet_us, vert_us,
+                print("%-14s %-6s %9.2f %9.2f %9.2f %9.2f %9.2f %9.3f" % (mode + ("" if one else " /2k"), "1e-9" if ref_exit else "1e-6", fall, nt / fall / 1e3, floor, tet_us, vert_us,
                                                                          BYTES[mode] * nt / (tet_us * 1e-6) / 1e12), flush=True)
-                if r == 0 and not ref_exit:
+                if r == 0 and not ref_exit and one:
                     q = b.quats
                     qq = np.empty_like(q)
                     qq[b.localTets] = q
