@@ -104,7 +104,12 @@ def pmc_traffic(kname, kernel_sha):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        return t.get(kname, {}).get("hbm_bytes_per_launch") if t.get("kernel_sha") == kernel_sha else None
+        if t.get("kernel_sha") != kernel_sha:
+            return None
+        for k, v in t.items():   # (template kernels are listed as "void name<0>" or "void name<(int)0>")
+            if isinstance(v, dict) and k.replace("void ", "").replace("(int)", "") == kname:
+                return v.get("hbm_bytes_per_launch")
+        return None
     except Exception:
         return None
 
@@ -119,7 +124,8 @@ def rocprof_kernel_stats(kname, kernel_sha):
         import csv
         with open(os.path.join(ROOT, "profiles", meta["csv"])) as f:
             for row in csv.DictReader(f):
-                if ("::" + kname + "(") in row["Name"]:
+                name = row["Name"].split("(")[0]
+                if name.endswith("::" + kname) or (kname.endswith(">") and name.endswith("::" + kname[:-3] + "<(int)" + kname[-2:])):   # ("k<0>" also as "k<(int)0>")
                     return {"file": "profiles/" + meta["csv"], "launches": int(row["Calls"]), "kernel_us": round(float(row["AverageNs"]) / 1e3, 2),
                             "stale": meta.get("kernel_sha") != kernel_sha}
     except Exception:
@@ -165,6 +171,9 @@ def run(args, rank, world, local_rank, ranks):
         if not np.isfinite(body.pos).all():
             raise SystemExit("non-finite positions after the timed region")
     nt_global = len(tets)
+    # tetsim_step_n of this body is ONE launch per call (pj_blocked.hip: pjb_call_kernel, TetSimInfo.fused_particle_pass 5): the dominant
+    # kernel is then the whole call -- tiles and particles of its 20 substeps -- and is timed as such (events around each launch)
+    one_launch = world == 1 and args.solver == "polar" and int(body.info.fused_particle_pass) == 5
     elapsed = ranks.max_float(elapsed_local) if use_dist else elapsed_local
     mg = multi_gpu_report(body, world, elapsed_local, host_local, args.steps, ranks) if use_dist else None
     if mg is not None and len(attempts) > 1:
@@ -252,6 +261,29 @@ def run(args, rank, world, local_rank, ranks):
             equal = {"elapsed": sorted(runs)[1], "runs": runs, "tet_us": acc4["tet_ms"] / acc4["tet_launches"] * 1e3, "launches": acc4["tet_launches"]}
         except Exception as e:  # noqa: BLE001
             print("[bench] the equal-work (reference threshold) leg failed: %r" % (e,), file=sys.stderr)
+    # THE CALL AS ONE LAUNCH: its own begin / end HIP events on the handle's stream around every frame's launch (tetsim_time_step_n), on
+    # bodies of their own stepped exactly like the headline body -- with the reference's rotation threshold (equal work: what `frac` is
+    # quoted on) and with the FAST exit (what `value` ran) --, over the K timed frames and, ~45 frames in, on the floor.
+    def call_windows(**kw):
+        from tetsim_amd import SoftBodyHIP
+        b = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, **kw)
+        for _ in range(args.warmup):
+            b.simulateSubsteps(SUBSTEPS, DT, pp)
+        b.sync()
+        timed = [b.timeSubsteps(SUBSTEPS, DT, pp) for _ in range(args.steps)]
+        for _ in range(max(0, 45 - args.steps - args.warmup)):
+            b.simulateSubsteps(SUBSTEPS, DT, pp)
+        floor = sorted(b.timeSubsteps(SUBSTEPS, DT, pp) for _ in range(9))
+        fin = bool(np.isfinite(b.pos).all())
+        b.close()
+        return {"timed_ms": sum(timed) / len(timed), "floor_ms": floor[4], "launches": len(timed), "finite": fin}
+    callk = None
+    if one_launch and args.precision == "fast" and not args.no_replay and rank == 0:
+        try:
+            kwf = dict(constant_rest_shape=True) if args.constant_rest_shape else dict(lean_state=True) if args.lean_state else {}
+            callk = {"ref": call_windows(ref_rotation_exit=True, **kwf), "fast": call_windows(**kwf)}
+        except Exception as e:  # noqa: BLE001
+            print("[bench] the call-kernel windows failed: %r" % (e,), file=sys.stderr)
     # THE LEAN TET RECORD (TETSIM_FLAG_LEAN_STATE): the same frames on bodies that stream 92 instead of 148 B per
     # tet (three carried corners, no quaternion) -- wall clock with the FAST exit (value_lean) and with the reference's threshold
     # (value_lean_reference_threshold), medians of three bodies from rest each, and the kernel on the floor by per-launch events + in graphs.
@@ -269,6 +301,7 @@ def run(args, rank, world, local_rank, ranks):
                     b.close()
                 return runs
             fast_runs, ref_runs = lean_runs(), lean_runs(ref_rotation_exit=True)
+            lean_call = {"ref": call_windows(lean_state=True, ref_rotation_exit=True), "fast": call_windows(lean_state=True)} if one_launch else None
             b5 = SoftBodyHIP(verts, tets, None, dict(pp), solver="polar", precision="fast", device=local_rank, lean_state=True, ref_rotation_exit=True)
             for _ in range(args.warmup):
                 b5.profile(SUBSTEPS, DT, pp)
@@ -291,7 +324,7 @@ def run(args, rank, world, local_rank, ranks):
             b5.close()
             lean = {"fast_runs": fast_runs, "ref_runs": ref_runs, "timed_tet_us": acc5["tet_ms"] / acc5["tet_launches"] * 1e3, "timed_launches": acc5["tet_launches"],
                     "floor_tet_us": fl["tet_ms"] / fl["tet_launches"] * 1e3, "floor_vert_us": fl["vertex_ms"] / max(fl["vertex_launches"], 1) * 1e3,
-                    "floor_substep_us": floor_sub, "finite": finite}
+                    "floor_substep_us": floor_sub, "finite": finite, "call": lean_call}
         except Exception as e:  # noqa: BLE001
             print("[bench] the lean-state leg failed: %r" % (e,), file=sys.stderr)
     if world == 1 or (args.profile_ranks and args.precision == "fast"):
@@ -342,7 +375,8 @@ def run(args, rank, world, local_rank, ranks):
         floor_win = window(after_us, "180 substeps after the timed region (the body lies on the floor: nine iterations in every tet whatever the threshold), "
                                      "per-launch events, median of three batches of 60")
         lead = floor_win
-        boundaries_us = (elapsed / (args.steps * SUBSTEPS) * 1e6 - tet_us - vert_us) if (win is replay and world == 1) else None
+        # (one launch per call: tiles and particles of neighbouring substeps overlap, "substep minus particle kernel minus boundaries" means nothing)
+        boundaries_us = (elapsed / (args.steps * SUBSTEPS) * 1e6 - tet_us - vert_us) if (win is replay and world == 1 and not one_launch) else None
         if floor_graph_us is not None and boundaries_us is not None:
             floor_win["in_graph"] = {"substep_us": round(floor_graph_us, 2), "kernel_us_implied": round(floor_graph_us - vert_us - boundaries_us, 2),
                                      "frac_implied": round(alg / ((floor_graph_us - vert_us - boundaries_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -445,7 +479,7 @@ def run(args, rank, world, local_rank, ranks):
                                                       "value_reference_threshold": round(out["value_lean_reference_threshold"] / out["value_reference_threshold"], 4) if "value_reference_threshold" in out else None}
             out["roofline_lean"] = rl
         # the FAST-exit replay against the wall clock of the timed region itself: a substep there is the two kernels plus two launch boundaries
-        if win is replay and world == 1:
+        if win is replay and world == 1 and not one_launch:
             sub_us = elapsed / (args.steps * SUBSTEPS) * 1e6
             out["roofline"]["timed_region_check"] = {"substep_us": round(sub_us, 2), "kernels_us": round(tet_us + vert_us, 2),
                                                      "two_launch_boundaries_us": round(sub_us - tet_us - vert_us, 2),
@@ -464,6 +498,63 @@ def run(args, rank, world, local_rank, ranks):
                                                         "kernel_vs_1GiB_copy": round(achieved / cp["1GiB"], 4),
                                                         "substep_vs_64MiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["64MiB"], 4),
                                                         "substep_vs_1GiB_copy": round(b_alg * out["value"] * 1e6 / 1e9 / cp["1GiB"], 4)}
+    if rank == 0 and pr is not None and one_launch and callk is not None:
+        # The dominant kernel of this body IS the call: pjb_call_kernel, one launch per frame (per substep every tile, then every particle).
+        # Its algorithmic bytes per launch are the WHOLE substep's (tet row + particle row = b_alg per tet-solve) x tets x 20;
+        # its duration comes from its own events around every launch.  What the kernel pair of rounds 1-5 measured (tetsim_step / tetsim_profile
+        # still run it, same bits) stays below as two_kernel_path.
+        tk = out["roofline"]
+        kcall = {"carried": "pjb_call_kernel<0>", "lean": "pjb_call_kernel<2>", "constant": "pjb_call_kernel<1>"}["lean" if args.lean_state else "constant" if args.constant_rest_shape else "carried"]
+        alg_call = b_alg * nt_global * SUBSTEPS
+
+        def cw(ms, what, alg=alg_call):
+            us = ms * 1e3
+            return {"kernel_us": round(us, 1), "substep_us": round(us / SUBSTEPS, 2), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
+                    "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "window": what}
+        how = "; one launch per frame of %d substeps, begin / end HIP events on the handle's stream around each launch (tetsim_time_step_n)" % SUBSTEPS
+        lead = cw(callk["ref"]["timed_ms"], "the %d timed frames with the reference's rotation threshold (|omega| < 1e-9: nine iterations in every tet) on a body of its own" % args.steps + how)
+        rf = {"bound": "hbm", "kernel": kcall + ": the tiles and the particles of a call's %d substeps in ONE launch, handed on by stamped partial sums / predictions" % SUBSTEPS,
+              "achieved": lead["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lead["frac"], "traffic": pmc_traffic(kcall, lib["kernel_sha"]) if cells == CELLS else None,
+              "kernel_us": lead["kernel_us"], "substep_us": lead["substep_us"], "window": lead["window"],
+              "work": "equal to the reference's: nine rotation iterations in every tet (SoftbodyGPU.js:122-139)",
+              "alg_bytes_per_launch": alg_call, "alg_bytes_per_tet_solve": round(b_alg, 1), "launches": callk["ref"]["launches"],
+              "on_floor": cw(callk["ref"]["floor_ms"], "nine launches ~45 frames in (the body lies on the floor), median" + how),
+              "fast_exit": cw(callk["fast"]["timed_ms"], "the %d timed frames with the FAST exit (what `value` ran: correction iterations end below 1e-6 rad)" % args.steps + how),
+              "fast_exit_on_floor": cw(callk["fast"]["floor_ms"], "nine launches ~45 frames in, FAST exit, median" + how),
+              "headline_wall_clock": {"substep_us": round(elapsed / (args.steps * SUBSTEPS) * 1e6, 2),
+                                      "frac": round(alg_call / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "what": "the headline's own timed region (FAST exit, no events inside): wall clock per frame against the same bytes"},
+              "substep_alg_bytes_per_tet": round(b_alg, 1), "substep_achieved": tk.get("substep_achieved"), "substep_frac": tk.get("substep_frac")}
+        if "value_reference_threshold" in out:
+            rf["frac_substep_reference_threshold"] = round(b_alg * out["value_reference_threshold"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)
+        rp = rocprof_kernel_stats(kcall, lib["kernel_sha"])
+        if rp is not None:
+            rp["frac"] = round(alg_call / (rp["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            rp["what"] = "rocprofv3 --kernel-trace --stats over this very command, profiler attached: the average over EVERY launch of the kernel (FAST exit and reference threshold, falling and on the floor)"
+            rf["frac_rocprof"], rf["rocprof"] = rp["frac"], rp
+        for k in ("measured_copy_peak", "measured_stream_peak_1GiB"):
+            if k in tk:
+                rf[k] = tk[k]
+        if "measured_copy_peak" in tk:
+            cp = tk["measured_copy_peak"]
+            rf["frac_of_measured_peak"] = {"kernel_vs_64MiB_copy": round(lead["achieved"] / cp["64MiB"], 4), "kernel_vs_1GiB_copy": round(lead["achieved"] / cp["1GiB"], 4)}
+        tk["what"] = ("the same substeps as a tet kernel + a particle kernel (tetsim_step, tetsim_profile: per-launch events; rounds 1-5's dominant kernel pjb_tet_kernel "
+                      "against its own 148 B per tet) -- same results bit for bit")
+        rf["two_kernel_path"] = tk
+        out["roofline"] = rf
+        rl = out.get("roofline_lean")
+        if rl is not None and lean is not None and lean.get("call"):
+            b_alg_lean = TET_KERNEL_BYTES_LEAN + VERTEX_BYTES * len(verts) / len(tets)
+            alg_lc = b_alg_lean * nt_global * SUBSTEPS
+            lc = lean["call"]
+            rl["two_kernel_path"] = {k: rl.pop(k) for k in ("kernel", "kernel_us", "achieved", "frac", "window", "on_floor", "timed_frames_reference_threshold", "vertex_kernel_us", "alg_bytes_per_launch") if k in rl}
+            top = cw(lc["ref"]["timed_ms"], "the %d timed frames with the reference's rotation threshold on a lean-state body of its own" % args.steps + how, alg_lc)
+            rl.update({"kernel": "pjb_call_kernel<2> (lean state)", "kernel_us": top["kernel_us"], "substep_us": top["substep_us"], "achieved": top["achieved"], "frac": top["frac"], "window": top["window"],
+                       "alg_bytes_per_launch": alg_lc, "alg_bytes_per_tet_solve": round(b_alg_lean, 1),
+                       "on_floor": cw(lc["ref"]["floor_ms"], "nine launches ~45 frames in, median" + how, alg_lc),
+                       "fast_exit": cw(lc["fast"]["timed_ms"], "the %d timed frames with the FAST exit (what value_lean ran)" % args.steps + how, alg_lc),
+                       "fast_exit_on_floor": cw(lc["fast"]["floor_ms"], "nine launches ~45 frames in, FAST exit, median" + how, alg_lc)})
+
     def whole_job_roofline():
         # N > 1 without --profile-ranks: the whole-job figure only (no extra GPU work after the timed region)
         agg = b_alg * out["value"] * 1e6 / 1e9

@@ -36,9 +36,9 @@ def other_configs(steps=20, warmup=5):
         body.close()
         return {"value": round(len(t) * n_sub * frames / el / 1e6, 2), "unit": "M tet-solves/s", "ms_per_frame": round(el / frames * 1e3, 4),
                 "us_per_substep": round(el / frames / n_sub * 1e6, 2), "frames": frames,
-                "launches_per_substep": round(1.0 / n_sub, 3) if mode == 4 else (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3), 3: round(1.0 / n_sub, 3)}[mode],
+                "launches_per_substep": round(1.0 / n_sub, 3) if mode == 4 else (levels + 1) if levels else {0: 2, 1: 1, 2: round(1.0 / n_sub, 3), 3: round(1.0 / n_sub, 3), 5: round(1.0 / n_sub, 3)}[mode],
                 "kernel": {0: "tet + particle kernel per substep", 1: "fused kernel per substep", 2: "persistent frame kernel, one lane per tet (256-tet tiles)",
-                           3: "persistent frame kernel, four lanes per tet (64-tet tiles)"}[mode] if not levels
+                           3: "persistent frame kernel, four lanes per tet (64-tet tiles)", 5: "the call's tiles and particles in one launch (stamped hand-overs)"}[mode] if not levels
                           else "Gauss-Seidel levels, one launch per frame: one workgroup, every particle in LDS" if mode == 4 else "Gauss-Seidel levels, one launch per level"}
 
     # config 1: Dragon, the reference's CPU solver (Neo-Hookean Gauss-Seidel), 10 substeps per frame

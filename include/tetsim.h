@@ -173,7 +173,12 @@ typedef struct TetSimInfo {
                                      tetsim_step is the persistent kernel for ONE substep -- one launch per call.)
                                      4: NEOHOOKEAN_GS, level schedules (TETSIM_ORDER_ORIGINAL / _COLOURED), at most 4,096 particles (PRECISE: and 12,288 tets): they all
                                      fit one CU's LDS and tetsim_step_n -- and tetsim_step -- run a whole call as ONE launch of one workgroup (one per body of a batch)
-                                     (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit */
+                                     (nh_kernels.inc); tetsim_profile keeps one launch per level, same arithmetic, same results bit for bit
+                                     5: (since ABI 5) POLAR_JACOBI + FAST blocked bodies that keep a tet and a particle kernel per substep (0: >= 2,048 tiles, or a
+                                     particle no tile sums): tetsim_step_n runs a whole CALL as ONE launch -- per substep the tiles' workgroups, then the particles',
+                                     substep after substep in one grid, partial sums and predictions handed on with the substep's sequence number in their fourth
+                                     float (pj_blocked.hip: pjb_call_kernel); tetsim_step and tetsim_profile keep the two kernels, same results bit for bit
+                                     (0 remains: partitioned bodies, PRECISE / gather bodies, TETSIM_PJ_ONE_LAUNCH=0) */
     uint32_t total_vis_verts;    /* rows of the visVerts the caller attached (num_vis_verts of them are this handle's: all, unless partitioned); since ABI 5 */
 } TetSimInfo;
 

@@ -76,10 +76,10 @@ def test_lean_state_call_of_n_equals_n_calls_equals_stepwise_kernels():
     assert a.pos[:, 1].min() < 0.02
 
 
-@pytest.mark.parametrize("cells,path", [(20, 2), (40, 1), (46, 0)])
+@pytest.mark.parametrize("cells,path", [(20, 2), (40, 1), (46, 5)])
 def test_lean_state_mid_sized_and_large_bodies(cells, path):
     """48,000 tets: one persistent launch per call over all XCDs; 384,000 tets: one fused kernel per substep; 584,016 tets: tet + particle
-    kernel per substep (the headline's path).  step_n (graph) equals step by step, and the body stays inside the default FAST path's
+    kernel per substep through tetsim_step, the whole call as one launch through tetsim_step_n (the headline's path).  step_n (graph) equals step by step, and the body stays inside the default FAST path's
     envelope against the oracle."""
     v, t = make_lattice(cells, y0=0.3)
     a, b = _lean(v, t), _lean(v, t)
@@ -181,7 +181,7 @@ def test_one_launch_substep_equals_two_kernels_bit_for_bit(kw):
     finally:
         del os.environ["TETSIM_PJ_ONE_LAUNCH"]
     c = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", **kw)
-    assert a.info.fused_particle_pass == 0
+    assert a.info.fused_particle_pass == 5 and b.info.fused_particle_pass == 0
     for k, (n, dt) in enumerate(((20, DT20), (1, DT20), (7, DT20), (3, DT20 * 2), (20, DT20))):
         if k == 2:
             for body in (a, b, c):

@@ -715,9 +715,13 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         if (int rc = tetsim_step_n(h, 32768u, dt, params)) return rc;
         n -= 32768u;
     }
-    while (h->pj_one_launch && n > 8192u) {   // (the one-launch call of large polar bodies: n x ~4,600 workgroups in one grid, stamps inside one block)
-        if (int rc = tetsim_step_n(h, 8192u, dt, params)) return rc;
-        n -= 8192u;
+    if (h->pj_one_launch) {   // (the one-launch call of large polar bodies: n x (tiles + particle workgroups) in one grid, stamps inside one block)
+        const uint64_t per_sub = (static_cast<uint64_t>(h->blk.nb) + 7u) / 8u * 8u + (h->blk.nv_owned + kBlockTile - 1u) / kBlockTile + 8u;
+        const uint32_t most = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(8192u, 0x7fffffffull / per_sub)));
+        while (n > most) {
+            if (int rc = tetsim_step_n(h, most, dt, params)) return rc;
+            n -= most;
+        }
     }
     if (h->nh_one_launch) {            // (the one-launch sweep stamps substep x colour inside one block too)
         const uint32_t most = 65000u / h->nh_sweep1.ncolours;

@@ -297,6 +297,7 @@ int create_polar(tetsim_body* h, const float* verts, uint32_t nv, const int32_t*
             const char* e = getenv("TETSIM_PJ_ONE_LAUNCH");   // (read at every creation: tests build both in one process)
             h->pj_one_launch = !(e && e[0] == '0') && !h->fused && !h->quad && !h->partitioned && nvo == nvl && ntl > 0 && B.num_blocks > 0;
             if (h->pj_one_launch) {
+                h->info.fused_particle_pass = 5u;
                 if ((rc = dev_alloc(h, &h->d_substep_err, 1))) return rc;
                 HIPCHK(h, hipMemset(h->d_substep_err, 0, sizeof(uint32_t)));
             }
