@@ -59,7 +59,8 @@ class TetSimLibraryInfo(C.Structure):
 
 DEBUG_ENV_NAMES = ["TETSIM_DEBUG_LOOPBACK_HALO", "TETSIM_DEBUG_LOOPBACK_COPY", "TETSIM_DEBUG_ONE_STREAM", "TETSIM_DEBUG_GROUP_SYNC",
                    "TETSIM_DEBUG_HOSTPROF", "TETSIM_DEBUG_TRACE", "TETSIM_HALO_SYNC", "TETSIM_HALO_GRAPH", "TETSIM_DEBUG_LOOPBACK_DELAY_US", "TETSIM_NH_QUADS", "TETSIM_FUSED_PARTICLE_PASS",
-                   "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES", "TETSIM_HALO_FOLD_WAIT", "TETSIM_QUAD", "TETSIM_QUAD_POLL_DELAY", "TETSIM_NH_FRAME"]
+                   "TETSIM_FRAME_KERNEL", "TETSIM_FRAME_LOCAL", "TETSIM_NH_FOLD", "TETSIM_HALO_ALIGNED_TILES", "TETSIM_HALO_FOLD_WAIT", "TETSIM_QUAD", "TETSIM_QUAD_POLL_DELAY", "TETSIM_NH_FRAME",
+                   "TETSIM_NH_ONE_LAUNCH", "TETSIM_PJ_ONE_LAUNCH"]
 
 
 # A/B switches of settled choices: read (and reported) by the development build only (csrc/body.h: lab_env, build_info.cpp)

@@ -25,7 +25,8 @@ extern "C" int tetsim_library_info(TetSimLibraryInfo* out) {
         {"TETSIM_DEBUG_LOOPBACK_HALO", false}, {"TETSIM_DEBUG_LOOPBACK_COPY", false}, {"TETSIM_DEBUG_ONE_STREAM", false}, {"TETSIM_DEBUG_GROUP_SYNC", false},
         {"TETSIM_DEBUG_HOSTPROF", false}, {"TETSIM_DEBUG_TRACE", true}, {"TETSIM_HALO_SYNC", false}, {"TETSIM_HALO_GRAPH", false}, {"TETSIM_DEBUG_LOOPBACK_DELAY_US", false},
         {"TETSIM_NH_QUADS", true}, {"TETSIM_FUSED_PARTICLE_PASS", false}, {"TETSIM_FRAME_KERNEL", false}, {"TETSIM_FRAME_LOCAL", true}, {"TETSIM_NH_FOLD", true},
-        {"TETSIM_HALO_ALIGNED_TILES", true}, {"TETSIM_HALO_FOLD_WAIT", false}, {"TETSIM_QUAD", false}, {"TETSIM_QUAD_POLL_DELAY", true}, {"TETSIM_NH_FRAME", true}};
+        {"TETSIM_HALO_ALIGNED_TILES", true}, {"TETSIM_HALO_FOLD_WAIT", false}, {"TETSIM_QUAD", false}, {"TETSIM_QUAD_POLL_DELAY", true}, {"TETSIM_NH_FRAME", true},
+        {"TETSIM_NH_ONE_LAUNCH", false}, {"TETSIM_PJ_ONE_LAUNCH", false}};
     for (unsigned i = 0; i < sizeof(kEnv) / sizeof(kEnv[0]); i++) {
 #ifndef TETSIM_ABLATION
         if (kEnv[i].lab) continue;

@@ -592,12 +592,14 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             // eight one after the other, in f64 -- as long as the pass it replaces (measured: 132 against 120 us per substep)
             h->nh_fold = h->fast && !(q && q[0] == '0') && !(e && e[0] == '0');
         }
+        for (uint32_t l = 0; l < nl; l++) {   // (colour l's clusters sit at [mask_off[l], mask_off[l + 1]) of the per-cluster tables)
+            const uint32_t nsteps = plan.step_off[l + 1] - plan.step_off[l];
+            mask_off[l + 1] = mask_off[l] + (nsteps ? plan.step_count[plan.step_off[l]] : 0);
+        }
         if (h->nh_fold) {
             std::vector<uint8_t> seen(nv, 0);
             for (uint32_t l = 0; l < nl; l++) {
-                const uint32_t nsteps = plan.step_off[l + 1] - plan.step_off[l];
-                const uint32_t clusters = nsteps ? plan.step_count[plan.step_off[l]] : 0;
-                mask_off[l + 1] = mask_off[l] + clusters;
+                const uint32_t clusters = mask_off[l + 1] - mask_off[l];
                 first_mask.resize(mask_off[l + 1], 0);
                 for (uint32_t k = 0; k < kClusterVerts; k++)
                     for (uint32_t i = 0; i < clusters; i++) {
@@ -629,6 +631,9 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
         // the slot's particle sits (0 = first touch of the sweep: first_mask's bit) and whether this cluster is the last to touch it;
         // the inverse masses as part of the cluster record; one exchange cell per particle.  The folded particle pass is part of it.
         const bool allow_one_launch = [] { const char* e = getenv("TETSIM_NH_ONE_LAUNCH"); return !(e && e[0] == '0'); }();   // (read at every creation: tests build both in one process)
+        // (FAST, four lanes per cluster with the folded particle pass.  PRECISE -- one lane per cluster in f64, bit-exact -- was built the same
+        // way for the 1 M-tet lattice and measured SLOWER: 128.6 against 116.7 us per substep with one launch per colour; every look at a
+        // handed-on particle is a memory-side load where the per-colour launches hit the L2, 8 per lane: removed, HISTORY.md round 6)
         if (allow_one_launch && h->nh_fold && nl >= 2 && nl <= 255u && nv > 0) {
             const size_t ncl = mask_off[nl];
             std::vector<float> slot_im(plan.slot_vid.size(), 0.0f);
