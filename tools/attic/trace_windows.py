@@ -8,7 +8,7 @@ command.  Windows in the order bench.py issues them (benchlib/headline.py):
 Per window: the tet kernel's mean duration, the particle kernel's, and the mean start-to-start interval of consecutive tet
 kernels inside a frame (= what a substep takes there; interval - kernels = the two launch boundaries, or the host's gaps in the
 per-launch-event windows).
-python tools/trace_windows.py <..._kernel_trace.csv> [K=20] [W=5] [substeps=20]"""
+python tools/attic/trace_windows.py <..._kernel_trace.csv> [K=20] [W=5] [substeps=20]"""
 import csv, sys
 path = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20

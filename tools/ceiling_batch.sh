@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-beyond-mall > "$OUT/stats.log" 2>&1 )
-python tools/trace_windows.py "$OUT/stats/s_kernel_trace.csv" > "$OUT/kernel_windows.txt" 2>&1
+python tools/kernel_launch_stats.py "$OUT/stats/s_kernel_trace.csv" > "$OUT/kernel_windows.txt" 2>&1
 # counters of the EQUAL-WORK kernel: the headline body with the reference's rotation threshold (nine iterations in every tet)
 BENCH_ARGS="--reference-rotation-exit --no-replay" timeout 900 bash tools/pmc_run.sh $TAG/pmc > "$OUT/pmc.log" 2>&1
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_counters.txt" 2>&1
