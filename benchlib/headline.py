@@ -124,8 +124,8 @@ def rocprof_kernel_stats(kname, kernel_sha):
         import csv
         with open(os.path.join(ROOT, "profiles", meta["csv"])) as f:
             for row in csv.DictReader(f):
-                name = row["Name"].split("(")[0]
-                if name.endswith("::" + kname) or (kname.endswith(">") and name.endswith("::" + kname[:-3] + "<(int)" + kname[-2:])):   # ("k<0>" also as "k<(int)0>")
+                name = row["Name"].replace("tetsim::(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("(int)", "").strip()
+                if name == kname:   # ("void tetsim::(anonymous namespace)::k<0>(...)" -> "k<0>")
                     return {"file": "profiles/" + meta["csv"], "launches": int(row["Calls"]), "kernel_us": round(float(row["AverageNs"]) / 1e3, 2),
                             "stale": meta.get("kernel_sha") != kernel_sha}
     except Exception:

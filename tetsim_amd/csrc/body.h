@@ -286,6 +286,7 @@ struct tetsim_body {
     // clustered FAST bodies: the sweep as ONE launch per substep, particles handed on with their stamp (dev_common.h: NHSweep);
     // TETSIM_NH_ONE_LAUNCH=0 at creation keeps one launch per colour (A/B); tetsim_profile always does (it times the colour kernels)
     bool nh_one_launch = false;
+    bool nh_call = false;             // ... and tetsim_step_n runs the sweeps of ALL its substeps as one launch (nh_call_kernel: every particle touched by some cluster, <= 127 colours)
     NHSweep nh_sweep1;
     uint32_t nh_sub_index = 0;        // substep inside the run being enqueued (enqueue_substep: first -> 0)
     uint32_t nh_epoch_arg = 0;        // tetsim_step: a block of stamps of its own as a kernel argument; 0 = DevParams::epoch (tetsim_step_n)

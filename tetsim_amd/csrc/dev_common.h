@@ -136,6 +136,7 @@ struct NHSweepColour {
     const float* slot_im = nullptr;      // [kNHClusterVerts][clusters]
     const uint2* delta = nullptr;        // [clusters] a byte per slot
     const uint8_t* last_mask = nullptr;  // [clusters] bit k: no later cluster of the sweep touches the particle in slot k
+    const uint2* delta_first = nullptr;  // [clusters] a byte per FIRST-touch slot: colours back to the particle's last toucher of the PREVIOUS sweep (nh_call_kernel)
     uint32_t first_block = 0;            // of this colour in the one-launch grid (4 waves of 16 clusters per block)
     uint32_t pad = 0;
 };
@@ -148,6 +149,9 @@ struct NHSweep {
 };
 // sub_index: substep inside the call (stamps of different substeps never collide); epoch: first stamp of the call, 0 = DevParams::epoch
 void nh_launch_sweep1_fast(hipStream_t s, const NHDev& d, const NHSweep& w, bool fold, uint32_t sub_index, uint32_t epoch);
+// the sweeps of ALL n substeps of a call in one launch (nh_kernels.inc: nh_call_kernel; bodies with NHSweepColour::delta_first): in front of it
+// the prediction kernel, behind it the kernel that ends the call; stamps start at DevParams::epoch
+void nh_launch_call_fast(hipStream_t s, const NHDev& d, const NHSweep& w, uint32_t n);
 
 // launchers (one set per arithmetic mode; defined in pj_precise.hip / pj_fast.hip / nh_*.hip)
 // e0/e1 (optional): HIP events that timestamp the kernel's own begin and end (hipExtLaunchKernelGGL), for

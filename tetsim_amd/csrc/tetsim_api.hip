@@ -405,6 +405,13 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         pjb_launch_call(h->stream, h->blk, n, h->d_substep_err, halo_timeout_ms(h));
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    } else if (h->nh_call && h->nh_one_launch) {
+        // clustered FAST Neo-Hookean bodies: prediction | the sweeps of all n substeps in ONE launch (nh_kernels.inc: nh_call_kernel) | the kernel that ends the call
+        nh_launch_predict_fast(h->stream, h->nh);
+        nh_launch_call_fast(h->stream, h->nh, h->nh_sweep1, n);
+        nh_launch_post_fast(h->stream, h->nh);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else if (h->nh_frame) {
         // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
         h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, n) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, n);

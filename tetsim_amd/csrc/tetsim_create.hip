@@ -659,7 +659,26 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
                     }
             }
             for (uint32_t v = 0; v < nv; v++) if (last_colour[v] >= 0) last_mask[last_cell[v] >> 3] |= static_cast<uint8_t>(1u << (last_cell[v] & 7u));
-            float* d_im; uint2* d_delta; uint8_t* d_last; NHSweepColour* d_cols;
+            // ... and, for a call as ONE launch (nh_call_kernel): how far back a first toucher finds its particle's last toucher of the sweep before
+            const bool call = h->nh_untouched == 0 && nl <= 127u;
+            std::vector<uint2> delta_first(call ? ncl : 0, make_uint2(0u, 0u));
+            if (call)
+                for (uint32_t l = 0; l < nl; l++) {
+                    const uint32_t clusters = mask_off[l + 1] - mask_off[l];
+                    for (uint32_t k = 0; k < kClusterVerts; k++)
+                        for (uint32_t i = 0; i < clusters; i++) {
+                            const int32_t v = plan.slot_vid[plan.vid_off[l] + static_cast<size_t>(k) * clusters + i];
+                            if (v < 0 || !((first_mask[mask_off[l] + i] >> k) & 1u)) continue;
+                            const uint32_t back = l + nl - static_cast<uint32_t>(last_colour[v]);
+                            uint2& dfv = delta_first[mask_off[l] + i];
+                            if (k < 4u) dfv.x |= back << (8u * k); else dfv.y |= back << (8u * (k - 4u));
+                        }
+                }
+            float* d_im; uint2 *d_delta, *d_dfirst = nullptr; uint8_t* d_last; NHSweepColour* d_cols;
+            if (call) {
+                if ((rc = dev_alloc(h, &d_dfirst, delta_first.size()))) return rc;
+                if ((rc = upload(h, d_dfirst, delta_first))) return rc;
+            }
             if ((rc = dev_alloc(h, &d_im, slot_im.size()))) return rc;
             if ((rc = upload(h, d_im, slot_im))) return rc;
             if ((rc = dev_alloc(h, &d_delta, delta.size()))) return rc;
@@ -673,6 +692,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
                 cols[l].slot_im = d_im + plan.vid_off[l];
                 cols[l].delta = d_delta + mask_off[l];
                 cols[l].last_mask = d_last + mask_off[l];
+                cols[l].delta_first = call ? d_dfirst + mask_off[l] : nullptr;
                 cols[l].first_block = blocks;
                 blocks += (h->cluster_launch[l].clusters + 63u) / 64u;
             }
@@ -686,6 +706,7 @@ int create_neohookean(tetsim_body* h, const float* verts, uint32_t nv, const int
             HIPCHK(h, hipMemset(w.error, 0, sizeof(uint32_t)));
             w.timeout_ms = halo_timeout_ms(h);
             h->nh_one_launch = true;
+            h->nh_call = call;
         }
     }
     // Small bodies with a level schedule (the reference's own workload, main.js:26-27): every particle of a body fits one CU's LDS (40 B
