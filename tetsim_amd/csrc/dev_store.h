@@ -10,6 +10,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// units of 64 clocks between two looks of a wave that waits for stamped data of another workgroup (pj_blocked.hip: pjb_call_kernel,
+// nh_kernels.inc: nh_sweep1_kernel / nh_call_kernel); -DTETSIM_POLL_SLEEP=n builds an A/B variant
+// (profiles/r06_poll_sleep.txt: the polar call kernel does not care -- 2 / 8 / 32: level --, the Gauss-Seidel chain does: 40.9-42.3 / 41.6-42.8 /
+// 44.3-45.6 us per substep)
+#ifndef TETSIM_POLL_SLEEP
+#define TETSIM_POLL_SLEEP 8
+#endif
+#ifndef TETSIM_NH_POLL_SLEEP
+#define TETSIM_NH_POLL_SLEEP 2
+#endif
+
 namespace tetsim {
 
 constexpr uint32_t kStoreWtMaxIndex = 1u << 27;  // 32-bit byte offsets: a float4 array of up to 2 GiB

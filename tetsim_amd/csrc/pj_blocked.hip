@@ -258,7 +258,7 @@ __device__ __forceinline__ void pjb_tet_body(const PJBlk& d, uint32_t tile_first
             if (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
                 const long long t0 = wall_clock64(), limit = 100000ll * poll->timeout_ms;   // 100 MHz ticks; 0 = unbounded
                 do {
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(TETSIM_POLL_SLEEP);
                     asm volatile("" ::: "memory");   // (every look is a fresh load)
                     if (pend) { pos_stage = load_coherent(d.pos_pred, vid); pend = __float_as_uint(pos_stage.w) != poll->want; }
                     if (limit && pend && wall_clock64() - t0 > limit) { __hip_atomic_store(poll->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); pend = false; }
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(kTile, 2) void pjb_call_kernel(PJBlk d, uint32_t n_
         if (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
             const long long t0 = wall_clock64();
             do {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(TETSIM_POLL_SLEEP);
                 asm volatile("" ::: "memory");   // (every look is a fresh load)
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; j++)
