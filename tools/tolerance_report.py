@@ -105,7 +105,7 @@ def main():
             reasons[k] = why
         if a == "--reasons":
             reasons.update(json.load(open(args[i + 1])))
-    round_tag = next((args[i + 1] for i, a in enumerate(args) if a == "--round"), "round 5")
+    round_tag = next((args[i + 1] for i, a in enumerate(args) if a == "--round"), "round 6")
     print("%-84s %10s %10s %10s %10s" % ("check", "observed", "stated", "3x observed", "ceiling"))
     for k, r in rows.items():
         o, a = r["observed"], r["allowed"]
