@@ -22,7 +22,9 @@ DT = (1.0 / 60.0) / 20
 v, t = make_lattice(cells, nz=cells * nranks, y0=0.02)          # close to the floor: contact within the run
 plane = (cells + 1) * (cells + 1)
 owner = np.minimum((np.arange(len(v)) // plane) // cells, nranks - 1).astype(np.int32)
-kw = dict(solver="polar", precision=precision, ref_fixed_bounds=False)
+lean = precision == "fast-lean"          # TETSIM_FLAG_LEAN_STATE over the RCCL halo: ghost tets evolve their three corners identically on both sides of a cut
+precision = precision.split("-")[0]
+kw = dict(solver="polar", precision=precision, ref_fixed_bounds=False, lean_state=lean)
 
 dts = [DT * (2.0 if c == 2 else 0.5 if c == 4 else 1.0) for c in range(calls)]   # the time step changes twice mid-run
 # an embedded visual mesh over the whole body: every rank skins the rows whose tet it owns (ghost corners fetched over the transport)

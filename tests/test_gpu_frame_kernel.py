@@ -168,6 +168,41 @@ def test_an_exclusive_body_is_counted_from_its_creation():
     assert np.isfinite(dragon.pos).all()
 
 
+def test_an_exclusive_body_and_one_launch_calls_take_turns():
+    """Round 6 (tools/soak.py found it): the one-launch calls of large bodies (pjb_call_kernel, nh_call_kernel: workgroups that WAIT for
+    stamped data of workgroups dispatched before them) next to an exclusive persistent frame kernel (515 tiles that must ALL be resident)
+    could each hold the slots the other needed -- 'a tile waited in vain' after the bounded wait, every call.  While an exclusive body
+    lives, those launches take part in the device's turn-taking too: stepped round-robin without synchronising, every body equals its
+    solo run bit for bit and no wait gives up (tetsim_sync would raise)."""
+    lv, lt = make_lattice(28, y0=0.05)
+    bv, bt = make_lattice(46, y0=0.05)
+
+    makers = [lambda: SoftBodyHIP(lv, lt, None, dict(PP), solver="polar", precision="fast"),
+              lambda: SoftBodyHIP(bv, bt, None, dict(PP), solver="polar", precision="fast"),
+              lambda: SoftBodyHIP(bv, bt, None, dict(PP), solver="polar", precision="fast", lean_state=True),
+              lambda: SoftBodyHIP(lv, lt, None, dict(PP), solver="neohookean", precision="fast", order="clustered")]
+    calls = [int(n) for n in np.random.default_rng(1).integers(1, 41, size=40)]
+    ref = []
+    for make in makers:                      # each alone first (no other body alive: nothing to take turns with)
+        body = make()
+        for n in calls:
+            body.simulateSubsteps(n, DT, PP)
+        ref.append(body.pos)
+        body.close()
+    together = [make() for make in makers]
+    assert [b.info.fused_particle_pass for b in together] == [2, 5, 5, 0]
+    for n in calls:
+        for b in together:
+            b.simulateSubsteps(n, DT, PP)
+    for b, r in zip(together, ref):
+        b.sync()
+        assert _same(b.pos, r)
+    together[3].simulate(DT, PP)             # ... and tetsim_step of the one-launch sweep takes its turn too
+    together[0].simulate(DT, PP)
+    together[3].sync()
+    together[0].sync()
+
+
 def _wheel(spokes):
     """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
     ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)

@@ -195,3 +195,22 @@ def test_one_launch_substep_equals_two_kernels_bit_for_bit(kw):
             c.simulate(dt, PP)                   # tetsim_step: eager kernel pairs
         assert _same(a.pos, b.pos) and _same(a.pos, c.pos) and _same(a.vel, c.vel), (kw, k)
     assert _same(a.quats, c.quats) and a.pos[:, 1].min() == 0.0
+
+
+def test_two_one_launch_calls_side_by_side():
+    """Two large bodies on their own streams, both stepping whole calls as one launch of stamped hand-overs, without synchronising in
+    between: each kernel's waiting workgroups only ever wait for workgroups of the SAME kernel dispatched before them, so the two cannot
+    starve each other -- each equals its solo run bit for bit and no wait gives up (tetsim_sync would say so)."""
+    v, t = make_lattice(46, y0=0.02)
+    solo = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")
+    pair = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast"), SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", lean_state=True),
+            SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast")]
+    for _ in range(12):
+        for b in pair:
+            b.simulateSubsteps(20, DT20, PP)
+    for _ in range(12):
+        solo.simulateSubsteps(20, DT20, PP)
+    for b in pair:
+        b.sync()
+    assert _same(pair[0].pos, solo.pos) and _same(pair[2].pos, solo.pos) and np.isfinite(pair[1].pos).all()
+    assert all(b.info.fused_particle_pass == 5 for b in pair)

@@ -478,7 +478,7 @@ def test_rccl_transport_selftest():
         assert 0.0 < host.value <= total.value < 1e4
 
 
-@pytest.mark.parametrize("nranks,precision,cells", [(2, "precise", 6), (3, "precise", 5), (2, "fast", 12), (4, "fast", 8), (3, "fast", 20)])
+@pytest.mark.parametrize("nranks,precision,cells", [(2, "precise", 6), (3, "precise", 5), (2, "fast", 12), (4, "fast", 8), (3, "fast", 20), (3, "fast-lean", 20)])
 def test_rccl_code_path_against_a_strict_test_double(nranks, precision, cells):
     """The RCCL-mode halo path (tetsim_comm_init + grouped ncclSend/ncclRecv per substep, boundary tiles on the halo
     stream) with N ranks = N host threads on this one GPU, librccl replaced by tests/mock_rccl (which rejects unmatched or

@@ -238,7 +238,8 @@ void nh_sweep(tetsim_body* h, bool fold, bool last, bool one_launch) {
     }
 }
 
-// Persistent frame kernels need every workgroup of their grid resident at once.  Bodies of at most half the device's slots fit side
+// Persistent frame kernels need every workgroup of their grid resident at once (and the one-launch calls of round 6 keep waiting workgroups
+// resident: they take part in the turns below).  Bodies of at most half the device's slots fit side
 // by side; once a body that needs MORE lives on a device (`frame_exclusive`), the frame launches of that device's bodies take turns:
 // a launch waits for the previous one (of another body) to finish.  Nothing happens, and nothing is paid, without such a body.
 // The count is taken when the exclusive body is CREATED (frame_turn_enter, from create_polar) -- not at its first launch: persistent
@@ -708,7 +709,8 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
         h->epoch_block_fresh = false;
         h->nh_epoch_arg = h->frame_epoch;
     }
-    rc = enqueue_substep(h);
+    if (h->nh_one_launch) rc = launch_in_turn(h, [&]() -> int { return enqueue_substep(h); });   // (see tetsim_step_n)
+    else rc = enqueue_substep(h);
     h->nh_epoch_arg = 0u;
     if (!rc) rc = flush_v(h);
     return rc;
@@ -788,7 +790,11 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         }
         it = h->graphs.emplace(n, exec).first;
     }
-    if (h->frame)
+    // (... and so do the calls that run as ONE launch of stamped hand-overs -- pjb_call_kernel, nh_sweep1 / nh_call_kernel: their waiting
+    // workgroups hold slots too.  Beside a body whose persistent launch needs most of the device resident AT ONCE the two deadlock until a
+    // wait gives up: the frame kernel's resident tiles fill an XCD waiting for tiles that find no slot, the call kernel's workgroups fill the
+    // rest waiting for a workgroup that is next in line on THAT XCD -- tools/soak.py, round 6.  Nothing is paid without such a body.)
+    if (h->frame || h->pj_one_launch || h->nh_one_launch)
         return launch_in_turn(h, [&]() -> int { HIPCHK(h, hipGraphLaunch(it->second, h->stream)); return 0; });
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return 0;

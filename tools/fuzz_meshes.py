@@ -37,6 +37,34 @@ for seed in range(first, first + count):
     if not (same(a.pos, b.pos) and same(a.pos, c.pos) and same(a.quats, c.quats)): msgs.append("polar fast launch / steps / stepwise kernels differ (mode %d)" % a.info.fused_particle_pass)
     err = float(np.abs(a.pos - o.pos).max())
     if not err < 5e-4: msgs.append("polar fast vs oracle %.3g" % err)
+    # round 6: the lean tet record (call == steps == stepwise kernels, and inside the FAST envelope), the kernel pair through the one-launch
+    # call (a loose particle puts a small body on path 5), the clustered FAST sweep as one launch per substep /
+    # per call against one launch per colour
+    a, b, c = [SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="fast", lean_state=True) for _ in range(3)]
+    for n in (20, 1, 19):
+        a.simulateSubsteps(n, DT, PP)
+        for _ in range(n): b.simulate(DT, PP)
+        c.profile(n, DT, PP)
+    if not (same(a.pos, b.pos) and same(a.pos, c.pos) and same(a.quats, c.quats)): msgs.append("polar lean launch / steps / stepwise kernels differ (mode %d)" % a.info.fused_particle_pass)
+    err_l = float(np.abs(a.pos - o.pos).max())
+    if not err_l < 5e-4: msgs.append("polar lean vs oracle %.3g" % err_l)
+    v2 = np.concatenate([v, [[3.0, 3.0, 3.0]]]).astype(np.float32)      # a loose particle: no tile sums it, the body keeps the kernel pair -- path 5 inside tetsim_step_n
+    a, b = [SoftBodyHIP(v2, t, None, dict(PP), solver="polar", precision="fast", lean_state=bool(seed & 1)) for _ in range(2)]
+    for n in (20, 1, 19):
+        a.simulateSubsteps(n, DT, PP)
+        for _ in range(n): b.simulate(DT, PP)
+    if not (a.info.fused_particle_pass == 5 and same(a.pos[:-1], b.pos[:-1]) and same(a.quats, b.quats)): msgs.append("one-launch call != kernel pair (mode %d)" % a.info.fused_particle_pass)
+    a = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order="clustered")
+    os.environ["TETSIM_NH_ONE_LAUNCH"] = "0"
+    try:
+        b = SoftBodyHIP(v, t, None, dict(PP), solver="neohookean", precision="fast", order="clustered")
+    finally:
+        del os.environ["TETSIM_NH_ONE_LAUNCH"]
+    for n in (7, 1, 12):
+        a.simulateSubsteps(n, DT * 2, PP)
+        for _ in range(n): b.simulate(DT * 2, PP)
+    a.simulate(DT * 2, PP); b.simulateSubsteps(1, DT * 2, PP)
+    if not (same(a.pos, b.pos) and a.volError == b.volError and np.isfinite(a.pos).all()): msgs.append("NH clustered one-launch != one launch per colour")
     p = SoftBodyHIP(v, t, None, dict(PP), solver="polar", precision="precise")
     p.simulateSubsteps(40, DT, PP)
     if not same(p.pos, o.pos): msgs.append("polar precise != oracle (max %.3g)" % float(np.abs(p.pos - o.pos).max()))

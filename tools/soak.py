@@ -12,12 +12,18 @@ PP = dict(gravity=-9.81, friction=1000.0, density=1000.0, devCompliance=1e-5, vo
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dv, dt_ = load_mesh("dragon")
 lv, lt = make_lattice(28, y0=0.05)
+bv, bt = make_lattice(46, y0=0.05)
 mk = lambda: [SoftBodyHIP(dv, dt_, None, dict(PP), solver="polar", precision="fast"),
               SoftBodyHIP(lv, lt, None, dict(PP), solver="polar", precision="fast"),
               SoftBodyHIP(dv, dt_, None, dict(PP), solver="neohookean", precision="precise", order="coloured"),
-              SoftBodyHIP(dv, dt_, None, dict(PP), solver="neohookean", precision="fast", order="coloured")]
+              SoftBodyHIP(dv, dt_, None, dict(PP), solver="neohookean", precision="fast", order="coloured"),
+              # round 6: calls as ONE launch with stamped hand-overs -- a large polar body (2,282 tiles) with the reference's and with the lean
+              # record, the clustered FAST Gauss-Seidel sweeps of a lattice
+              SoftBodyHIP(bv, bt, None, dict(PP), solver="polar", precision="fast"),
+              SoftBodyHIP(bv, bt, None, dict(PP), solver="polar", precision="fast", lean_state=True),
+              SoftBodyHIP(lv, lt, None, dict(PP), solver="neohookean", precision="fast", order="clustered")]
 A, B = mk(), mk()
-print("paths", [int(b.info.fused_particle_pass) for b in A])
+print("paths", [int(b.info.fused_particle_pass) for b in A], flush=True)
 DT = (1 / 60) / 20
 t0 = time.time(); calls = 0; sub = 0
 rng = np.random.default_rng(1)
