@@ -195,7 +195,7 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
 // n substeps -- per substep every tile, then every owned particle -- as ONE launch (pj_blocked.hip: pjb_call_kernel): partial sums and
 // predictions carry the sequence number (d.epoch or DevParams::epoch) + substep + 1, their readers look for it; err: raised by a wave that
 // waited in vain.  n * blocks per substep must fit a grid (tetsim_step_n chunks long calls).
-void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, uint32_t timeout_ms);
+void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev);
 // the same tiles with the previous substep's particle update fused into the staging (d.partial_prev / fin_in / fin_out set)
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjb_launch_vertex(hipStream_t s, const PJBlk& d, uint32_t first, uint32_t count, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,

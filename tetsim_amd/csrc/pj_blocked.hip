@@ -745,11 +745,15 @@ __global__ __launch_bounds__(64) void pjb_vertex_kernel(PJBlk d, uint32_t first,
 // pass -- two dependent memory trips and little else -- and the tiles' staging run under the neighbouring passes' compute.  The
 // arithmetic is pjb_tet_body's and pjb_vertex_update's, operation for operation: a call equals the same substeps through the two
 // kernels (tetsim_step, tetsim_profile) bit for bit.
+//   The call's parameters arrive BY VALUE, with the launch: the 176-byte upload in front of every call (a copy, its event, the switch between
+// the copy engine and the compute queue) was most of the ~18 us the device idled between two calls (tools/call_gap.py).  The first workgroup
+// leaves them in DevParams for the kernels behind this one (tetsim_step's pair, the read-outs).
 template <int kMode>
 __global__ __launch_bounds__(kTile, 2) void pjb_call_kernel(PJBlk d, uint32_t n_sub, uint32_t tile_count, uint32_t tiles_per_xcd, uint32_t tet_blocks, uint32_t blocks_per_sub,
-                                                           uint32_t* err, uint32_t timeout_ms TETSIM_DBG_PARAM) {
+                                                           uint32_t* err, uint32_t timeout_ms, DevParams pv, DevParams* pdev TETSIM_DBG_PARAM) {
     const uint32_t sub = blockIdx.x / blocks_per_sub, r = blockIdx.x - sub * blocks_per_sub;   // (blocks_per_sub is a multiple of 8: r and blockIdx.x land on the same XCD)
-    const uint32_t stamp = (d.epoch ? d.epoch : d.params->epoch) + sub + 1u;
+    const uint32_t stamp = (d.epoch ? d.epoch : pv.epoch) + sub + 1u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *pdev = pv;
     if (r < tet_blocks) {
         const PJPoll poll = {r, sub ? stamp - 1u : 0u, err, timeout_ms};
         pjb_tet_body<kMode, false, false, false, true>(d, 0u, tile_count, tiles_per_xcd TETSIM_DBG_ARG, nullptr, stamp, &poll);
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(kTile, 2) void pjb_call_kernel(PJBlk d, uint32_t n_
             if (limit && wall_clock64() - t0 > limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
         }
     }
-    const VertexOut o = pjb_vertex_update(xyz(acc), wsum, xyz(prev), *d.params, v);
+    const VertexOut o = pjb_vertex_update(xyz(acc), wsum, xyz(prev), pv, v);
     store_wt(d.fin_out, v, make_float4(o.p.x, o.p.y, o.p.z, __uint_as_float(stamp)));
     if (d.vel && sub + 1u == n_sub) store_wt(d.vel, v, make_float4(o.vel.x, o.vel.y, o.vel.z, 0.0f));   // (the velocity array: behind a call's last substep only)
     store_wt(d.pos_pred, v, make_float4(o.pred.x, o.pred.y, o.pred.z, __uint_as_float(stamp)));
@@ -938,12 +942,12 @@ void pjb_launch_tet(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, e0, e1, 0, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
     else hipLaunchKernelGGL(kernel, dim3(per_xcd * 8u), dim3(kTile), 0, s, d, tile_first, tile_count, per_xcd TETSIM_DBG_LAUNCH);
 }
-void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, uint32_t timeout_ms) {
+void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev) {
     if (d.nb == 0 || n == 0) return;
     const uint32_t per_xcd = (d.nb + 7u) / 8u, tet_blocks = per_xcd * 8u, per_sub = (tet_blocks + (d.nv_owned + kTile - 1u) / kTile + 7u) & ~7u;
     const int mode = blk_mode(d);
     auto* kernel = mode == kModeConstantRest ? pjb_call_kernel<kModeConstantRest> : mode == kModeLeanState ? pjb_call_kernel<kModeLeanState> : pjb_call_kernel<kModeCarried>;
-    hipLaunchKernelGGL(kernel, dim3(per_sub * n), dim3(kTile), 0, s, d, n, d.nb, per_xcd, tet_blocks, per_sub, err, timeout_ms TETSIM_DBG_LAUNCH);
+    hipLaunchKernelGGL(kernel, dim3(per_sub * n), dim3(kTile), 0, s, d, n, d.nb, per_xcd, tet_blocks, per_sub, err, timeout_ms, params, params_dev TETSIM_DBG_LAUNCH);
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) { launch_tet_x(s, d, 0u, d.nb, TetFused{0u}, e0, e1); }
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,

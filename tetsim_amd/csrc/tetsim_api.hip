@@ -154,6 +154,22 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
     return 0;
 }
 
+// The parameters of a call whose ONE launch takes them by value (pjb_call_kernel: its first workgroup leaves them in DevParams for the
+// kernels behind it): the same checks, a fresh block of sequence numbers, the host's record of what the device holds once the launch has
+// run -- and no copy, no event, no pinned slot.
+int stage_params(tetsim_body* h, double dt, const TetSimParams* params) {
+    if (!params) return fail(h, TETSIM_EINVAL, "params is null");
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
+    HIPCHK(h, hipSetDevice(h->opt.device));
+    h->final_ghosts_fresh = false;
+    h->quat_stale = true;
+    if (int rc = next_epoch_block(h)) return rc;
+    h->epoch_block_fresh = false;
+    fill_params(h, dt, *params, &h->params_on_device);
+    h->params_known = true;
+    h->fork_needed = true;
+    return 0;
+}
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
 void pj_tet(tetsim_body* h, hipEvent_t e0, hipEvent_t e1) {
@@ -400,12 +416,6 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
         // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
         rc = launch_frame_kernel(h, n, 0u);
-    } else if (h->pj_one_launch) {
-        // large unpartitioned polar bodies: the n substeps' tiles and particles in ONE grid, handed on by stamped data (pj_blocked.hip:
-        // pjb_call_kernel); the sequence numbers start at DevParams::epoch (this call's parameter upload took a fresh block)
-        pjb_launch_call(h->stream, h->blk, n, h->d_substep_err, halo_timeout_ms(h));
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     } else if (h->nh_call && h->nh_one_launch) {
         // clustered FAST Neo-Hookean bodies: prediction | the sweeps of all n substeps in ONE launch (nh_kernels.inc: nh_call_kernel) | the kernel that ends the call
         nh_launch_predict_fast(h->stream, h->nh);
@@ -740,6 +750,21 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         }
     }
     HIPCHK(h, hipSetDevice(h->opt.device));
+    if (h->pj_one_launch && !has_transport(h)) {
+        // large unpartitioned polar bodies: the n substeps' tiles and particles in ONE grid, handed on by stamped data (pj_blocked.hip:
+        // pjb_call_kernel), launched directly -- one kernel needs no graph -- with the call's parameters among its arguments.  Only a call
+        // whose dt differs from the prediction's uploads them first: the re-prediction in front of it reads DevParams.
+        const bool repredict = !h->pred_any_dt && static_cast<float>(dt) != h->dt_pred;
+        int rc = repredict ? push_params(h, dt, params) : stage_params(h, dt, params);
+        if (rc) return rc;
+        if ((rc = ensure_prediction(h, dt))) return rc;
+        // (in turn with an exclusive frame-kernel body, if one lives on this device: see the graph launch below)
+        return launch_in_turn(h, [&]() -> int {
+            pjb_launch_call(h->stream, h->blk, n, h->d_substep_err, halo_timeout_ms(h), h->params_on_device, h->d_params);
+            const hipError_t le = hipGetLastError();
+            return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        });
+    }
     int rc = push_params(h, dt, params);
     if (rc) return rc;
     if ((rc = ensure_prediction(h, dt))) return rc;
@@ -794,7 +819,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
     // workgroups hold slots too.  Beside a body whose persistent launch needs most of the device resident AT ONCE the two deadlock until a
     // wait gives up: the frame kernel's resident tiles fill an XCD waiting for tiles that find no slot, the call kernel's workgroups fill the
     // rest waiting for a workgroup that is next in line on THAT XCD -- tools/soak.py, round 6.  Nothing is paid without such a body.)
-    if (h->frame || h->pj_one_launch || h->nh_one_launch)
+    if (h->frame || h->nh_one_launch)
         return launch_in_turn(h, [&]() -> int { HIPCHK(h, hipGraphLaunch(it->second, h->stream)); return 0; });
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return 0;
