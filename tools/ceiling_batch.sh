@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# The inputs of the bench line's rocprof / traffic / ceiling objects and of profiles/r05z_tet_kernel_ceiling.txt, on a GPU box:
+# The inputs of the bench line's rocprof / traffic / ceiling objects and of profiles/r06z_tet_kernel_ceiling.txt, on a GPU box:
 #   bash tools/ceiling_batch.sh <tag>   ->  gpurun_out/<tag>/{stats/, pmc/, iteration_floor.txt, tet_kernel_ceiling.{txt,json}, pmc_traffic.json, bench.json}
 set -u
 TAG=${1:-ceiling}

@@ -159,7 +159,7 @@ def main():
                        "vector-issue floor = SQ_INSTS_VALU per SIMD x measured issue cycles (3.15 plain, 8.8 transcendental) at 2.4 GHz",
                "kernel_sha": ker_sha, "memory_floor_us": res["memory_floor_us"], "valu_issue_floor_us": res["valu_issue_floor_us"],
                "valu_instructions_per_wave": round(res["counters"]["SQ_INSTS_VALU"] / res["counters"]["SQ_WAVES"], 1),
-               "source": "profiles/r05z_tet_kernel_ceiling.txt"}
+               "source": "profiles/r06z_tet_kernel_ceiling.txt"}
         i = args.index("--write")
         path = args[i + 1] if i + 1 < len(args) and not args[i + 1].startswith("--") else os.path.join(ROOT, "profiles", "tet_kernel_ceiling.json")
         with open(path, "w") as f:
