@@ -232,8 +232,9 @@ int tetsim_get_info(tetsim_handle h, TetSimInfo *info);
 /* Replaces `simulate(dt, physicsParams)` (Softbody.js:195-240 ; SoftbodyGPU.js:610-641): ONE substep,
  * enqueued on the handle's stream, no synchronisation. */
 int tetsim_step(tetsim_handle h, double dt, const TetSimParams *params);
-/* n substeps with the same dt/params/grab as one host call and one HIP-graph launch: the body of the
- * caller's substep loop (main.js:79-84). */
+/* n substeps with the same dt/params/grab as one host call and one launch: the body of the caller's substep loop (main.js:79-84).
+ * One replay of a captured HIP graph -- or, where the whole call is ONE kernel (TetSimInfo.fused_particle_pass 5: large
+ * unpartitioned POLAR_JACOBI FAST bodies), that kernel launched directly with the call's parameters among its arguments. */
 int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams *params);
 /* Block until everything enqueued on the handle's stream(s) has finished.  Partitioned bodies: TETSIM_ECOMM if a device-side
  * halo wait gave up (TETSIM_HALO_TIMEOUT_MS, 30 s by default: a stuck peer, or the two chains of a graph replay sharing one
