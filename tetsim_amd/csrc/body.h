@@ -36,7 +36,6 @@
 
 namespace tetsim {
 
-constexpr int kRing = 64;  // pinned parameter slots in flight
 // device words of the flag-synchronised halo path (binary semaphores): [0] G, [2] V, [3] re-prediction after a dt change, [4] error, [6] [7] queue probe
 constexpr uint32_t kSyncWords = 8;
 
@@ -163,12 +162,6 @@ struct tetsim_body {
     uint32_t halo_parity = 0;
     DevParams* d_params = nullptr;
     DevParams* d_params_halo = nullptr;   // the same parameters, copied on the HALO stream (its boundary-particle pass reads them)
-    DevParams* h_ring = nullptr;  // pinned [kRing]
-    hipEvent_t ring_ev[kRing] = {};
-    hipEvent_t ring_ev_halo[kRing] = {};
-    bool ring_used_halo[kRing] = {};
-    bool ring_used[kRing] = {};
-    int ring_pos = 0;
     std::vector<int32_t> tet_colour;  // copy of TetSimOptions.tet_colour (create only)
     int32_t grab_global = -1;
     int32_t grab_ref[2] = {-1, -1};  // particles the reference's indexFromUV pins for grab_global (TETSIM_FLAG_REF_GRAB_TEXEL)

@@ -176,8 +176,8 @@ struct NHFrameLaunch {
     uint32_t levels = 0, bodies = 0, block = 512;   // threads per workgroup, <= 512
     uint32_t max_body_particles = 0;       // x 40 bytes of LDS per workgroup
 };
-void nh_launch_frame_precise(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n);
-void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n);
+void nh_launch_frame_precise(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n, const DevParams& params, DevParams* params_dev);   // (parameters by value: pjb_launch_frame)
+void nh_launch_frame_fast(hipStream_t s, const NHDev& d, const NHFrameLaunch& f, uint32_t n, const DevParams& params, DevParams* params_dev);
 // levels of at most this many tets are solved on four lanes per tet by the single-workgroup launch of small bodies (and, FAST, by its
 // stepwise twin): 128 quads = two waves per SIMD in f32; f64 (PRECISE) runs at half rate, one wave per SIMD
 constexpr uint32_t kNHQuadLevelFast = 128, kNHQuadLevelPrecise = 64;
@@ -208,13 +208,14 @@ void pjb_launch_recover_quats(hipStream_t s, const PJBlk& d, const float4* rest0
 // on one XCD that way); local: the exchange of partial sums only has to be coherent inside one XCD's L2 (valid with such a
 // placement, see pjb_probe_xcd).  pbuf: the two partial-sum buffers; err: a device word raised if a neighbour tile's partial sums
 // did not appear within timeout_ms (never in a correct run: all workgroups are co-resident -- pjb_frame_capacity).
+// params / params_dev: the call's parameters travel with the launch (by value); its first workgroup leaves them in device memory.
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
-                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                      uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // ... and the same three entry points for SMALL bodies tiled into 64-tet tiles, one tet / one particle on four lanes (pj_quad.hip):
 // the persistent frame kernel, and its substep as two launches through memory (tetsim_step, tetsim_profile, fallback).  All three
 // agree bit for bit.  d.partial: the split kernels' partial sums; pbuf0 / pbuf1: the frame kernel's (sequence-numbered).
 void pjq_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
-                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                      uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjq_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void pjq_launch_vertex(hipStream_t s, const PJBlk& d, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 uint32_t pjq_frame_capacity(uint32_t* compute_units);              // workgroups of pjq_frame_kernel one CU keeps resident (0 = query failed)
@@ -270,6 +271,8 @@ void pjb_launch_vertex_await(hipStream_t s, const PJBlk& d, uint32_t first, uint
 
 void nh_launch_predict_precise(hipStream_t s, const NHDev& d);
 void nh_launch_predict_fast(hipStream_t s, const NHDev& d);
+void nh_launch_predict_value_precise(hipStream_t s, const NHDev& d, const DevParams& params, DevParams* params_dev);   // (the prediction that brings a call's parameters along)
+void nh_launch_predict_value_fast(hipStream_t s, const NHDev& d, const DevParams& params, DevParams* params_dev);
 void nh_launch_level_precise(hipStream_t s, const NHDev& d, uint32_t first, uint32_t count);
 void nh_launch_level_fast(hipStream_t s, const NHDev& d, uint32_t first, uint32_t count);
 void nh_launch_post_precise(hipStream_t s, const NHDev& d);
@@ -308,6 +311,7 @@ void util_launch_stream(hipStream_t s, int kind, bool nt, uint32_t unroll, uint3
 void util_launch_delay(hipStream_t s, uint32_t us);
 // tetsim_halo_p2p_probe: raise[k] = this rank's inbox word at neighbour k (peer memory), wait[k] = neighbour k's inbox word here
 struct P2PProbe { uint32_t* raise[kMaxPeers] = {}; uint32_t* wait[kMaxPeers] = {}; uint32_t n = 0; };
+void util_launch_set_params(hipStream_t s, DevParams* dst, const DevParams& v);   // the call's parameters into device memory, in stream order
 void util_launch_p2p_probe(hipStream_t s, const P2PProbe& p, uint32_t base, uint32_t reps, unsigned long long* ticks, uint32_t* error, uint32_t timeout_ms);   // loopback measurements: a stand-in for wire latency
 void util_launch_gather4(hipStream_t s, const float4* src, const int32_t* idx, float4* dst, uint32_t n);
 

@@ -438,7 +438,7 @@ void launch_tet_x(hipStream_t s, const PJBlk& d, uint32_t tile_first, uint32_t t
 // stores and cache-bypassing loads, coherent at the memory side (any placement).
 constexpr int kFrameIters = TETSIM_LAB_FRAME_ITERS;   // the product's compile-time constant, 9 (tools/mutation_check.sh mutates it for both kernels)
 template <int kMode, bool kLocal>
-__device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
+__device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const DevParams& P, const uint32_t n, const int32_t* const block_tile, float4* const pbuf0, float4* const pbuf1,
                                                uint32_t* const err, const uint32_t timeout_ms) {
     __shared__ float4 s_pos[kTile];
     __shared__ float s_gx[4 * kTile];
@@ -479,7 +479,6 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
     f3 prev = xyz(d.pos_final[vid]);
     const float wsum = d.wsum[vid];
     f3 stage = xyz(d.pos_pred[vid]);     // substep 0 starts from the prediction the previous call left
-    const DevParams& P = *d.params;
     const uint32_t epoch = d.epoch ? d.epoch : P.epoch;   // (a direct launch -- tetsim_step -- brings its own block of sequence numbers)
     const uint32_t first = range & 0x7ffu, last = range >> 16;
     const bool owner = has_slot && ((range >> 15) & 1u);
@@ -621,8 +620,9 @@ __device__ __forceinline__ void pjb_frame_body(const PJBlk& d, const uint32_t n,
 }
 #define TETSIM_FRAME_KERNEL(name, mode, local)                                                                                         \
     __global__ __launch_bounds__(kTile, 2) void name(PJBlk d, uint32_t n, const int32_t* block_tile, float4* pbuf0, float4* pbuf1, uint32_t* err, \
-                                                     uint32_t timeout_ms) {                                                            \
-        pjb_frame_body<mode, local>(d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);                                                  \
+                                                     uint32_t timeout_ms, DevParams pv, DevParams* pdev) {                             \
+        if (blockIdx.x == 0u && threadIdx.x == 0u) *pdev = pv; /* (parameters by value: see pjb_call_kernel) */                      \
+        pjb_frame_body<mode, local>(d, pv, n, block_tile, pbuf0, pbuf1, err, timeout_ms);                                              \
     }
 TETSIM_FRAME_KERNEL(pjb_frame_kernel, kModeCarried, false)
 TETSIM_FRAME_KERNEL(pjb_frame_kernel_constant_rest, kModeConstantRest, false)
@@ -951,13 +951,13 @@ void pjb_launch_call(hipStream_t s, const PJBlk& d, uint32_t n, uint32_t* err, u
 }
 void pjb_launch_tet_fused(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) { launch_tet_x(s, d, 0u, d.nb, TetFused{0u}, e0, e1); }
 void pjb_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
-                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
+                      uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0 || n == 0 || blocks == 0) return;
     const int mode = blk_mode(d);
     auto* kernel = local ? (mode == kModeConstantRest ? pjb_frame_kernel_constant_rest_local : mode == kModeLeanState ? pjb_frame_kernel_lean_local : pjb_frame_kernel_local)
                          : (mode == kModeConstantRest ? pjb_frame_kernel_constant_rest : mode == kModeLeanState ? pjb_frame_kernel_lean : pjb_frame_kernel);
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
-    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms, params, params_dev);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTile), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms, params, params_dev);
 }
 uint32_t pjb_frame_capacity(int mode, uint32_t* compute_units) {
     int per_cu = 0, dev = 0;

@@ -180,7 +180,7 @@ constexpr uint32_t kQMaxSrc = kQuadMaxPartials;   // partial sums per particle a
 
 // kLocal (frame kernel): every tile of a body sits on ONE XCD: the exchange is coherent in that XCD's L2 (dev_store.h)
 template <int kMode, bool kLocal>
-__device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const uint32_t b, float4* const pbuf0, float4* const pbuf1, uint32_t* const err,
+__device__ __forceinline__ void pjq_body(const PJBlk& d, const DevParams& P, const uint32_t n, const uint32_t b, float4* const pbuf0, float4* const pbuf1, uint32_t* const err,
                                          const uint32_t timeout_ms) {
     __shared__ float s_pos[4 * kQT];          // staged particle positions, xyzw per slot
     __shared__ float s_g[3 * 4 * kQT];        // V * goal, [component][corner][tet]
@@ -204,7 +204,6 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
     const uint32_t v0 = d.blk_vert_off[b], nu = d.blk_vert_off[b + 1] - v0;
     const bool has_slot = qd < nu, has_tet = qd < ntb;
     const uint32_t slot = v0 + (has_slot ? qd : 0u), e = t0 + (has_tet ? qd : 0u);
-    const DevParams& P = *d.params;
 
     // ---- what stays for the whole call (ids first: the particle loads depend on them) ------------------------------------------
     const uint32_t vid = static_cast<uint32_t>(d.blk_verts[slot]);
@@ -387,24 +386,27 @@ __device__ __forceinline__ void pjq_body(const PJBlk& d, const uint32_t n, const
 // (four waves per SIMD, i.e. at most 128 registers: four workgroups per CU put the Dragon's 62 tiles on ONE XCD -- 64 is half of an XCD's 128
 // slots -- where the exchange is an L2 trip; at 130 registers the tiles spread over all XCDs and the gather phase took 6.1 k instead of
 // 4.5 k cycles per substep, profiles/r04_quad_lanes.txt)
+// (The call's parameters arrive by value, with the launch -- no upload in front of a call, nothing between two calls: pjb_call_kernel,
+// pj_blocked.hip; the first workgroup leaves them in DevParams for the kernels behind this one.)
 template <bool kLocal>
 __global__ __launch_bounds__(kQThreads, 4) void pjq_frame_kernel(PJBlk d, uint32_t n, const int32_t* block_tile, float4* pbuf0, float4* pbuf1, uint32_t* err,
-                                                              uint32_t timeout_ms) {
+                                                              uint32_t timeout_ms, DevParams pv, DevParams* pdev) {
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *pdev = pv;
     const int32_t bt = block_tile[blockIdx.x];
     if (bt < 0) return;   // (a block that only pads the grid so that the others land on the intended XCDs)
-    pjq_body<kModeFrame, kLocal>(d, n, static_cast<uint32_t>(bt), pbuf0, pbuf1, err, timeout_ms);
+    pjq_body<kModeFrame, kLocal>(d, pv, n, static_cast<uint32_t>(bt), pbuf0, pbuf1, err, timeout_ms);
 }
-__global__ __launch_bounds__(kQThreads) void pjq_tet_kernel(PJBlk d) { pjq_body<kModeTet, false>(d, 1u, blockIdx.x, nullptr, nullptr, nullptr, 0u); }
-__global__ __launch_bounds__(kQThreads) void pjq_vertex_kernel(PJBlk d) { pjq_body<kModeVertex, false>(d, 1u, blockIdx.x, nullptr, nullptr, nullptr, 0u); }
+__global__ __launch_bounds__(kQThreads) void pjq_tet_kernel(PJBlk d) { pjq_body<kModeTet, false>(d, *d.params, 1u, blockIdx.x, nullptr, nullptr, nullptr, 0u); }
+__global__ __launch_bounds__(kQThreads) void pjq_vertex_kernel(PJBlk d) { pjq_body<kModeVertex, false>(d, *d.params, 1u, blockIdx.x, nullptr, nullptr, nullptr, 0u); }
 
 }  // namespace
 
 void pjq_launch_frame(hipStream_t s, const PJBlk& d, uint32_t n, const int32_t* block_tile, uint32_t blocks, bool local, float4* pbuf0, float4* pbuf1,
-                      uint32_t* err, uint32_t timeout_ms, hipEvent_t e0, hipEvent_t e1) {
+                      uint32_t* err, uint32_t timeout_ms, const DevParams& params, DevParams* params_dev, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0 || n == 0 || blocks == 0) return;
     auto* kernel = local ? pjq_frame_kernel<true> : pjq_frame_kernel<false>;
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kQThreads), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
-    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kQThreads), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms);
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(kQThreads), 0, s, e0, e1, 0, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms, params, params_dev);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kQThreads), 0, s, d, n, block_tile, pbuf0, pbuf1, err, timeout_ms, params, params_dev);
 }
 void pjq_launch_tet(hipStream_t s, const PJBlk& d, hipEvent_t e0, hipEvent_t e1) {
     if (d.nb == 0) return;

@@ -113,7 +113,7 @@ int next_epoch_block(tetsim_body* h) {
     return 0;
 }
 
-// Stage the parameters of this call into a pinned ring slot and copy them to the device in stream order.
+// The parameters of this call into DevParams, in stream order.
 int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reuse_ok) {
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, TETSIM_EINVAL, "dt must be a positive finite number");
@@ -129,27 +129,18 @@ int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reus
         now.epoch = h->params_on_device.epoch;
         if (std::memcmp(&now, &h->params_on_device, sizeof now) == 0) { h->fork_needed = true; return 0; }
     }
-    const int slot = h->ring_pos;
-    h->ring_pos = (h->ring_pos + 1) % kRing;
-    if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
-    if (h->ring_used_halo[slot]) { HIPCHK(h, hipEventSynchronize(h->ring_ev_halo[slot])); h->ring_used_halo[slot] = false; }
     if (int rc = next_epoch_block(h)) return rc;
     h->epoch_block_fresh = reuse_ok;   // (only tetsim_step passes reuse_ok: its frame launch may use this block instead of taking another;
                                        //  every other caller's launches consume the block the upload names)
-    fill_params(h, dt, *params, &h->h_ring[slot]);
-    HIPCHK(h, hipMemcpyAsync(h->d_params, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
-    h->params_on_device = h->h_ring[slot];
+    fill_params(h, dt, *params, &h->params_on_device);
     h->params_known = true;
-    HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
-    h->ring_used[slot] = true;
-    if (h->comm_stream && h->d_params_halo) {
-        // the halo queue runs the boundary particles itself (enqueue_phase_a) and is ordered against the main queue only through
-        // the semaphore words: it gets its own copy of the parameters, in ITS stream order
-        if (!h->ring_ev_halo[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->ring_ev_halo[slot], hipEventDisableTiming));
-        HIPCHK(h, hipMemcpyAsync(h->d_params_halo, &h->h_ring[slot], sizeof(DevParams), hipMemcpyHostToDevice, h->comm_stream));
-        HIPCHK(h, hipEventRecord(h->ring_ev_halo[slot], h->comm_stream));
-        h->ring_used_halo[slot] = true;
-    }
+    // (a one-lane kernel whose arguments are the parameters: in stream order like the copy it replaces, without the copy engine)
+    util_launch_set_params(h->stream, h->d_params, h->params_on_device);
+    // the halo queue runs the boundary particles itself (enqueue_phase_a) and is ordered against the main queue only through
+    // the semaphore words: it gets its own copy of the parameters, in ITS stream order
+    if (h->comm_stream && h->d_params_halo) util_launch_set_params(h->comm_stream, h->d_params_halo, h->params_on_device);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
     h->fork_needed = true;  // whatever the caller did on the main stream since the last call must be visible to the boundary stream
     return 0;
 }
@@ -169,6 +160,14 @@ int stage_params(tetsim_body* h, double dt, const TetSimParams* params) {
     h->params_known = true;
     h->fork_needed = true;
     return 0;
+}
+
+// ... for such a call: staged, unless its dt differs from the one the predictions on the device were made with -- the re-prediction kernel
+// in front of the call reads DevParams, so that call uploads as every other does.
+int params_for_launch(tetsim_body* h, double dt, const TetSimParams* params) {
+    const bool repredict = h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI && !h->pred_any_dt && static_cast<float>(dt) != h->dt_pred;
+    if (int rc = repredict ? push_params(h, dt, params) : stage_params(h, dt, params)) return rc;
+    return ensure_prediction(h, dt);
 }
 
 // ---- kernel sequencing ---------------------------------------------------------------------------------
@@ -307,8 +306,15 @@ int launch_in_turn(tetsim_body* h, F&& launch) {
 int launch_frame_kernel(tetsim_body* h, uint32_t n, uint32_t epoch) {
     PJBlk k = h->blk;
     k.epoch = epoch;
-    if (h->quad) pjq_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
-    else pjb_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h));
+    if (h->quad) pjq_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h), h->params_on_device, h->d_params);
+    else pjb_launch_frame(h->stream, k, n, h->d_block_tile, h->frame_blocks, h->frame_local, h->blk.partial, h->partial_b, h->d_frame_err, halo_timeout_ms(h), h->params_on_device, h->d_params);
+    const hipError_t le = hipGetLastError();
+    return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+}
+// the single-workgroup frame kernel of a small Neo-Hookean body for n substeps, the call's parameters among its arguments
+int launch_nh_frame_kernel(tetsim_body* h, uint32_t n) {
+    h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, n, h->params_on_device, h->d_params)
+            : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, n, h->params_on_device, h->d_params);
     const hipError_t le = hipGetLastError();
     return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
 }
@@ -412,24 +418,7 @@ int build_graph(tetsim_body* h, uint32_t n, hipGraphExec_t* out) {
         h->halo_pending = false;
         h->fork_needed = true;
     }
-    if (h->frame) {
-        // small unpartitioned bodies: the whole call is ONE persistent launch, every tile's workgroup resident for its n substeps
-        // (pj_blocked.hip: pjb_frame_kernel); the sequence numbers of its partial sums start at DevParams::epoch
-        rc = launch_frame_kernel(h, n, 0u);
-    } else if (h->nh_call && h->nh_one_launch) {
-        // clustered FAST Neo-Hookean bodies: prediction | the sweeps of all n substeps in ONE launch (nh_kernels.inc: nh_call_kernel) | the kernel that ends the call
-        nh_launch_predict_fast(h->stream, h->nh);
-        nh_launch_call_fast(h->stream, h->nh, h->nh_sweep1, n);
-        nh_launch_post_fast(h->stream, h->nh);
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
-    } else if (h->nh_frame) {
-        // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
-        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, n) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, n);
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
-    } else
-        for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
+    for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
     if (halo && !rc) {
         hipError_t je = hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0);  // join: the last transfer
         if (je != hipSuccess) rc = fail(h, TETSIM_EHIP, std::string("join: ") + hipGetErrorString(je));
@@ -575,9 +564,6 @@ int create_common(const float* verts, uint32_t nv, const int32_t* tets, uint32_t
             !hipok(hipEventCreateWithFlags(&h->ev_packed2[i], hipEventDisableTiming), "hipEventCreate") ||
             !hipok(hipEventCreateWithFlags(&h->ev_sent2[i], hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
     if (!hipok(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
-    for (int i = 0; i < kRing; i++)
-        if (!hipok(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming), "hipEventCreate")) return bail(TETSIM_EHIP);
-    if (!hipok(hipHostMalloc(reinterpret_cast<void**>(&h->h_ring), sizeof(DevParams) * kRing, hipHostMallocDefault), "hipHostMalloc")) return bail(TETSIM_EHIP);
     { int rc = dev_alloc(h, &h->d_params, 1); if (rc) return bail(rc); }
 
     TetSimOptions with_owner = o;  // vert_owner is only read during construction
@@ -671,11 +657,8 @@ void tetsim_destroy(tetsim_handle h) {
     for (PeerLink& l : h->links) for (void* m : l.ipc) if (m) (void)hipIpcCloseMemHandle(m);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* p : h->allocs) (void)hipFree(p);
-    if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->pinned_pos) (void)hipHostFree(h->pinned_pos);
     if (h->pinned_quat) (void)hipHostFree(h->pinned_quat);
-    for (int i = 0; i < kRing; i++) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
-    for (int i = 0; i < kRing; i++) if (h->ring_ev_halo[i]) (void)hipEventDestroy(h->ring_ev_halo[i]);
     for (hipEvent_t ev : {h->ev_a, h->ev_b, h->ev_halo, h->ev_boundary2[0], h->ev_boundary2[1], h->ev_packed2[0], h->ev_packed2[1],
                           h->ev_sent2[0], h->ev_sent2[1]}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {h->ev_fork, h->ev_bnd_tet}) if (ev) (void)hipEventDestroy(ev);
@@ -694,26 +677,21 @@ int tetsim_step(tetsim_handle h, double dt, const TetSimParams* params) {
     if (!h) return TETSIM_EINVAL;
     if (!h->group.empty()) return fail(h, TETSIM_ESTATE, "this body belongs to an in-process group: step it with tetsim_group_step_n");
     HIPCHK(h, hipSetDevice(h->opt.device));
-    int rc = push_params(h, dt, params, true);   // (unchanged parameters stay where they are; a frame kernel launched below brings its own sequence numbers)
-    if (rc) return rc;
-    if ((rc = ensure_prediction(h, dt))) return rc;
+    if (h->frame) {
+        // small polar bodies: a single substep is ONE launch too -- the persistent frame kernel for n = 1, its parameters (and with them a
+        // block of sequence numbers of its own) among its arguments: no upload, moving grab or not
+        if (int rc = params_for_launch(h, dt, params)) return rc;
+        return launch_in_turn(h, [&]() -> int { return launch_frame_kernel(h, 1u, 0u); });
+    }
     if (h->nh_frame) {
         // small Neo-Hookean bodies: also a single substep is ONE single-workgroup launch (a host that keeps the reference's loop,
         // main.js:79-84, pays one enqueue per substep instead of one per level: 34 on the Dragon); tetsim_profile keeps the level kernels
-        h->fast ? nh_launch_frame_fast(h->stream, h->nh, h->nh_frame_launch, 1u) : nh_launch_frame_precise(h->stream, h->nh, h->nh_frame_launch, 1u);
-        const hipError_t le = hipGetLastError();
-        return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        if (int rc = params_for_launch(h, dt, params)) return rc;
+        return launch_nh_frame_kernel(h, 1u);
     }
-    if (h->frame) {
-        // small polar bodies: a single substep is ONE launch too -- the persistent frame kernel for n = 1, with a block of sequence
-        // numbers of its own as a kernel argument (the parameters on the device may be the previous call's: see push_params)
-        // (push_params took a fresh block when it uploaded: the launch uses that one -- with a moving grab every call uploads, and a
-        // second block per call halved the time to the wrap of the sequence numbers; unchanged parameters: a block of its own)
-        if (!h->epoch_block_fresh && (rc = next_epoch_block(h))) return rc;
-        h->epoch_block_fresh = false;
-        const uint32_t epoch = h->frame_epoch;
-        return launch_in_turn(h, [&]() -> int { return launch_frame_kernel(h, 1u, epoch); });
-    }
+    int rc = push_params(h, dt, params, true);   // (unchanged parameters stay where they are)
+    if (rc) return rc;
+    if ((rc = ensure_prediction(h, dt))) return rc;
     if (h->nh_one_launch) {   // (the parameters on the device may be the previous call's: this launch brings its own block of stamps, like the frame kernel above)
         if (!h->epoch_block_fresh && (rc = next_epoch_block(h))) return rc;
         h->epoch_block_fresh = false;
@@ -750,16 +728,30 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
         }
     }
     HIPCHK(h, hipSetDevice(h->opt.device));
-    if (h->pj_one_launch && !has_transport(h)) {
-        // large unpartitioned polar bodies: the n substeps' tiles and particles in ONE grid, handed on by stamped data (pj_blocked.hip:
-        // pjb_call_kernel), launched directly -- one kernel needs no graph -- with the call's parameters among its arguments.  Only a call
-        // whose dt differs from the prediction's uploads them first: the re-prediction in front of it reads DevParams.
-        const bool repredict = !h->pred_any_dt && static_cast<float>(dt) != h->dt_pred;
-        int rc = repredict ? push_params(h, dt, params) : stage_params(h, dt, params);
-        if (rc) return rc;
-        if ((rc = ensure_prediction(h, dt))) return rc;
+    if (h->nh_call && h->nh_one_launch && !has_transport(h)) {
+        // clustered FAST Neo-Hookean bodies: prediction | the sweeps of all n substeps in ONE launch (nh_kernels.inc: nh_call_kernel) | the kernel
+        // that ends the call -- three direct launches, the first of which brings the call's parameters along
+        if (int rc = params_for_launch(h, dt, params)) return rc;
+        return launch_in_turn(h, [&]() -> int {
+            nh_launch_predict_value_fast(h->stream, h->nh, h->params_on_device, h->d_params);
+            nh_launch_call_fast(h->stream, h->nh, h->nh_sweep1, n);
+            nh_launch_post_fast(h->stream, h->nh);
+            const hipError_t le = hipGetLastError();
+            return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        });
+    }
+    if (h->nh_frame) {   // small Neo-Hookean bodies: the whole call is ONE single-workgroup launch with every particle in LDS (nh_kernels.inc: nh_frame_kernel)
+        if (int rc = params_for_launch(h, dt, params)) return rc;
+        return launch_nh_frame_kernel(h, n);
+    }
+    if ((h->frame || h->pj_one_launch) && !has_transport(h)) {
+        // Calls that are ONE kernel -- small polar bodies: the persistent frame kernel, every tile's workgroup resident for the n substeps
+        // (pjb_frame_kernel, pjq_frame_kernel); large ones: the n substeps' tiles and particles in one grid, handed on by stamped data
+        // (pjb_call_kernel) -- are launched directly, one kernel needs no graph, with the call's parameters among the arguments.
+        if (int rc = params_for_launch(h, dt, params)) return rc;
         // (in turn with an exclusive frame-kernel body, if one lives on this device: see the graph launch below)
         return launch_in_turn(h, [&]() -> int {
+            if (h->frame) return launch_frame_kernel(h, n, 0u);
             pjb_launch_call(h->stream, h->blk, n, h->d_substep_err, halo_timeout_ms(h), h->params_on_device, h->d_params);
             const hipError_t le = hipGetLastError();
             return le == hipSuccess ? 0 : fail(h, TETSIM_EHIP, std::string("kernel launch: ") + hipGetErrorString(le));
@@ -819,7 +811,7 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
     // workgroups hold slots too.  Beside a body whose persistent launch needs most of the device resident AT ONCE the two deadlock until a
     // wait gives up: the frame kernel's resident tiles fill an XCD waiting for tiles that find no slot, the call kernel's workgroups fill the
     // rest waiting for a workgroup that is next in line on THAT XCD -- tools/soak.py, round 6.  Nothing is paid without such a body.)
-    if (h->frame || h->nh_one_launch)
+    if (h->nh_one_launch)
         return launch_in_turn(h, [&]() -> int { HIPCHK(h, hipGraphLaunch(it->second, h->stream)); return 0; });
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return 0;

@@ -123,6 +123,11 @@ __global__ void p2p_probe_kernel(P2PProbe p, uint32_t base, uint32_t reps, unsig
 void util_launch_p2p_probe(hipStream_t s, const P2PProbe& p, uint32_t base, uint32_t reps, unsigned long long* ticks, uint32_t* error, uint32_t timeout_ms) {
     hipLaunchKernelGGL(p2p_probe_kernel, dim3(1), dim3(64), 0, s, p, base, reps, ticks, error, timeout_ms);
 }
+// A call's parameters into DevParams, in stream order: one lane, the 176 bytes arrive as kernel arguments.  (The copy this replaces --
+// pinned slot, hipMemcpyAsync, an event per slot -- put the copy engine between two compute launches: most of the ~18 us the device idled
+// in front of every call, tools/call_gap.py.)
+__global__ void set_params_kernel(DevParams v, DevParams* dst) { *dst = v; }
+void util_launch_set_params(hipStream_t s, DevParams* dst, const DevParams& v) { hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, s, v, dst); }
 void util_launch_delay(hipStream_t s, uint32_t us) {
     if (us) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, 100ll * us);
 }
