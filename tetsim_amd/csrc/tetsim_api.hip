@@ -113,6 +113,8 @@ int next_epoch_block(tetsim_body* h) {
     return 0;
 }
 
+constexpr uint32_t kDirectLaunchTets = 150000u;   // from here on a body's substeps are launched kernel by kernel instead of replayed from a graph (tetsim_step_n)
+
 // The parameters of this call into DevParams, in stream order.
 int push_params(tetsim_body* h, double dt, const TetSimParams* params, bool reuse_ok) {
     if (!params) return fail(h, TETSIM_EINVAL, "params is null");
@@ -790,6 +792,14 @@ int tetsim_step_n(tetsim_handle h, uint32_t n, double dt, const TetSimParams* pa
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sent2[h->halo_parity ^ 1u], 0));
             h->halo_pending = false;
         }
+    }
+    if (!has_transport(h) && !h->nh_one_launch && h->info.num_elems >= kDirectLaunchTets &&
+        (h->opt.solver == TETSIM_SOLVER_POLAR_JACOBI || h->info.num_levels <= 32u)) {   // (a Gauss-Seidel schedule of hundreds of small levels stays a graph)
+        // One queue and kernels of tens of microseconds each: the substeps' kernels go into the stream one by one.  A graph's replay ends
+        // with a completion signal that the next call's first kernel waits ~9 us for; kernel follows kernel without a gap, and the host
+        // (2-3 us per launch) stays ahead.  Small bodies keep their graphs: their kernels are shorter than a launch call.
+        for (uint32_t i = 0; i < n && !rc; i++) rc = enqueue_substep(h, i == 0, i + 1 == n);
+        return rc;
     }
     auto it = h->graphs.find(n);
     if (it == h->graphs.end()) {
