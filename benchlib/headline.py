@@ -380,7 +380,7 @@ def run(args, rank, world, local_rank, ranks):
         if floor_graph_us is not None and boundaries_us is not None:
             floor_win["in_graph"] = {"substep_us": round(floor_graph_us, 2), "kernel_us_implied": round(floor_graph_us - vert_us - boundaries_us, 2),
                                      "frac_implied": round(alg / ((floor_graph_us - vert_us - boundaries_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "what": "10 more frames as graph replays (wall clock) minus the particle kernel and the two launch boundaries of timed_region_check"}
+                                     "what": "10 more frames as tetsim_step_n calls (wall clock) minus the particle kernel and the two launch boundaries of timed_region_check"}
         ref_win = None
         if equal is not None:
             ref_win = window(equal["tet_us"], "the %d timed frames (%d launches) with the reference's rotation threshold (|omega| < 1e-9), per-launch events on a "
@@ -389,7 +389,7 @@ def run(args, rank, world, local_rank, ranks):
             if boundaries_us is not None:
                 imp = sub_ref - vert_us - boundaries_us
                 ref_win["in_graph"] = {"substep_us": round(sub_ref, 2), "kernel_us_implied": round(imp, 2), "frac_implied": round(alg / (imp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "what": "wall clock of the same frames as graph replays (value_reference_threshold) minus the particle kernel and the two launch "
+                                       "what": "wall clock of the same frames as tetsim_step_n calls (value_reference_threshold) minus the particle kernel and the two launch "
                                                "boundaries of timed_region_check; on the first frames after a body's creation the graphs run the iteration-heavy kernel "
                                                "slower than its per-launch events say (tools/attic/frame_series.py)"}
         # WHAT THE PRODUCT RUNS LEADS: the equal-work kernel INSIDE the graphs tetsim_step_n replays -- the timed
@@ -406,7 +406,7 @@ def run(args, rank, world, local_rank, ranks):
         elif "in_graph" in floor_win:
             ig = floor_win["in_graph"]
             lead = {"kernel_us": ig["kernel_us_implied"], "achieved": round(alg / (ig["kernel_us_implied"] * 1e-6) / 1e9, 1), "frac": ig["frac_implied"],
-                    "window": "ten frames on the floor as graph replays: " + ig["what"]}
+                    "window": "ten frames on the floor as tetsim_step_n calls: " + ig["what"]}
         achieved = lead["achieved"]
         out["roofline"] = {"bound": "hbm", "kernel": kname + ("" if world == 1 else " (rank 0, interior tiles)"),
                            "achieved": lead["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -458,14 +458,14 @@ def run(args, rank, world, local_rank, ranks):
             if boundaries_us is not None:   # what leads: the equal-work kernel inside the graphs (as for the reference formulation above)
                 imp = sub_ref_lean - lean["floor_vert_us"] - boundaries_us
                 rl.update({"kernel_us": round(imp, 2), "achieved": round(alg_lean / (imp * 1e-6) / 1e9, 1), "frac": round(alg_lean / (imp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                           "window": "the %d timed frames with the reference's rotation threshold as graph replays: wall clock per substep (%.2f us, median of three bodies) minus the "
+                           "window": "the %d timed frames with the reference's rotation threshold as tetsim_step_n calls: wall clock per substep (%.2f us, median of three bodies) minus the "
                                      "particle kernel (%.2f us) and the two launch boundaries (%.2f us)" % (args.steps, sub_ref_lean, lean["floor_vert_us"], boundaries_us)})
             else:
                 rl.update({"kernel_us": round(lean["floor_tet_us"], 2), "achieved": round(alg_lean / (lean["floor_tet_us"] * 1e-6) / 1e9, 1),
                            "frac": round(alg_lean / (lean["floor_tet_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "window": "on the floor, per-launch events"})
             ev = lambda us, what: {"kernel_us": round(us, 2), "achieved": round(alg_lean / (us * 1e-6) / 1e9, 1), "frac": round(alg_lean / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "window": what}   # noqa: E731
             rl["on_floor"] = dict(ev(lean["floor_tet_us"], "180 substeps on the floor (nine iterations in every tet), per-launch events, median of three batches of 60"),
-                                  in_graph={"substep_us": round(lean["floor_substep_us"], 2), "what": "ten more frames as graph replays, wall clock per substep"})
+                                  in_graph={"substep_us": round(lean["floor_substep_us"], 2), "what": "ten more frames as tetsim_step_n calls, wall clock per substep"})
             rl["timed_frames_reference_threshold"] = ev(lean["timed_tet_us"], "the %d timed frames (%d launches) with the reference's rotation threshold, per-launch events" % (args.steps, lean["timed_launches"]))
             rl["vertex_kernel_us"] = round(lean["floor_vert_us"], 2)
             rl["substep_frac_reference_threshold"] = round(b_alg_lean * out["value_lean_reference_threshold"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)
