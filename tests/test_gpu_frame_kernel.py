@@ -203,6 +203,30 @@ def test_an_exclusive_body_and_one_launch_calls_take_turns():
     together[0].sync()
 
 
+def test_the_blocks_of_sequence_numbers_wrap():
+    """Every call that hands data on by stamps takes a fresh block of 65,536 sequence numbers (tetsim_api.hip: next_epoch_block); after
+    65,534 blocks the 32-bit count starts over.  70,000 calls of one substep take a body through the wrap; its twin makes the same 70,000
+    substeps in 7,000 calls and stays far from it: the persistent frame kernel (Dragon, four lanes), the polar call kernel (486,680 tets)
+    and the Gauss-Seidel call kernel end bit-equal to their twins, and no wait gives up."""
+    dv, dt_ = load_mesh("dragon")
+    bv, bt = make_lattice(46, y0=0.05)
+    lv, lt = make_lattice(12, y0=0.05)
+    for make, path in ((lambda: SoftBodyHIP(dv, dt_, None, dict(PP), solver="polar", precision="fast"), 3),
+                       (lambda: SoftBodyHIP(bv, bt, None, dict(PP), solver="polar", precision="fast"), 5),
+                       (lambda: SoftBodyHIP(lv, lt, None, dict(PP), solver="neohookean", precision="fast", order="clustered"), 0)):
+        a, b = make(), make()
+        assert a.info.fused_particle_pass == b.info.fused_particle_pass == path
+        for _ in range(70000):
+            a.simulateSubsteps(1, DT, PP)
+        for _ in range(7000):
+            b.simulateSubsteps(10, DT, PP)
+        a.sync()
+        b.sync()
+        assert _same(a.pos, b.pos) and np.isfinite(a.pos).all(), path
+        a.close()
+        b.close()
+
+
 def _wheel(spokes):
     """`spokes` tets around a common axis (particles 0 and 1): both axis particles have valence `spokes`."""
     ang = np.linspace(0.0, 2.0 * np.pi, spokes, endpoint=False)
